@@ -1,0 +1,191 @@
+/*
+ * libshmgan_hip.so -- C ABI of the MI355X (gfx950) kernels behind SHMGAN's
+ * generator + discriminator train_step.
+ *
+ * The reference (Atif-Anwer/SHMGAN, /root/reference/ShmGANwithSSpecSeg.py = "SHM.py")
+ * has no FFI: every op below replaces a TensorFlow/Keras call made from Python.  Each
+ * entry point cites the reference call site it stands in for.  See INTEGRATION.md for
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - all tensors are float32, NHWC, device pointers (the caller owns every buffer, the
+ *    library never allocates device memory and keeps no pointer after return);
+ *  - "ld*" arguments are channel pitches in floats (>= the channel count; 16-float
+ *    aligned pitches let 3- and 10-channel images go through the MFMA path);
+ *  - "f64 scratch" arguments are small double accumulators the call zeroes itself;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return value: SHM_OK or a negative error; shm_last_error() gives the text.
+ */
+#ifndef SHMGAN_HIP_H
+#define SHMGAN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHM_OK 0
+#define SHM_E_SHAPE (-1)
+#define SHM_E_DTYPE (-2)
+#define SHM_E_WORKSPACE (-3)
+#define SHM_E_HIP (-4)
+
+int shm_version(void);
+const char* shm_last_error(void);
+
+/* ---- weight layout ---------------------------------------------------------------
+ * [ntaps][rows][cols] -> [ntaps][cols][rows_pad] (zero padded): HWIO -> K-contiguous
+ * [tap][Cout][Cin] for the implicit-GEMM B operand. */
+int shm_transpose_taps(const float* w, float* wt, int ntaps, int rows, int cols, int rows_pad,
+                       void* stream);
+
+/* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) -----------------------
+ * Keras Conv2D(k in {1,3}, strides in {1,2}, padding='same') + bias + LeakyReLU(slope)
+ * (SHM.py:244-245, 254-326, 365-369, 387).  Input = channel concat of x (c1 channels,
+ * pitch ldx) and optional x2 (cin-c1 channels, pitch ldx2): Concatenate() SHM.py:299,306,
+ * 313,320 is never materialised.  wk = [k*k][cout][cin] (shm_transpose_taps of HWIO),
+ * cin % 16 == 0.  bias may be NULL; slope 1.0f = no activation. */
+int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
+                   const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+                   int cout, int ksize, int stride, float slope, void* stream);
+
+/* Input-gradient of the same conv.  dy [batch,ho,wo,cout] (pitch lddy), w = HWIO
+ * [k*k][cin][cout] as stored (it is already K-contiguous for this product), cout % 16 == 0.
+ * dx channels [0,n1) go to dx (pitch lddx), [n1,cin) to dx2 (pitch lddx2): the split of a
+ * concat gradient.  Pass dx2=NULL, n1=cin for a single destination. */
+int shm_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, float* dx2, int n1,
+                     int lddx, int lddx2, int batch, int hi, int wi, int cin, int cout,
+                     int ksize, int stride, void* stream);
+
+/* Keras Conv2DTranspose(k=3, strides=2, 'same') + bias + LeakyReLU (SHM.py:298,305,312,319).
+ * x [batch,hi,wi,cin]; w = Keras layout [3][3][cout][cin] as stored; y [batch,2hi,2wi,cout]. */
+int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                             int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
+                             void* stream);
+
+/* Weight gradient: dw[t][ci][co] (+)= sum_pixels x[pix*stride + tap][ci] * dy[pix][co]
+ * (HWIO).  For Conv2DTranspose pass x = dz of the transposed conv (2H res), dy = its input
+ * (H res), stride 2: the result is the Keras [3][3][cout][cin] layout.  cin_ld = number of
+ * input channels to read (multiple of 4, pad channels must be zero), cin = rows stored.
+ * workspace: split-K partial slabs, at least shm_conv2d_wgrad_workspace() bytes. */
+size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize);
+int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* dy,
+                     int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
+                     int cout, int ksize, int stride, int accumulate, void* workspace,
+                     size_t ws_bytes, void* stream);
+
+/* ---- InstanceNormalization (tfa, axis=-1, eps, gamma==1, constant beta) -----------
+ * SHM.py:245...:388; op chain Generator_summary.txt:9-36.
+ * stats = f64 [batch*c*2]; on return (stream order) stats[(n*c+ch)*2] = mean over H*W,
+ * stats[(n*c+ch)*2+1] = rsqrt(biased variance + eps). */
+int shm_in_stats(const float* a, int lda, double* stats, int batch, int hw, int c, float eps,
+                 void* stream);
+/* out = (a - mean) * inv + beta[c]  (out may alias a). */
+int shm_in_apply(const float* a, int lda, const double* stats, const float* beta, float* out,
+                 int ldo, int batch, int hw, int c, void* stream);
+/* Backward of LeakyReLU -> IN given the gradient at the IN output:
+ *   d_out = g1 + 0.25 * g2[h/2][w/2]   (g2 = gradient of AveragePooling2D(2,2), may be NULL)
+ *   dz = lrelu'(a) * inv * (d_out - mean(d_out) - xhat * mean(d_out * xhat))
+ * red = f64 scratch [batch*c*2]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL). */
+int shm_in_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* a, int lda,
+               const double* stats, double* red, float* dz, int lddz, double* dbias, int batch,
+               int h, int w, int c, float slope, void* stream);
+
+/* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y). */
+int shm_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz,
+                  double* dbias, size_t npix, int c, float slope, void* stream);
+
+/* AveragePooling2D(2,2,'same') on even sizes (SHM.py:249,258,267,276). */
+int shm_avgpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int h, int w, int c,
+                     void* stream);
+
+/* f64 accumulator -> f32 (dst = or += src). */
+int shm_cvt_f64_f32(const double* src, float* dst, size_t n, int accumulate, void* stream);
+int shm_zero(void* p, size_t bytes, void* stream);
+
+/* ---- 1-output-channel layers ------------------------------------------------------
+ * Generator head Conv2D(1, k=1) + LeakyReLU (SHM.py:326). */
+int shm_head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, size_t npix,
+                 int c, float slope, void* stream);
+/* dz = dy*lrelu'(y); dx = dz (x) w; dw_acc[c] += sum x*dz; db_acc[0] += sum dz (f64, not zeroed). */
+int shm_head_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dx,
+                 int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope,
+                 void* stream);
+/* PatchGAN logits Conv2D(1, k=3, no bias) + LeakyReLU (SHM.py:365-369). x [batch,h,w,c]. */
+int shm_patch_fwd(const float* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,
+                  float slope, void* stream);
+/* dz = dy*lrelu'(y) (written to dz [batch,h,w]); dx = transposed conv of dz (overwritten);
+ * dw[9*c] = sum x*dz (overwritten; may be NULL). */
+int shm_patch_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
+                  float* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope,
+                  void* stream);
+/* Flatten + Dense(5, no bias) (SHM.py:371-375): logits[n][j] = sum_k x[n][k] * w[k][j]. */
+int shm_dense_fwd(const float* x, const float* w, float* y, int batch, int k, int nout, void* stream);
+/* dx[n][k] += sum_j dy[n][j]*w[k][j] (accumulates onto dx); dw[k][j] = sum_n x[n][k]*dy[n][j]
+ * (dw may be NULL). */
+int shm_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int batch,
+                  int k, int nout, void* stream);
+/* Dropout(0.2) as keep-mask multiply (SHM.py:363): y = x * mask * scale. */
+int shm_mul_mask(const float* x, const float* mask, float* y, size_t n, float scale, void* stream);
+
+/* ---- colour / standardisation / input assembly (SHM.py:480-531, 544-553, 576-624) -- */
+/* tf.image.rgb_to_yuv + custom_per_image_standardization (SHM.py:1271-1309), per sample.
+ * acc = f64 scratch [batch*2]; scale_out[batch] receives max(std, 1/256). */
+int shm_rgb2yuv_std(const float* rgb, float* yuv, double* acc, float* scale_out, int batch,
+                    size_t npix, void* stream);
+/* averageCbCr (SHM.py:505): out[b,p,0:2] = mean_k yuv_k[b,p,1:3]. */
+int shm_avg_cbcr(const float* y0, const float* y1, const float* y2, const float* y3,
+                 const float* y4, float* out, size_t n_pix_total, void* stream);
+/* 10-channel generator inputs in a 16-float pitch (SHM.py:517-531, 576-594).
+ * mode 0: G(1) input  -> out [batch,...]: view k = flags[k] ? 0 : Y_k ; one-hot tail = ED.
+ * mode 1: cyclic inputs -> out [5*batch,...] (k-major): view j = (j==k) ? 0 : (flags[j] ? genY : Y_j);
+ * one-hot k.  yuv_k are the standardised [batch,S,S,3] tensors, genY [batch,S,S,1]. */
+int shm_build_gen_input(const float* y0, const float* y1, const float* y2, const float* y3,
+                        const float* y4, const float* gen_y, int flags_mask, int mode, float* out,
+                        int batch, size_t npix, void* stream);
+/* Gradient of the cyclic inputs back into genY (G o G chain): dgenY[b,p] += sum over k, j!=k with
+ * flags[j] of dcyc[k*batch+b, p, j]. */
+int shm_cyc_input_bwd(const float* dcyc, int flags_mask, float* dgen_y, int batch, size_t npix,
+                      void* stream);
+/* tf.image.yuv_to_rgb of concat([Y, avgCbCr]) (SHM.py:544-553, 613-624) for nimg = reps*batch
+ * images (image i uses cbcr[i % batch]); writes rgb [nimg,S,S,3] and, if dpad != NULL, the
+ * 16-pitch discriminator input (rgb + optional GaussianNoise `noise` [nimg,S,S,3], SHM.py:352). */
+int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, float* dpad,
+                int nimg, int batch, size_t npix, void* stream);
+/* Pack raw rgb [nimg,S,S,3] (+ noise) into the 16-pitch discriminator input. */
+int shm_pack_rgb16(const float* rgb, const float* noise, float* dpad, size_t npix_total, void* stream);
+/* dY[i,p] (+)= sum_c d_rgb16[i,p,c], c<3 (yuv_to_rgb backward: every channel has dRGB/dY = 1). */
+int shm_rgb16_to_dy(const float* d16, float* dy, size_t npix_total, int accumulate, void* stream);
+
+/* ---- losses (SHM.py:669-844) ------------------------------------------------------
+ * Discriminator-head losses and their gradients.  Sample order in the D batch:
+ * [D1: B][D3: 5B, k-major][D2: B][D4: 5B, k-major].  rf [12B, np], cls [12B,5].
+ * Outputs: loss[16] (f64 sums over the batch of: D1_RF, D3_RF, D2_RF, D4_RF, D1_cls, D3_cls,
+ * D4_cls), drf_D/dcls_D = gradient of mean_b(total_D+total_Class), drf_G [6B,np] = gradient of
+ * mean_b((D1_RF + D3_RF)/6). */
+int shm_dhead_losses(const float* rf, const float* cls, double* loss, float* drf_d, float* dcls_d,
+                     float* drf_g, int batch, int np, float target, void* stream);
+/* Image-space generator losses + gradient wrt the generated Y planes.
+ * gen_rgb [B,S,S,3], cyc_rgb [5B,S,S,3] (k-major), cyc_y [5B,S,S,1], cbcr [B,S,S,2],
+ * orig_k [B,S,S,3] raw rgb, ds_k [B,S,S,3] standardised yuv.
+ * loss (f64 [32]): sums over the batch, see shmgan_amd/losses.py for the slot map.
+ * dgen_y [B,S,S,1], dcyc_y [5B,S,S,1] are overwritten with d mean_b(10*L1 + 10*ssim + 10*NST).
+ * ws: f64/f32 scratch of shm_image_losses_workspace() bytes. */
+size_t shm_image_losses_workspace(int batch, int s);
+int shm_image_losses(const float* gen_rgb, const float* cyc_rgb, const float* cyc_y,
+                     const float* cbcr, const float* const* orig, const float* const* ds,
+                     int flags_mask, float style_factor, double* loss, float* dgen_y, float* dcyc_y,
+                     void* ws, size_t ws_bytes, int batch, int s, void* stream);
+
+/* ---- optimizer (SHM.py:169-175, 859-872) ------------------------------------------
+ * tf.clip_by_value(g,-1,1) + Keras adam_v2.Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
+ * w -= alpha * m / (sqrt(v) + eps); alpha = lr_t*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
+ * gscale multiplies g before the clip (1/world_size for data parallel). */
+int shm_adam_clip(float* w, float* m, float* v, const float* g, size_t n, float alpha, float beta1,
+                  float beta2, float eps, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHMGAN_HIP_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of libshmgan_hip.so (the C ABI declared in include/shmgan_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails
+this module raises.  `build()` (re)compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libshmgan_hip.so"
+CSRC = _HERE / "csrc"
+HEADER = _HERE.parent / "include" / "shmgan_hip.h"
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
+               "-Wall", "-Wno-unused-function"]
+
+P, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); must mirror include/shmgan_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "shm_version": (I, []),
+    "shm_last_error": (C.c_char_p, []),
+    "shm_transpose_taps": (I, [P, P, I, I, I, I, P]),
+    "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P]),
+    "shm_conv2d_dgrad": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "shm_conv2d_transpose_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, P]),
+    "shm_conv2d_wgrad_workspace": (Z, [I, I, I, I, I, I]),
+    "shm_conv2d_wgrad": (I, [P, P, I, I, I, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "shm_in_stats": (I, [P, I, P, I, I, I, F, P]),
+    "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, P]),
+    "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, P]),
+    "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, Z, I, F, P]),
+    "shm_avgpool2_fwd": (I, [P, I, P, I, I, I, I, I, P]),
+    "shm_cvt_f64_f32": (I, [P, P, Z, I, P]),
+    "shm_zero": (I, [P, Z, P]),
+    "shm_head_fwd": (I, [P, I, P, P, P, Z, I, F, P]),
+    "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, Z, I, F, P]),
+    "shm_patch_fwd": (I, [P, I, P, P, I, I, I, I, F, P]),
+    "shm_patch_bwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, F, P]),
+    "shm_dense_fwd": (I, [P, P, P, I, I, I, P]),
+    "shm_dense_bwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "shm_mul_mask": (I, [P, P, P, Z, F, P]),
+    "shm_rgb2yuv_std": (I, [P, P, P, P, I, Z, P]),
+    "shm_avg_cbcr": (I, [P, P, P, P, P, P, Z, P]),
+    "shm_build_gen_input": (I, [P, P, P, P, P, P, I, I, P, I, Z, P]),
+    "shm_cyc_input_bwd": (I, [P, I, P, I, Z, P]),
+    "shm_yuv2rgb": (I, [P, P, P, P, P, I, I, Z, P]),
+    "shm_pack_rgb16": (I, [P, P, P, Z, P]),
+    "shm_rgb16_to_dy": (I, [P, P, Z, I, P]),
+    "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "shm_image_losses_workspace": (Z, [I, I]),
+    "shm_image_losses": (I, [P, P, P, P, P, P, I, F, P, P, P, P, Z, I, I, P]),
+    "shm_adam_clip": (I, [P, P, P, P, Z, F, F, F, F, F, P]),
+}
+
+
+def header_functions():
+    """Names declared in include/shmgan_hip.h (used by the ABI test)."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return re.findall(r"\b(shm_[a-z0-9_]+)\s*\(", txt)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into libshmgan_hip.so with hipcc (cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / "common.h", HEADER]
+    if not force and LIB_PATH.exists():
+        newest = max(p.stat().st_mtime for p in deps)
+        if LIB_PATH.stat().st_mtime >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, *map(str, srcs), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it is missing: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  shmgan_amd has no CPU/PyTorch fallback.")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class ShmError(RuntimeError):
+    pass
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = lib().shm_last_error()
+        raise ShmError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,382 @@
+// Implicit-GEMM convolution family on v_mfma_f32_32x32x2_f32 (gfx950, exact fp32).
+//
+// One kernel ("tap GEMM") serves Conv2D forward (k=1/3, stride 1/2), its input-gradient
+// (stride 1: flipped taps; stride 2: four output phases) and Conv2DTranspose forward
+// (= input-gradient of the stride-2 conv):
+//
+//     out[pix(m), n] = act( bias[n] + sum_{tap} sum_{k<K} A[src(m, tap), k] * B[tap][n][k] )
+//
+//   M = batch * grid_h * grid_w output positions of one phase, N = output channels,
+//   K = channels of the A tensor (multiple of 16).  A is NHWC (optionally the channel
+//   concat of two tensors), B is [tap][N][K] (K contiguous), so both operands are staged
+//   as rows of 16 consecutive floats: 16-byte global loads, ds_write_b128 into LDS rows
+//   padded to 20 floats (conflict-free ds_read_b128 per 16-lane group), and each lane
+//   feeds four consecutive MFMAs from one 16-byte LDS read (the k order inside an 8-wide
+//   group is permuted identically for A and B, which a dot product does not see).
+//
+// Block = 256 threads = 2x2 waves, tile BM x BN (128x64 or 128x128), BK = 16, two LDS
+// stages, register prefetch of the next stage's global loads under the current MFMAs.
+#include "common.h"
+
+struct TapPhase {
+    int oph, opw, ntaps;
+    int dh[9], dw[9], widx[9];
+};
+
+struct TapGemmArgs {
+    const float* x;   // A source 1 [batch, hi, wi, c1]   pitch ldx
+    const float* x2;  // A source 2 [batch, hi, wi, K-c1] pitch ldx2 (or unused, c1 == K)
+    int c1, ldx, ldx2;
+    const float* w;     // [taps][nout][K]
+    const float* bias;  // [nout] or null
+    float* y;           // channels [0,n1)
+    float* y2;          // channels [n1,nout)
+    int n1, ldy, ldy2;
+    int hi, wi, K;      // A tensor dims
+    int hg, wg;         // output grid of one phase
+    int ho, wo, nout;   // full output dims
+    int is, os;         // A stride, output stride
+    int M;              // batch*hg*wg
+    float slope;
+    TapPhase ph[4];
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
+    constexpr int LDK = 20;          // 16 + 4 pad floats per LDS row
+    constexpr int AR = BM / 64;      // A rows staged per thread
+    constexpr int BR = BN / 64;      // B rows staged per thread
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+
+    const TapPhase& P = a.ph[blockIdx.z];
+    const int tid = threadIdx.x, quad = tid & 3, lrow = tid >> 2;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    int pixbase[AR], ih0[AR], iw0[AR];
+    bool mval[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        int m = m0 + lrow + 64 * j;
+        mval[j] = m < a.M;
+        int mm = mval[j] ? m : 0;
+        int ow = mm % a.wg, t = mm / a.wg;
+        int oh = t % a.hg, n = t / a.hg;
+        ih0[j] = oh * a.is;
+        iw0[j] = ow * a.is;
+        pixbase[j] = (n * a.hi + ih0[j]) * a.wi + iw0[j];
+    }
+
+    const int nchunks = a.K >> 4;
+    const int ksteps = P.ntaps * nchunks;
+
+    f32x4 ra[AR], rb[BR];
+    auto gload = [&](int s) {
+        int chunk = s / P.ntaps, tap = s - chunk * P.ntaps;
+        int c0 = chunk << 4;
+        const float* src = a.x;
+        int ld = a.ldx, cc = c0;
+        if (c0 >= a.c1) {
+            src = a.x2;
+            ld = a.ldx2;
+            cc = c0 - a.c1;
+        }
+        const int dh = P.dh[tap], dw = P.dw[tap];
+        const int doff = dh * a.wi + dw;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            int ih = ih0[j] + dh, iw = iw0[j] + dw;
+            bool ok = mval[j] && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(src + (size_t)(pixbase[j] + doff) * ld + cc + quad * 4);
+            ra[j] = v;
+        }
+        const float* wb = a.w + (size_t)P.widx[tap] * a.nout * a.K + c0 + quad * 4;
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            int nn = n0 + lrow + 64 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < a.nout) v = *(const f32x4*)(wb + (size_t)nn * a.K);
+            rb[j] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) *(f32x4*)(&As[buf][(lrow + 64 * j) * LDK + quad * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *(f32x4*)(&Bs[buf][(lrow + 64 * j) * LDK + quad * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int s = 0; s < ksteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < ksteps) gload(s + 1);
+        const float* Ab = &As[buf][(wm * WM + l31) * LDK + h * 4];
+        const float* Bb = &Bs[buf][(wn * WN + l31) * LDK + h * 4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < ksteps) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + LeakyReLU + store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    const bool direct = (a.os == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * WM + i * 32 + row;
+            if (m >= a.M) continue;
+            size_t opix;
+            if (direct) {
+                opix = (size_t)m;
+            } else {
+                int ow = m % a.wg, t = m / a.wg;
+                int oh = t % a.hg, n = t / a.hg;
+                opix = ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 32 + l31;
+                if (n < a.nout) {
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    v = shm_lrelu(v, a.slope);
+                    if (n < a.n1)
+                        a.y[opix * a.ldy + n] = v;
+                    else
+                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
+                }
+            }
+        }
+    }
+}
+
+static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
+    SHM_REQUIRE(a.K % 16 == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of 16", who, a.K);
+    SHM_REQUIRE(a.c1 % 16 == 0, SHM_E_SHAPE, "%s: concat split %d must be a multiple of 16", who, a.c1);
+    SHM_REQUIRE(a.ldx % 4 == 0 && (a.x2 == nullptr || a.ldx2 % 4 == 0), SHM_E_SHAPE, "%s: input pitch must be a multiple of 4", who);
+    SHM_REQUIRE((size_t)batch * a.hi * a.wi < (1u << 31) && (size_t)batch * a.ho * a.wo < (1u << 31), SHM_E_SHAPE, "%s: pixel count overflows int32", who);
+    a.M = batch * a.hg * a.wg;
+    if (a.M == 0 || a.nout == 0) return SHM_OK;
+    if (a.nout > 64) {
+        dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<128, 128>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 64), nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<128, 64>), grid, dim3(256), 0, st, a);
+    }
+    SHM_LAUNCH_CHECK(who);
+    return SHM_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// [ntaps][rows][cols] -> [ntaps][cols][rows_pad]
+__global__ void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols, int rows_pad) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const float* src = w + (size_t)t * rows * cols;
+    float* dst = wt + (size_t)t * cols * rows_pad;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < cols && r < rows_pad) dst[(size_t)c * rows_pad + r] = tile[threadIdx.x][i];
+    }
+}
+
+extern "C" int shm_transpose_taps(const float* w, float* wt, int ntaps, int rows, int cols, int rows_pad, void* stream) {
+    SHM_REQUIRE(rows_pad >= rows && ntaps > 0 && rows > 0 && cols > 0, SHM_E_SHAPE, "shm_transpose_taps: bad shape");
+    dim3 grid(shm_cdiv(cols, 32), shm_cdiv(rows_pad, 32), ntaps);
+    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, w, wt, rows, cols, rows_pad);
+    SHM_LAUNCH_CHECK("shm_transpose_taps");
+    return SHM_OK;
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
+                              const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+                              int cout, int ksize, int stride, float slope, void* stream) {
+    SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_fwd: ksize %d not in {1,3}", ksize);
+    SHM_REQUIRE(stride == 1 || stride == 2, SHM_E_SHAPE, "shm_conv2d_fwd: stride %d not in {1,2}", stride);
+    SHM_REQUIRE(x && wk && y, SHM_E_SHAPE, "shm_conv2d_fwd: null pointer");
+    TapGemmArgs a{};
+    a.x = x;
+    a.x2 = x2;
+    a.c1 = x2 ? c1 : cin;
+    a.ldx = ldx;
+    a.ldx2 = ldx2;
+    a.w = wk;
+    a.bias = bias;
+    a.y = y;
+    a.y2 = nullptr;
+    a.n1 = cout;
+    a.ldy = ldy;
+    a.ldy2 = 0;
+    a.hi = hi;
+    a.wi = wi;
+    a.K = cin;
+    int ho, wo, pt, pl;
+    shm_same_pad(hi, ksize, stride, &ho, &pt);
+    shm_same_pad(wi, ksize, stride, &wo, &pl);
+    a.hg = a.ho = ho;
+    a.wg = a.wo = wo;
+    a.nout = cout;
+    a.is = stride;
+    a.os = 1;
+    a.slope = slope;
+    TapPhase& P = a.ph[0];
+    P.oph = P.opw = 0;
+    P.ntaps = ksize * ksize;
+    for (int kh = 0; kh < ksize; ++kh)
+        for (int kw = 0; kw < ksize; ++kw) {
+            int t = kh * ksize + kw;
+            P.dh[t] = kh - pt;
+            P.dw[t] = kw - pl;
+            P.widx[t] = t;
+        }
+    return launch_tapgemm(a, batch, 1, (hipStream_t)stream, "shm_conv2d_fwd");
+}
+
+// Transposed stride-2 product shared by Conv2DTranspose forward and the stride-2 dgrad:
+//   out[2a+ph] = sum_{k : k = ph+pt (mod 2)} A[a + (ph+pt-k)/2] * B[k]
+static void fill_s2_phases(TapGemmArgs& a, int pt, int pl) {
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            TapPhase& P = a.ph[ph * 2 + pw];
+            P.oph = ph;
+            P.opw = pw;
+            int nt = 0;
+            for (int kh = 0; kh < 3; ++kh) {
+                if (((ph + pt - kh) & 1) != 0) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (((pw + pl - kw) & 1) != 0) continue;
+                    P.dh[nt] = (ph + pt - kh) / 2;   // exact
+                    P.dw[nt] = (pw + pl - kw) / 2;
+                    P.widx[nt] = kh * 3 + kw;
+                    ++nt;
+                }
+            }
+            P.ntaps = nt;
+        }
+}
+
+extern "C" int shm_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, float* dx2, int n1,
+                                int lddx, int lddx2, int batch, int hi, int wi, int cin, int cout,
+                                int ksize, int stride, void* stream) {
+    SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_dgrad: ksize %d not in {1,3}", ksize);
+    SHM_REQUIRE(stride == 1 || (stride == 2 && ksize == 3), SHM_E_SHAPE, "shm_conv2d_dgrad: stride %d unsupported", stride);
+    SHM_REQUIRE(dy && w && dx, SHM_E_SHAPE, "shm_conv2d_dgrad: null pointer");
+    int ho, wo, pt, pl;
+    shm_same_pad(hi, ksize, stride, &ho, &pt);
+    shm_same_pad(wi, ksize, stride, &wo, &pl);
+    TapGemmArgs a{};
+    a.x = dy;
+    a.x2 = nullptr;
+    a.c1 = cout;
+    a.ldx = lddy;
+    a.w = w;            // HWIO [t][cin][cout] == [t][N=cin][K=cout]
+    a.bias = nullptr;
+    a.y = dx;
+    a.y2 = dx2;
+    a.n1 = dx2 ? n1 : cin;
+    a.ldy = lddx;
+    a.ldy2 = lddx2;
+    a.hi = ho;
+    a.wi = wo;
+    a.K = cout;
+    a.ho = hi;
+    a.wo = wi;
+    a.nout = cin;
+    a.is = 1;
+    a.slope = 1.f;
+    if (stride == 1) {
+        a.hg = hi;
+        a.wg = wi;
+        a.os = 1;
+        TapPhase& P = a.ph[0];
+        P.oph = P.opw = 0;
+        P.ntaps = ksize * ksize;
+        for (int kh = 0; kh < ksize; ++kh)
+            for (int kw = 0; kw < ksize; ++kw) {
+                int t = kh * ksize + kw;
+                P.dh[t] = pt - kh;   // dx[p] = sum_t dy[p - (k - pad)] * W_t^T
+                P.dw[t] = pl - kw;
+                P.widx[t] = t;
+            }
+        return launch_tapgemm(a, batch, 1, (hipStream_t)stream, "shm_conv2d_dgrad");
+    }
+    SHM_REQUIRE(hi % 2 == 0 && wi % 2 == 0, SHM_E_SHAPE, "shm_conv2d_dgrad: stride 2 needs even input size");
+    a.hg = hi / 2;
+    a.wg = wi / 2;
+    a.os = 2;
+    fill_s2_phases(a, pt, pl);
+    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_dgrad");
+}
+
+extern "C" int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                                        int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
+                                        void* stream) {
+    SHM_REQUIRE(x && w && y, SHM_E_SHAPE, "shm_conv2d_transpose_fwd: null pointer");
+    // the stride-2 SAME conv that maps [2hi,2wi] back to [hi,wi] has pad_before = 0
+    int ho2, wo2, pt, pl;
+    shm_same_pad(2 * hi, 3, 2, &ho2, &pt);
+    shm_same_pad(2 * wi, 3, 2, &wo2, &pl);
+    TapGemmArgs a{};
+    a.x = x;
+    a.x2 = nullptr;
+    a.c1 = cin;
+    a.ldx = ldx;
+    a.w = w;            // Keras [t][cout][cin] == [t][N=cout][K=cin]
+    a.bias = bias;
+    a.y = y;
+    a.y2 = nullptr;
+    a.n1 = cout;
+    a.ldy = ldy;
+    a.hi = hi;
+    a.wi = wi;
+    a.K = cin;
+    a.hg = hi;
+    a.wg = wi;
+    a.ho = 2 * hi;
+    a.wo = 2 * wi;
+    a.nout = cout;
+    a.is = 1;
+    a.os = 2;
+    a.slope = slope;
+    fill_s2_phases(a, pt, pl);
+    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_transpose_fwd");
+}

@@ -1,0 +1,583 @@
+// HBM-bound kernels around the convolutions: InstanceNormalization statistics / apply /
+// backward (fused with LeakyReLU' and the AveragePooling2D gradient), pooling, the
+// 1-output-channel layers (generator head, PatchGAN logits, Dense(5)), dropout mask.
+//
+// Layout: NHWC with a channel pitch; every thread moves 16 bytes (4 channels of one
+// pixel); a block covers PP = 256/(C/4) pixels per iteration, so a wave reads whole
+// contiguous channel rows.  Per-(sample,channel) sums are accumulated in fp64 per thread,
+// combined through LDS and added with one f64 atomic per (block, channel).
+#include "common.h"
+
+#include <stdarg.h>
+
+// ---------------------------------------------------------------------------- core API
+static thread_local char g_err[512] = "";
+
+void shm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* shm_last_error(void) { return g_err; }
+extern "C" int shm_version(void) { return 100; }
+
+extern "C" int shm_zero(void* p, size_t bytes, void* stream) {
+    if (bytes == 0) return SHM_OK;
+    hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+    SHM_REQUIRE(e == hipSuccess, SHM_E_HIP, "shm_zero: %s", hipGetErrorString(e));
+    return SHM_OK;
+}
+
+__global__ void cvt_f64_f32_kernel(const double* __restrict__ s, float* __restrict__ d, size_t n, int acc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (acc ? d[i] : 0.f) + (float)s[i];
+}
+
+extern "C" int shm_cvt_f64_f32(const double* src, float* dst, size_t n, int accumulate, void* stream) {
+    if (n == 0) return SHM_OK;
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, accumulate);
+    SHM_LAUNCH_CHECK("shm_cvt_f64_f32");
+    return SHM_OK;
+}
+
+// ------------------------------------------------------------------ pixel-chunk skeleton
+// thread -> (pp, cl): pixel slot and 4-channel lane.  PP pixel slots per block iteration.
+struct PixMap {
+    int lanes_c, PP, pp, cl;
+    bool active;
+    __device__ PixMap(int c) {
+        lanes_c = c >> 2;
+        PP = 256 / lanes_c;
+        pp = threadIdx.x / lanes_c;
+        cl = threadIdx.x - pp * lanes_c;
+        active = pp < PP;
+    }
+};
+
+static int pix_chunks(long npix_per_sample, int batch, int c) {
+    int lanes_c = c / 4;
+    int PP = 256 / lanes_c;
+    long want = (2048 + batch - 1) / batch;
+    long maxc = (npix_per_sample + (long)PP * 4 - 1) / ((long)PP * 4);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+#define SHM_CHECK_C(c, who) SHM_REQUIRE((c) % 4 == 0 && (c) >= 4 && (c) <= 1024, SHM_E_SHAPE, "%s: channels %d must be a multiple of 4 in [4,1024]", who, (c))
+
+// Combine per-thread double[NV][4] partials over the PP pixel slots, then one atomic per
+// (channel, value).  dst index = base + (ch * NV + v) when interleaved, or v*c + ch otherwise.
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(double (&v)[NV][4], const PixMap& pm, double* dst, int c, bool interleaved) {
+    __shared__ double red[256 * 4];
+    for (int q = 0; q < NV; ++q) {
+        __syncthreads();
+        if (pm.active) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(pm.pp * pm.lanes_c + pm.cl) * 4 + e] = v[q][e];
+        }
+        __syncthreads();
+        if (pm.active && pm.pp == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double s = 0.0;
+                for (int p = 0; p < pm.PP; ++p) s += red[(p * pm.lanes_c + pm.cl) * 4 + e];
+                int ch = pm.cl * 4 + e;
+                if (ch < c) atomicAdd(&dst[interleaved ? ch * NV + q : q * c + ch], s);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- IN statistics
+__global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__ a, int lda, double* __restrict__ stats, int hw, int c, int chunk) {
+    PixMap pm(c);
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
+    double v[2][4] = {};
+    if (pm.active) {
+        const float* base = a + (size_t)n * hw * lda + pm.cl * 4;
+        for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+            f32x4 x = *(const f32x4*)(base + (size_t)p * lda);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[0][e] += (double)x[e];
+                v[1][e] += (double)x[e] * (double)x[e];
+            }
+        }
+    }
+    block_reduce_atomic<2>(v, pm, stats + (size_t)n * c * 2, c, true);
+}
+
+__global__ void in_finalize_kernel(double* __restrict__ stats, int total, int hw, double eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    double s = stats[2 * i], q = stats[2 * i + 1];
+    double mean = s / hw;
+    double var = q / hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = 1.0 / sqrt(var + eps);
+}
+
+extern "C" int shm_in_stats(const float* a, int lda, double* stats, int batch, int hw, int c, float eps, void* stream) {
+    SHM_CHECK_C(c, "shm_in_stats");
+    SHM_REQUIRE(lda % 4 == 0 && lda >= c, SHM_E_SHAPE, "shm_in_stats: bad pitch %d", lda);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0 || hw == 0) return SHM_OK;
+    int r = shm_zero(stats, (size_t)batch * c * 2 * sizeof(double), stream);
+    if (r) return r;
+    int nch = pix_chunks(hw, batch, c);
+    int chunk = shm_cdiv(hw, nch);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, a, lda, stats, hw, c, chunk);
+    SHM_LAUNCH_CHECK("shm_in_stats");
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, batch * c, hw, (double)eps);
+    SHM_LAUNCH_CHECK("shm_in_stats(finalize)");
+    return SHM_OK;
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int ldo, int hw, int c, int chunk) {
+    PixMap pm(c);
+    if (!pm.active) return;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
+    float mean[4], inv[4], bt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int ch = pm.cl * 4 + e;
+        mean[e] = (float)stats[((size_t)n * c + ch) * 2];
+        inv[e] = (float)stats[((size_t)n * c + ch) * 2 + 1];
+        bt[e] = beta[ch];
+    }
+    const float* base = a + (size_t)n * hw * lda + pm.cl * 4;
+    float* ob = out + (size_t)n * hw * ldo + pm.cl * 4;
+    for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+        f32x4 x = *(const f32x4*)(base + (size_t)p * lda);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (x[e] - mean[e]) * inv[e] + bt[e];
+        *(f32x4*)(ob + (size_t)p * ldo) = y;
+    }
+}
+
+extern "C" int shm_in_apply(const float* a, int lda, const double* stats, const float* beta, float* out, int ldo, int batch, int hw, int c, void* stream) {
+    SHM_CHECK_C(c, "shm_in_apply");
+    SHM_REQUIRE(lda % 4 == 0 && ldo % 4 == 0, SHM_E_SHAPE, "shm_in_apply: bad pitch");
+    if (batch == 0 || hw == 0) return SHM_OK;
+    int nch = pix_chunks(hw, batch, c);
+    int chunk = shm_cdiv(hw, nch);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, (hipStream_t)stream, a, lda, stats, beta, out, ldo, hw, c, chunk);
+    SHM_LAUNCH_CHECK("shm_in_apply");
+    return SHM_OK;
+}
+
+// --------------------------------------------------------------------------- IN backward
+struct InBwdArgs {
+    const float* g1;
+    const float* g2;
+    const float* a;
+    const double* stats;
+    double* red;
+    float* dz;
+    double* dbias;
+    int ldg1, ldg2, lda, lddz;
+    int h, w, c, chunk;
+    float slope;
+};
+
+__device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, int cl) {
+    f32x4 g = *(const f32x4*)(k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
+    if (k.g2) {
+        int y = p / k.w, x = p - y * k.w;
+        size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
+        f32x4 u = *(const f32x4*)(k.g2 + q * k.ldg2 + cl * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] += 0.25f * u[e];
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
+    PixMap pm(k.c);
+    const int n = blockIdx.y, hw = k.h * k.w;
+    const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    double v[2][4] = {};
+    if (pm.active) {
+        float mean[4], inv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2];
+            inv[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2 + 1];
+        }
+        for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+            f32x4 g = in_bwd_dout(k, n, p, pm.cl);
+            f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xh = (x[e] - mean[e]) * inv[e];
+                v[0][e] += (double)g[e];
+                v[1][e] += (double)g[e] * (double)xh;
+            }
+        }
+    }
+    block_reduce_atomic<2>(v, pm, k.red + (size_t)n * k.c * 2, k.c, true);
+}
+
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
+    PixMap pm(k.c);
+    const int n = blockIdx.y, hw = k.h * k.w;
+    const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    double v[1][4] = {};
+    if (pm.active) {
+        float mean[4], inv[4], m1[4], m2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            size_t i = ((size_t)n * k.c + pm.cl * 4 + e) * 2;
+            mean[e] = (float)k.stats[i];
+            inv[e] = (float)k.stats[i + 1];
+            m1[e] = (float)(k.red[i] / hw);
+            m2[e] = (float)(k.red[i + 1] / hw);
+        }
+        for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+            f32x4 g = in_bwd_dout(k, n, p, pm.cl);
+            f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xh = (x[e] - mean[e]) * inv[e];
+                float da = inv[e] * (g[e] - m1[e] - xh * m2[e]);
+                d[e] = x[e] > 0.f ? da : da * k.slope;
+                v[0][e] += (double)d[e];
+            }
+            *(f32x4*)(k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4) = d;
+        }
+    }
+    if (k.dbias) block_reduce_atomic<1>(v, pm, k.dbias, k.c, true);
+}
+
+extern "C" int shm_in_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* a, int lda,
+                          const double* stats, double* red, float* dz, int lddz, double* dbias, int batch,
+                          int h, int w, int c, float slope, void* stream) {
+    SHM_CHECK_C(c, "shm_in_bwd");
+    SHM_REQUIRE(ldg1 % 4 == 0 && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "shm_in_bwd: bad pitch");
+    SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "shm_in_bwd: pooled gradient needs even h,w");
+    if (batch == 0 || h * w == 0) return SHM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
+    if (r) return r;
+    InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope};
+    int hw = h * w;
+    int nch = pix_chunks(hw, batch, c);
+    k.chunk = shm_cdiv(hw, nch);
+    dim3 grid(shm_cdiv(hw, k.chunk), batch);
+    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, k);
+    SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, k);
+    SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
+    return SHM_OK;
+}
+
+// ---------------------------------------------------------------------- LeakyReLU backward
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dz, int lddz,
+                                                        double* dbias, size_t npix, int c, size_t chunk, float slope) {
+    PixMap pm(c);
+    const size_t p0 = (size_t)blockIdx.x * chunk;
+    const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
+    double v[1][4] = {};
+    if (pm.active) {
+        for (size_t p = p0 + pm.pp; p < p1; p += pm.PP) {
+            f32x4 g = *(const f32x4*)(dy + p * lddy + pm.cl * 4);
+            f32x4 x = *(const f32x4*)(y + p * ldy + pm.cl * 4);
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d[e] = x[e] > 0.f ? g[e] : g[e] * slope;
+                v[0][e] += (double)d[e];
+            }
+            *(f32x4*)(dz + p * lddz + pm.cl * 4) = d;
+        }
+    }
+    if (dbias) block_reduce_atomic<1>(v, pm, dbias, c, true);
+}
+
+extern "C" int shm_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz,
+                             double* dbias, size_t npix, int c, float slope, void* stream) {
+    SHM_CHECK_C(c, "shm_lrelu_bwd");
+    SHM_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0, SHM_E_SHAPE, "shm_lrelu_bwd: bad pitch");
+    if (npix == 0) return SHM_OK;
+    int nch = pix_chunks((long)npix, 1, c);
+    size_t chunk = (npix + nch - 1) / nch;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(shm_cdiv((long)npix, (long)chunk)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, dz, lddz, dbias, npix, c, chunk, slope);
+    SHM_LAUNCH_CHECK("shm_lrelu_bwd");
+    return SHM_OK;
+}
+
+// -------------------------------------------------------------------------------- pooling
+__global__ void avgpool2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int h, int w, int c4, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cl = (int)(i % c4);
+    size_t q = i / c4;                     // output pixel (n, oy, ox)
+    int wo = w >> 1, ho = h >> 1;
+    int ox = (int)(q % wo);
+    size_t t = q / wo;
+    int oy = (int)(t % ho);
+    size_t n = t / ho;
+    const float* b = x + ((n * h + 2 * oy) * w + 2 * ox) * ldx + cl * 4;
+    f32x4 s = *(const f32x4*)b + *(const f32x4*)(b + ldx) + *(const f32x4*)(b + (size_t)w * ldx) + *(const f32x4*)(b + (size_t)(w + 1) * ldx);
+    *(f32x4*)(y + q * ldy + cl * 4) = s * 0.25f;
+}
+
+extern "C" int shm_avgpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int h, int w, int c, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, SHM_E_SHAPE, "shm_avgpool2_fwd: channels/pitch must be multiples of 4");
+    SHM_REQUIRE(h % 2 == 0 && w % 2 == 0, SHM_E_SHAPE, "shm_avgpool2_fwd: odd size %dx%d", h, w);
+    size_t total = (size_t)batch * (h / 2) * (w / 2) * (c / 4);
+    if (total == 0) return SHM_OK;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, h, w, c / 4, total);
+    SHM_LAUNCH_CHECK("shm_avgpool2_fwd");
+    return SHM_OK;
+}
+
+// -------------------------------------------------------------------------- generator head
+// y[p] = lrelu(sum_c x[p][c] w[c] + b); C/4 lanes per pixel (power of two <= 64).
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, size_t npix, int c, float slope) {
+    const int lanes_c = c >> 2, PP = 256 / lanes_c;
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x % lanes_c;
+    f32x4 wv = *(const f32x4*)(w + cl * 4);
+    const float b = bias ? bias[0] : 0.f;
+    for (size_t p = (size_t)blockIdx.x * PP + pp; p < npix; p += (size_t)gridDim.x * PP) {
+        f32x4 xv = *(const f32x4*)(x + p * ldx + cl * 4);
+        float s = xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        for (int o = lanes_c >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (cl == 0) y[p] = shm_lrelu(s + b, slope);
+    }
+}
+
+static bool pow2_le64(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
+
+extern "C" int shm_head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, size_t npix, int c, float slope, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && ldx % 4 == 0, SHM_E_SHAPE, "shm_head_fwd: channels %d unsupported", c);
+    if (npix == 0) return SHM_OK;
+    int PP = 256 / (c / 4);
+    long blocks = ((long)npix + PP - 1) / PP;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, npix, c, slope);
+    SHM_LAUNCH_CHECK("shm_head_fwd");
+    return SHM_OK;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope) {
+    PixMap pm(c);
+    f32x4 wv = *(const f32x4*)(w + pm.cl * 4);
+    double v[1][4] = {};
+    double dbs = 0.0;
+    for (size_t p = (size_t)blockIdx.x * pm.PP + pm.pp; p < npix; p += (size_t)gridDim.x * pm.PP) {
+        float g = dy[p];
+        float dz = y[p] > 0.f ? g : g * slope;
+        f32x4 xv = *(const f32x4*)(x + p * ldx + pm.cl * 4);
+        *(f32x4*)(dx + p * lddx + pm.cl * 4) = wv * dz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[0][e] += (double)xv[e] * (double)dz;
+        if (pm.cl == 0) dbs += (double)dz;
+    }
+    block_reduce_atomic<1>(v, pm, dw_acc, c, true);
+    // bias gradient: wave sum then one atomic per wave
+    dbs = shm_wave_sum(dbs);
+    if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(db_acc, dbs);
+}
+
+extern "C" int shm_head_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dx,
+                            int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && ldx % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_head_bwd: channels %d unsupported", c);
+    if (npix == 0) return SHM_OK;
+    int PP = 256 / (c / 4);
+    long blocks = ((long)npix + (long)PP * 8 - 1) / ((long)PP * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope);
+    SHM_LAUNCH_CHECK("shm_head_bwd");
+    return SHM_OK;
+}
+
+// ------------------------------------------------------------------------ PatchGAN logits
+__device__ __forceinline__ float block_sum_256(float v) {
+    __shared__ float ws[4];
+    v = shm_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// one block per output pixel
+__global__ __launch_bounds__(256) void patch_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, float* __restrict__ y, int h, int wd, int c, float slope) {
+    const int q = blockIdx.x;              // (n, i, j)
+    const int j = q % wd, t = q / wd;
+    const int i = t % h, n = t / h;
+    const int c4 = c >> 2;
+    float s = 0.f;
+    for (int it = threadIdx.x; it < 9 * c4; it += 256) {
+        int tap = it / c4, cl = it - tap * c4;
+        int ii = i + tap / 3 - 1, jj = j + tap % 3 - 1;
+        if ((unsigned)ii < (unsigned)h && (unsigned)jj < (unsigned)wd) {
+            f32x4 xv = *(const f32x4*)(x + ((size_t)(n * h + ii) * wd + jj) * ldx + cl * 4);
+            f32x4 wv = *(const f32x4*)(w + (size_t)tap * c + cl * 4);
+            s += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+    }
+    s = block_sum_256(s);
+    if (threadIdx.x == 0) y[q] = shm_lrelu(s, slope);
+}
+
+extern "C" int shm_patch_fwd(const float* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c, float slope, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0, SHM_E_SHAPE, "shm_patch_fwd: channels must be a multiple of 4");
+    int total = batch * h * wd;
+    if (total == 0) return SHM_OK;
+    hipLaunchKernelGGL(patch_fwd_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, x, ldx, w, y, h, wd, c, slope);
+    SHM_LAUNCH_CHECK("shm_patch_fwd");
+    return SHM_OK;
+}
+
+__global__ void patch_dz_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz, int n, float slope) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// dx[n,i,j,c] = sum_tap dz[n, i-(kh-1), j-(kw-1)] * w[tap][c]
+__global__ void patch_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx, int lddx, int h, int wd, int c4, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int cl = (int)(idx % c4);
+    size_t q = idx / c4;
+    int j = (int)(q % wd);
+    size_t t = q / wd;
+    int i = (int)(t % h);
+    size_t n = t / h;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap) {
+        int ii = i - (tap / 3 - 1), jj = j - (tap % 3 - 1);
+        if ((unsigned)ii < (unsigned)h && (unsigned)jj < (unsigned)wd) {
+            float g = dz[(n * h + ii) * wd + jj];
+            s += *(const f32x4*)(w + (size_t)tap * c4 * 4 + cl * 4) * g;
+        }
+    }
+    *(f32x4*)(dx + q * lddx + cl * 4) = s;
+}
+
+// dw[tap][c] = sum_{n,i,j} x[n,i+kh-1,j+kw-1,c] * dz[n,i,j]; thread per (tap, c)
+__global__ void patch_dw_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, float* __restrict__ dw, int batch, int h, int wd, int c) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 9 * c) return;
+    int tap = idx / c, ch = idx - tap * c;
+    int dh = tap / 3 - 1, dwv = tap % 3 - 1;
+    double s = 0.0;
+    for (int n = 0; n < batch; ++n)
+        for (int i = 0; i < h; ++i) {
+            int ii = i + dh;
+            if ((unsigned)ii >= (unsigned)h) continue;
+            for (int j = 0; j < wd; ++j) {
+                int jj = j + dwv;
+                if ((unsigned)jj >= (unsigned)wd) continue;
+                s += (double)x[((size_t)(n * h + ii) * wd + jj) * ldx + ch] * (double)dz[(n * h + i) * wd + j];
+            }
+        }
+    dw[idx] = (float)s;
+}
+
+extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
+                             float* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_patch_bwd: channels must be a multiple of 4");
+    int npx = batch * h * wd;
+    if (npx == 0) return SHM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(patch_dz_kernel, dim3(shm_cdiv(npx, 256)), dim3(256), 0, st, y, dy, dz, npx, slope);
+    SHM_LAUNCH_CHECK("shm_patch_bwd(dz)");
+    size_t total = (size_t)npx * (c / 4);
+    hipLaunchKernelGGL(patch_dx_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, (const float*)dz, w, dx, lddx, h, wd, c / 4, total);
+    SHM_LAUNCH_CHECK("shm_patch_bwd(dx)");
+    if (dw) {
+        hipLaunchKernelGGL(patch_dw_kernel, dim3(shm_cdiv(9 * c, 64)), dim3(64), 0, st, x, ldx, (const float*)dz, dw, batch, h, wd, c);
+        SHM_LAUNCH_CHECK("shm_patch_bwd(dw)");
+    }
+    return SHM_OK;
+}
+
+// --------------------------------------------------------------------------------- Dense(5)
+constexpr int DENSE_MAX_OUT = 8;
+
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int k, int nout) {
+    const int n = blockIdx.x;
+    float acc[DENSE_MAX_OUT] = {};
+    const float* xr = x + (size_t)n * k;
+    for (int i = threadIdx.x; i < k; i += 256) {
+        float xv = xr[i];
+        for (int j = 0; j < nout; ++j) acc[j] += xv * w[(size_t)i * nout + j];
+    }
+    for (int j = 0; j < nout; ++j) {
+        float s = block_sum_256(acc[j]);
+        if (threadIdx.x == 0) y[(size_t)n * nout + j] = s;
+    }
+}
+
+extern "C" int shm_dense_fwd(const float* x, const float* w, float* y, int batch, int k, int nout, void* stream) {
+    SHM_REQUIRE(nout >= 1 && nout <= DENSE_MAX_OUT, SHM_E_SHAPE, "shm_dense_fwd: nout %d > %d", nout, DENSE_MAX_OUT);
+    if (batch == 0) return SHM_OK;
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, x, w, y, k, nout);
+    SHM_LAUNCH_CHECK("shm_dense_fwd");
+    return SHM_OK;
+}
+
+// thread per k: dx[n][k] += sum_j dy[n][j] w[k][j];  dw[k][j] = sum_n x[n][k] dy[n][j]
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, float* __restrict__ dx,
+                                                        float* __restrict__ dw, int batch, int k, int nout) {
+    extern __shared__ float sdy[];          // [batch][nout]
+    for (int i = threadIdx.x; i < batch * nout; i += 256) sdy[i] = dy[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    float wv[DENSE_MAX_OUT], acc[DENSE_MAX_OUT] = {};
+    for (int j = 0; j < nout; ++j) wv[j] = w[(size_t)i * nout + j];
+    for (int n = 0; n < batch; ++n) {
+        float xv = x[(size_t)n * k + i];
+        float s = 0.f;
+        for (int j = 0; j < nout; ++j) {
+            float g = sdy[n * nout + j];
+            s += g * wv[j];
+            acc[j] += xv * g;
+        }
+        dx[(size_t)n * k + i] += s;
+    }
+    if (dw)
+        for (int j = 0; j < nout; ++j) dw[(size_t)i * nout + j] = acc[j];
+}
+
+extern "C" int shm_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int batch, int k, int nout, void* stream) {
+    SHM_REQUIRE(nout >= 1 && nout <= DENSE_MAX_OUT, SHM_E_SHAPE, "shm_dense_bwd: nout %d > %d", nout, DENSE_MAX_OUT);
+    SHM_REQUIRE((size_t)batch * nout * 4 <= 48 * 1024, SHM_E_SHAPE, "shm_dense_bwd: batch %d too large", batch);
+    if (batch == 0 || k == 0) return SHM_OK;
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(shm_cdiv(k, 256)), dim3(256), (size_t)batch * nout * 4, (hipStream_t)stream, x, w, dy, dx, dw, batch, k, nout);
+    SHM_LAUNCH_CHECK("shm_dense_bwd");
+    return SHM_OK;
+}
+
+// --------------------------------------------------------------------------- dropout mask
+__global__ void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, size_t n4, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = ((const f32x4*)x)[i], b = ((const f32x4*)m)[i];
+    ((f32x4*)y)[i] = a * b * scale;
+}
+
+extern "C" int shm_mul_mask(const float* x, const float* mask, float* y, size_t n, float scale, void* stream) {
+    SHM_REQUIRE(n % 4 == 0, SHM_E_SHAPE, "shm_mul_mask: n must be a multiple of 4");
+    if (n == 0) return SHM_OK;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3(shm_cdiv((long)(n / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n / 4, scale);
+    SHM_LAUNCH_CHECK("shm_mul_mask");
+    return SHM_OK;
+}

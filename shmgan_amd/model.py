@@ -1,0 +1,486 @@
+"""SHMGAN generator (U-Net) and discriminator (PatchGAN + classifier) on the HIP kernels.
+
+Mirrors `build_generator` (SHM.py:228-327) and `build_discriminator` (SHM.py:343-389) of
+/root/reference/ShmGANwithSSpecSeg.py "as executed" (SURVEY.md findings 3-5): block order
+Conv -> bias -> LeakyReLU(0.2) -> InstanceNormalization(eps=1e-6, gamma=1, constant beta);
+the SpecSeg attention term is a constant zero added to the skips; Concatenate puts the
+upsampled tensor first.  Forward AND backward are explicit sequences of C-ABI calls
+(shmgan_amd.ops); torch tensors are storage.
+
+Weights live in one flat fp32 buffer per model (so clip+Adam is one launch and the
+data-parallel all-reduce is one contiguous bucket); `trainable_variables` are views into
+it in the reference's Keras order and layouts (HWIO; Conv2DTranspose [kh,kw,Cout,Cin];
+Dense [in,out]).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+LRELU = 0.2
+IN_EPS = 1e-6
+PAD_C = 16          # channel pitch of 3- and 10-channel images
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+class Arena:
+    """Named, shape-keyed tensor cache: every activation buffer is allocated once and reused
+    on the next step (the step has a static memory plan; 288 GB of HBM is not the limit)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.t.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            self.t[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+def generator_layers(f):
+    """(keras_name, kind, k, cin, cout) in Keras creation order (Generator_summary.txt)."""
+    return [
+        ("conv2d", "c", 3, 10, f), ("conv2d_1", "c", 3, f, f),
+        ("conv2d_4", "c", 3, f, 2 * f), ("conv2d_5", "c", 3, 2 * f, 2 * f),
+        ("conv2d_8", "c", 3, 2 * f, 4 * f), ("conv2d_9", "c", 3, 4 * f, 4 * f),
+        ("conv2d_12", "c", 3, 4 * f, 8 * f), ("conv2d_13", "c", 3, 8 * f, 8 * f),
+        ("conv2d_16", "c", 1, 8 * f, 8 * f), ("conv2d_17", "c", 1, 8 * f, 8 * f),
+        ("conv2d_transpose", "t", 3, 8 * f, 8 * f),
+        ("conv2d_18", "c", 3, 16 * f, 8 * f), ("conv2d_19", "c", 3, 8 * f, 8 * f),
+        ("conv2d_transpose_1", "t", 3, 8 * f, 4 * f),
+        ("conv2d_20", "c", 3, 8 * f, 4 * f), ("conv2d_21", "c", 3, 4 * f, 4 * f),
+        ("conv2d_transpose_2", "t", 3, 4 * f, 2 * f),
+        ("conv2d_22", "c", 3, 4 * f, 2 * f), ("conv2d_23", "c", 3, 2 * f, 2 * f),
+        ("conv2d_transpose_3", "t", 3, 2 * f, f),
+        ("conv2d_24", "c", 3, 2 * f, f), ("conv2d_25", "c", 3, f, f),
+        ("conv2d_26", "c", 1, f, 1),
+    ]
+
+
+class _Vars:
+    """Flat parameter / gradient / Adam-moment storage with named views."""
+
+    def __init__(self, shapes, order, device):
+        """shapes: list of shapes in Keras variable order; order: storage order (indices)."""
+        self.shapes = [tuple(s) for s in shapes]
+        sizes = [int(np.prod(s)) for s in self.shapes]
+        self.n = sum(sizes)
+        self.offsets = [0] * len(shapes)
+        off = 0
+        for i in order:
+            self.offsets[i] = off
+            off += sizes[i]
+        self.flat = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.vars = [self.flat[o:o + z].view(s) for o, z, s in zip(self.offsets, sizes, self.shapes)]
+        self.grads = [self.grad[o:o + z].view(s) for o, z, s in zip(self.offsets, sizes, self.shapes)]
+        self.iterations = 0
+
+    def load(self, arrays):
+        assert len(arrays) == len(self.vars)
+        for v, a in zip(self.vars, arrays):
+            a = torch.as_tensor(np.asarray(a, dtype=np.float32))
+            assert tuple(a.shape) == tuple(v.shape), (a.shape, v.shape)
+            v.copy_(a)
+
+    def numpy(self, which="vars"):
+        return [t.detach().cpu().numpy().copy() for t in getattr(self, which)]
+
+
+class _ModelBase:
+    trainable = True
+
+    @property
+    def trainable_variables(self):
+        return self.P.vars
+
+    @property
+    def gradients(self):
+        return self.P.grads
+
+    def count_params(self):
+        return self.P.n
+
+    def get_weights(self):
+        return self.P.numpy("vars")
+
+    def set_weights(self, arrays):
+        self.P.load(arrays)
+        self.weights_dirty = True
+
+
+# =============================================================================== Generator
+class Generator(_ModelBase):
+    name = "SHM_Generator"
+
+    def __init__(self, image_size, filter_size, device, arena, ws_provider):
+        self.S, self.F, self.dev = image_size, filter_size, device
+        self.arena, self.ws_provider = arena, ws_provider
+        assert image_size % 16 == 0 and filter_size % 16 == 0, "image_size and filter_size must be multiples of 16"
+        self.layers = generator_layers(filter_size)
+        shapes = []
+        for _, kind, k, cin, cout in self.layers:
+            shapes.append((k, k, cin, cout) if kind == "c" else (k, k, cout, cin))
+            shapes.append((cout,))
+        nl = len(self.layers)
+        # storage order: all MFMA-wgrad kernels, then [head kernel, every bias] (f64-accumulated grads)
+        order = [2 * i for i in range(nl - 1)] + [2 * (nl - 1)] + [2 * i + 1 for i in range(nl)]
+        self.P = _Vars(shapes, order, device)
+        self.acc_off = self.P.offsets[2 * (nl - 1)]            # start of the f64-accumulated region
+        self.acc_n = self.P.n - self.acc_off
+        self.acc = torch.zeros(self.acc_n, dtype=torch.float64, device=device)
+        self.in_channels = [cout for n_, kind, k, cin, cout in self.layers if kind == "c" and n_ != "conv2d_26"]
+        self.betas = [torch.zeros(c, dtype=torch.float32, device=device) for c in self.in_channels]
+        # K-contiguous copies: conv fwd needs [t][cout][cin_pad]; convT dgrad needs [t][cin][cout]
+        self.wk = {}
+        for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
+            if kind == "c":
+                self.wk[i] = torch.zeros(k * k * cout * _pad16(cin), dtype=torch.float32, device=device)
+            else:
+                self.wk[i] = torch.zeros(9 * cin * cout, dtype=torch.float32, device=device)
+        self.weights_dirty = True
+        self.ctx = {}
+
+    # -- parameter plumbing ---------------------------------------------------------------
+    def set_betas(self, arrays):
+        for b, a in zip(self.betas, arrays):
+            b.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+
+    def _acc_slice(self, var_index):
+        o = self.P.offsets[var_index] - self.acc_off
+        return self.acc[o:o + self.P.vars[var_index].numel()]
+
+    def prepare_weights(self):
+        """Refresh the K-contiguous weight copies after an optimizer step."""
+        if not self.weights_dirty:
+            return
+        for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
+            w = self.P.vars[2 * i]
+            if kind == "c":      # HWIO [t][cin][cout] -> [t][cout][cin_pad]
+                ops.transpose_taps(w, self.wk[i], k * k, cin, cout, _pad16(cin))
+            else:                # Keras convT [t][cout][cin] -> [t][cin][cout] (for its dgrad)
+                ops.transpose_taps(w, self.wk[i], 9, cout, cin, cout)
+        self.weights_dirty = False
+
+    def zero_grad(self):
+        ops.zero(self.P.grad)
+        ops.zero(self.acc)
+
+    def finish_grads(self):
+        """Fold the f64-accumulated head-kernel / bias gradients into the flat fp32 gradient."""
+        ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
+
+    # -- forward --------------------------------------------------------------------------
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w):
+        """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record)."""
+        _, _, k, cin, cout = self.layers[li]
+        cin_p = _pad16(cin)
+        A = self.arena
+        a = A.get(f"{tag}/a{li}", (n, h, w, cout))
+        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout))
+        stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
+        ops.conv2d_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
+                       k, 1, LRELU)
+        ops.in_stats(a, cout, stats, n, h * w, cout, IN_EPS)
+        ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
+        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
+        return ahat, rec
+
+    def forward(self, x16, tag):
+        """x16: [N,S,S,16] (10 real channels, 6 zero).  Returns gen_Y [N,S,S,1]."""
+        n, S, F = x16.shape[0], self.S, self.F
+        assert tuple(x16.shape) == (n, S, S, PAD_C)
+        self.prepare_weights()
+        A = self.arena
+        recs = []
+        cur, ld, h = x16, PAD_C, S
+        li = bi = 0
+        downs = []
+        for lvl in range(4):
+            for _ in range(2):
+                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+                recs.append(r)
+                ld = self.layers[li][4]
+                li += 1
+                bi += 1
+            downs.append((cur, ld, h))
+            pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, ld))
+            ops.avgpool2_fwd(cur, ld, pooled, ld, n, h, h, ld)
+            cur, h = pooled, h // 2
+        for _ in range(2):                       # the two 1x1 blocks
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+            recs.append(r)
+            li += 1
+            bi += 1
+        ups = []
+        for lvl in range(4):
+            _, _, _, cin, cout = self.layers[li]
+            u = A.get(f"{tag}/u{lvl}", (n, 2 * h, 2 * h, cout))
+            ops.conv2d_transpose_fwd(cur, ld, self.P.vars[2 * li], self.P.vars[2 * li + 1], u, cout, n, h, h, cin,
+                                     cout, LRELU)
+            ups.append(dict(li=li, x=cur, ldx=ld, u=u, h=h))
+            li += 1
+            h *= 2
+            skip, sld, sh = downs[3 - lvl]
+            assert sh == h
+            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h)   # concat [u, skip]
+            recs.append(r)
+            ld = self.layers[li][4]
+            li += 1
+            bi += 1
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+            recs.append(r)
+            li += 1
+            bi += 1
+        y = A.get(f"{tag}/y", (n, S, S, 1))
+        ops.head_fwd(cur, ld, self.P.vars[2 * li], self.P.vars[2 * li + 1], y, n * S * S, ld, LRELU)
+        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, y=y, x16=x16)
+        return y
+
+    # -- backward -------------------------------------------------------------------------
+    def _cnl_bwd(self, tag, rec, g1, g2, n, need_dx, dx=None, dx2=None, n1=0):
+        """Backward of one Conv->LReLU->IN block.  g1: gradient at the IN output (same res),
+        g2: optional gradient of the 2x2 average pool that consumed the IN output.
+        Accumulates dW / dbias; returns nothing (dx/dx2 are written if need_dx)."""
+        li, h, w = rec["li"], rec["h"], rec["w"]
+        _, _, k, cin, cout = self.layers[li]
+        A = self.arena
+        dz = A.get(f"bwd/dz/{n}x{h}x{cout}", (n, h, w, cout))
+        red = A.get(f"bwd/red/{n * cout}", (n * cout * 2,), torch.float64)
+        ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
+                   h, w, cout, LRELU)
+        cin_p = _pad16(cin)
+        ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
+        ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout, self.P.grads[2 * li], n,
+                         h, w, cin, cin_p, cout, k, 1, 1, ws)
+        if need_dx:
+            lddx = rec["ldx"]
+            ops.conv2d_dgrad(dz, cout, self.P.vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
+
+    def backward(self, dy, tag, need_dx=False):
+        """dy: gradient wrt gen_Y [N,S,S,1].  Accumulates into the flat gradient (+ f64 region).
+        Returns the gradient wrt the 16-pitch input if need_dx (channels 0..9 valid)."""
+        c = self.ctx[tag]
+        n, recs, ups = c["n"], c["recs"], c["ups"]
+        A = self.arena
+        S, F = self.S, self.F
+        nl = len(self.layers)
+        # head
+        hx = c["head_x"]
+        dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F))
+        ops.head_bwd(hx, F, self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
+                     self._acc_slice(2 * (nl - 1) + 1), n * S * S, F, LRELU)
+        ri = len(recs) - 1
+        dskips = [None] * 4
+        for lvl in range(3, -1, -1):
+            up = ups[lvl]
+            r2, r1 = recs[ri], recs[ri - 1]
+            ri -= 2
+            h = r2["h"]
+            cout = self.layers[r2["li"]][4]
+            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout))
+            self._cnl_bwd(tag, r2, dcur, None, n, True, dmid, None, cout)
+            # concat block: split gradient into (du, dskip)
+            cu = r1["c1"]
+            cs = self.layers[r1["li"]][3] - cu
+            du = A.get(f"bwd/du/{n}x{h}x{cu}", (n, h, h, cu))
+            dsk = A.get(f"bwd/dskip{3 - lvl}/{n}x{h}x{cs}", (n, h, h, cs))
+            self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu)
+            dskips[3 - lvl] = dsk
+            # Conv2DTranspose: LeakyReLU', bias grad, wgrad (roles swapped), dgrad = stride-2 conv
+            tli = up["li"]
+            _, _, _, tcin, tcout = self.layers[tli]
+            dzu = A.get(f"bwd/dzu/{n}x{h}x{cu}", (n, h, h, cu))
+            ops.lrelu_bwd(du, cu, up["u"], cu, dzu, cu, self._acc_slice(2 * tli + 1), n * h * h, cu, LRELU)
+            ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, tcout, tcin, 3))
+            ops.conv2d_wgrad(dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout,
+                             tcin, 3, 2, 1, ws)
+            hin = up["h"]
+            dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin))
+            ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0)
+        # bottleneck 1x1 blocks
+        for _ in range(2):
+            r = recs[ri]
+            ri -= 1
+            h = r["h"]
+            cin = self.layers[r["li"]][3]
+            dn = A.get(f"bwd/db{ri}/{n}x{h}x{cin}", (n, h, h, cin))
+            self._cnl_bwd(tag, r, dcur, None, n, True, dn, None, cin)
+            dcur = dn
+        dpool = dcur                                   # gradient wrt pool4 output
+        for lvl in range(3, -1, -1):
+            r2, r1 = recs[ri], recs[ri - 1]
+            ri -= 2
+            h = r2["h"]
+            cout = self.layers[r2["li"]][4]
+            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout))
+            self._cnl_bwd(tag, r2, dskips[lvl], dpool, n, True, dmid, None, cout)
+            cin = self.layers[r1["li"]][3]
+            if lvl > 0:
+                dpool = A.get(f"bwd/dp/{n}x{h}x{cin}", (n, h, h, cin))
+                self._cnl_bwd(tag, r1, dmid, None, n, True, dpool, None, cin)
+            else:
+                if need_dx:
+                    dx16 = A.get(f"bwd/dx16/{n}", (n, h, h, PAD_C))
+                    self._cnl_bwd(tag, r1, dmid, None, n, True, dx16, None, cin)
+                    return dx16
+                self._cnl_bwd(tag, r1, dmid, None, n, False)
+        return None
+
+    def __call__(self, x, training=False, tag="call"):
+        """Keras-style call on a [N,S,S,10] tensor (reference: self.G(x, training=...))."""
+        n = x.shape[0]
+        x16 = self.arena.get(f"{tag}/x16", (n, self.S, self.S, PAD_C))
+        x16.zero_()
+        x16[..., :10].copy_(x)
+        return self.forward(x16, tag)
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{self.name}"')
+        for i, (name, kind, k, cin, cout) in enumerate(self.layers):
+            cnt = self.P.vars[2 * i].numel() + self.P.vars[2 * i + 1].numel()
+            print_fn(f"{name:24s} {'Conv2DTranspose' if kind == 't' else 'Conv2D':16s} k={k} {cin}->{cout}  {cnt}")
+        print_fn(f"Total params: {self.P.n:,}")
+
+
+
+
+# =========================================================================== Discriminator
+class Discriminator(_ModelBase):
+    name = "SHM_Discriminator"
+
+    def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2):
+        self.S, self.F, self.dev = image_size, filter_size, device
+        self.arena, self.ws_provider = arena, ws_provider
+        self.dropout = dropout
+        assert image_size % 32 == 0
+        f, s = filter_size, image_size // 32
+        self.s = s
+        self.chan = [3, f, 2 * f, 4 * f, 8 * f, 16 * f]
+        shapes = [(3, 3, self.chan[i], self.chan[i + 1]) for i in range(5)]
+        shapes += [(3, 3, 16 * f, 1), (s * s * 16 * f, 5)]
+        self.names = ["conv2d_27", "conv2d_28", "conv2d_29", "conv2d_30", "conv2d_33", "conv2d_34", "dense"]
+        self.P = _Vars(shapes, list(range(7)), device)
+        self.betas = [torch.zeros(c, dtype=torch.float32, device=device) for c in self.chan[1:]]
+        self.wk = [torch.zeros(9 * self.chan[i + 1] * _pad16(self.chan[i]), dtype=torch.float32, device=device)
+                   for i in range(5)]
+        self.weights_dirty = True
+        self.ctx = None
+
+    def set_betas(self, arrays):
+        for b, a in zip(self.betas, arrays):
+            b.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+
+    def prepare_weights(self):
+        if not self.weights_dirty:
+            return
+        for i in range(5):
+            ops.transpose_taps(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _pad16(self.chan[i]))
+        self.weights_dirty = False
+
+    def zero_grad(self):
+        ops.zero(self.P.grad)
+
+    def forward(self, xd16, keep_mask=None, mask_rows=()):
+        """xd16 [N,S,S,16] (rgb + zeros).  keep_mask [len(mask_rows)...] is the Dropout keep mask of
+        the `training=True` samples: mask_rows = list of (row_start, nrows, mask_row_start)."""
+        n, S = xd16.shape[0], self.S
+        self.prepare_weights()
+        A = self.arena
+        cur, ld, h = xd16, PAD_C, S
+        recs = []
+        for i in range(5):
+            cin, cout = self.chan[i], self.chan[i + 1]
+            ho = h // 2
+            a = A.get(f"d/a{i}/{n}", (n, ho, ho, cout))
+            ahat = A.get(f"d/h{i}/{n}", (n, ho, ho, cout))
+            stats = A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)
+            ops.conv2d_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU)
+            ops.in_stats(a, cout, stats, n, ho * ho, cout, IN_EPS)
+            ops.in_apply(a, cout, stats, self.betas[i], ahat, cout, n, ho * ho, cout)
+            recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
+            cur, ld, h = ahat, cout, ho
+        c5 = self.chan[5]
+        per = h * h * c5
+        scale = 1.0 / (1.0 - self.dropout)
+        for r0, nr, m0 in mask_rows:                 # Dropout on the training=True samples, in place
+            ops.mul_mask(cur[r0:r0 + nr], keep_mask[m0:m0 + nr], cur[r0:r0 + nr], nr * per, scale)
+        rf = A.get(f"d/rf/{n}", (n, h, h, 1))
+        cls = A.get(f"d/cls/{n}", (n, 5))
+        ops.patch_fwd(cur, c5, self.P.vars[5], rf, n, h, h, c5, LRELU)
+        ops.dense_fwd(cur, self.P.vars[6], cls, n, per, 5)
+        self.ctx = dict(n=n, recs=recs, x5=cur, rf=rf, cls=cls, keep_mask=keep_mask, mask_rows=mask_rows)
+        return rf, cls
+
+    def _backward(self, n, drf, dcls, params, need_dx):
+        """Backward over the first n samples of the last forward.  params: accumulate weight
+        gradients; need_dx: return the gradient wrt the 16-pitch input."""
+        c = self.ctx
+        A = self.arena
+        s, c5 = self.s, self.chan[5]
+        per = s * s * c5
+        x5 = c["x5"]
+        dz_p = A.get(f"d/bwd/dzp/{n}", (n, s, s, 1))
+        dx5 = A.get(f"d/bwd/dx5/{n}", (n, s, s, c5))
+        ops.patch_bwd(x5, c5, self.P.vars[5], c["rf"], drf, dz_p, dx5, c5, self.P.grads[5] if params else None, n, s, s,
+                      c5, LRELU)
+        if dcls is not None:
+            ops.dense_bwd(x5, self.P.vars[6], dcls, dx5, self.P.grads[6] if params else None, n, per, 5)
+        scale = 1.0 / (1.0 - self.dropout)
+        for r0, nr, m0 in c["mask_rows"]:
+            if r0 + nr <= n:
+                ops.mul_mask(dx5[r0:r0 + nr], c["keep_mask"][m0:m0 + nr], dx5[r0:r0 + nr], nr * per, scale)
+        dcur = dx5
+        for i in range(4, -1, -1):
+            rec = c["recs"][i]
+            cin, cout = self.chan[i], self.chan[i + 1]
+            h = rec["h"]
+            ho = h // 2
+            dz = A.get(f"d/bwd/dz{i}/{n}", (n, ho, ho, cout))
+            red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 2,), torch.float64)
+            ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
+            if params:
+                ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))
+                ops.conv2d_wgrad(rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _pad16(cin),
+                                 cout, 3, 2, 0, ws)
+            if i > 0 or need_dx:
+                ldx = rec["ldx"]
+                dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx))
+                ops.conv2d_dgrad(dz, cout, self.P.vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2)
+                dcur = dprev
+        return dcur if need_dx else None
+
+    def backward_params(self, drf, dcls):
+        """D-loss backward over the whole D batch: fills the flat weight gradient."""
+        self._backward(self.ctx["n"], drf, dcls, True, False)
+
+    def backward_input(self, n, drf):
+        """G-loss backward (data gradient only) through the first n samples."""
+        return self._backward(n, drf, None, False, True)
+
+    def __call__(self, x, training=False, noise=None, keep_mask=None):
+        """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""
+        n = x.shape[0]
+        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, PAD_C))
+        ops.pack_rgb16(x.contiguous(), noise if training else None, xd, n * self.S * self.S)
+        rows = [(0, n, 0)] if (training and keep_mask is not None) else []
+        return self.forward(xd, keep_mask, rows)
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{self.name}"')
+        for nme, v in zip(self.names, self.P.vars):
+            print_fn(f"{nme:24s} {tuple(v.shape)}  {v.numel()}")
+        print_fn(f"Total params: {self.P.n:,}")

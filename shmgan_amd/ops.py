@@ -1,0 +1,162 @@
+"""Thin tensor-level wrappers over the C ABI (include/shmgan_hip.h).
+
+PyTorch tensors are storage only: every function takes float32 CUDA(ROCm) tensors, passes
+their device pointers to libshmgan_hip.so on torch's current stream and returns nothing
+(outputs are preallocated by the caller).  No torch.nn op runs here.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def transpose_taps(w, wt, ntaps, rows, cols, rows_pad):
+    check(lib().shm_transpose_taps(_p(w), _p(wt), ntaps, rows, cols, rows_pad, _stream()), "shm_transpose_taps")
+
+
+def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope):
+    check(lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                               cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd")
+
+
+def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
+    check(lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
+                                 cout, ksize, stride, _stream()), "shm_conv2d_dgrad")
+
+
+def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
+    check(lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
+                                         slope, _stream()), "shm_conv2d_transpose_fwd")
+
+
+def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
+    return int(lib().shm_conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize))
+
+
+def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride,
+                 accumulate, ws):
+    check(lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
+                                 cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
+                                 _stream()), "shm_conv2d_wgrad")
+
+
+def in_stats(a, lda, stats, batch, hw, c, eps):
+    check(lib().shm_in_stats(_p(a), lda, _p(stats), batch, hw, c, eps, _stream()), "shm_in_stats")
+
+
+def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
+    check(lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _stream()), "shm_in_apply")
+
+
+def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
+    check(lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
+                           batch, h, w, c, slope, _stream()), "shm_in_bwd")
+
+
+def lrelu_bwd(dy, lddy, y, ldy, dz, lddz, dbias, npix, c, slope):
+    check(lib().shm_lrelu_bwd(_p(dy), lddy, _p(y), ldy, _p(dz), lddz, _p(dbias), npix, c, slope, _stream()),
+          "shm_lrelu_bwd")
+
+
+def avgpool2_fwd(x, ldx, y, ldy, batch, h, w, c):
+    check(lib().shm_avgpool2_fwd(_p(x), ldx, _p(y), ldy, batch, h, w, c, _stream()), "shm_avgpool2_fwd")
+
+
+def cvt_f64_f32(src, dst, n, accumulate):
+    check(lib().shm_cvt_f64_f32(_p(src), _p(dst), n, int(accumulate), _stream()), "shm_cvt_f64_f32")
+
+
+def zero(t):
+    check(lib().shm_zero(_p(t), t.numel() * t.element_size(), _stream()), "shm_zero")
+
+
+def head_fwd(x, ldx, w, bias, y, npix, c, slope):
+    check(lib().shm_head_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, slope, _stream()), "shm_head_fwd")
+
+
+def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope):
+    check(lib().shm_head_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), npix, c,
+                             slope, _stream()), "shm_head_bwd")
+
+
+def patch_fwd(x, ldx, w, y, batch, h, wd, c, slope):
+    check(lib().shm_patch_fwd(_p(x), ldx, _p(w), _p(y), batch, h, wd, c, slope, _stream()), "shm_patch_fwd")
+
+
+def patch_bwd(x, ldx, w, y, dy, dz, dx, lddx, dw, batch, h, wd, c, slope):
+    check(lib().shm_patch_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dz), _p(dx), lddx, _p(dw), batch, h, wd, c,
+                              slope, _stream()), "shm_patch_bwd")
+
+
+def dense_fwd(x, w, y, batch, k, nout):
+    check(lib().shm_dense_fwd(_p(x), _p(w), _p(y), batch, k, nout, _stream()), "shm_dense_fwd")
+
+
+def dense_bwd(x, w, dy, dx, dw, batch, k, nout):
+    check(lib().shm_dense_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), batch, k, nout, _stream()), "shm_dense_bwd")
+
+
+def mul_mask(x, mask, y, n, scale):
+    check(lib().shm_mul_mask(_p(x), _p(mask), _p(y), n, scale, _stream()), "shm_mul_mask")
+
+
+def rgb2yuv_std(rgb, yuv, acc, scale_out, batch, npix):
+    check(lib().shm_rgb2yuv_std(_p(rgb), _p(yuv), _p(acc), _p(scale_out), batch, npix, _stream()), "shm_rgb2yuv_std")
+
+
+def avg_cbcr(ys, out, n):
+    check(lib().shm_avg_cbcr(_p(ys[0]), _p(ys[1]), _p(ys[2]), _p(ys[3]), _p(ys[4]), _p(out), n, _stream()),
+          "shm_avg_cbcr")
+
+
+def build_gen_input(ys, gen_y, flags_mask, mode, out, batch, npix):
+    check(lib().shm_build_gen_input(_p(ys[0]), _p(ys[1]), _p(ys[2]), _p(ys[3]), _p(ys[4]), _p(gen_y), flags_mask,
+                                    mode, _p(out), batch, npix, _stream()), "shm_build_gen_input")
+
+
+def cyc_input_bwd(dcyc, flags_mask, dgen_y, batch, npix):
+    check(lib().shm_cyc_input_bwd(_p(dcyc), flags_mask, _p(dgen_y), batch, npix, _stream()), "shm_cyc_input_bwd")
+
+
+def yuv2rgb(ych, cbcr, noise, rgb, dpad, nimg, batch, npix):
+    check(lib().shm_yuv2rgb(_p(ych), _p(cbcr), _p(noise), _p(rgb), _p(dpad), nimg, batch, npix, _stream()),
+          "shm_yuv2rgb")
+
+
+def pack_rgb16(rgb, noise, dpad, npix_total):
+    check(lib().shm_pack_rgb16(_p(rgb), _p(noise), _p(dpad), npix_total, _stream()), "shm_pack_rgb16")
+
+
+def rgb16_to_dy(d16, dy, npix_total, accumulate):
+    check(lib().shm_rgb16_to_dy(_p(d16), _p(dy), npix_total, int(accumulate), _stream()), "shm_rgb16_to_dy")
+
+
+def dhead_losses(rf, cls, loss, drf_d, dcls_d, drf_g, batch, np_, target):
+    check(lib().shm_dhead_losses(_p(rf), _p(cls), _p(loss), _p(drf_d), _p(dcls_d), _p(drf_g), batch, np_, target,
+                                 _stream()), "shm_dhead_losses")
+
+
+def image_losses_workspace(batch, s):
+    return int(lib().shm_image_losses_workspace(batch, s))
+
+
+def image_losses(gen_rgb, cyc_rgb, cyc_y, cbcr, orig_ptrs, ds_ptrs, flags_mask, style_factor, loss, dgen_y, dcyc_y,
+                 ws, batch, s):
+    """orig_ptrs / ds_ptrs: ctypes arrays of 5 device pointers (host memory, read at call time)."""
+    check(lib().shm_image_losses(_p(gen_rgb), _p(cyc_rgb), _p(cyc_y), _p(cbcr), orig_ptrs, ds_ptrs, flags_mask,
+                                 style_factor, _p(loss), _p(dgen_y), _p(dcyc_y), _p(ws),
+                                 ws.numel() * ws.element_size(), batch, s, _stream()), "shm_image_losses")
+
+
+def adam_clip(w, m, v, g, n, alpha, beta1, beta2, eps, gscale):
+    check(lib().shm_adam_clip(_p(w), _p(m), _p(v), _p(g), n, alpha, beta1, beta2, eps, gscale, _stream()),
+          "shm_adam_clip")

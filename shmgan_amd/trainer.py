@@ -1,0 +1,354 @@
+"""Drop-in for the reference trainer object on MI355X.
+
+`ShmGANwithSSpecSeg` mirrors the surface of /root/reference/ShmGANwithSSpecSeg.py:86-1309
+that main.py / test.py use for the training hot path: `__init__(args)`, `build_generator()`,
+`build_discriminator()`, `train_step(orig0, orig45, orig90, orig135, origED)`,
+`custom_per_image_standardization`, `gram_matrix`, the `optimizer_G/D` iteration counters and
+the loss / image attributes `train_step` leaves behind (SHM.py:467-875).
+
+Semantics are the reference's "as executed" ones (SURVEY.md findings 3-7, oracle/step_torch.py
+restates them): batch rule for B>1 = every sample is an independent B=1 reference step and
+the loss is the mean over samples; the style-loss factor is explicit (`style_factor=`); RNG
+draws default to fresh ones but can be injected (`draws=`) for parity tests.
+
+One process drives one GPU.  Under torch.distributed (backend nccl = RCCL) every rank holds
+a replica; gradients are summed with all-reduce on a side stream (D bucket overlapped with
+the generator backward) and scaled by 1/world inside the clip+Adam kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import PAD_C, Arena, Discriminator, Generator
+
+
+class _Optimizer:
+    """Keras adam_v2.Adam(learning_rate=ExponentialDecay(lr0, 10000, 0.95)) bookkeeping
+    (SHM.py:169-175); the update itself is shm_adam_clip."""
+
+    def __init__(self, lr0, beta_1, beta_2, epsilon=1e-7):
+        self.lr0, self.beta_1, self.beta_2, self.epsilon = lr0, beta_1, beta_2, epsilon
+
+    def alpha(self, iterations):
+        t = iterations + 1
+        lr = self.lr0 * 0.95 ** (iterations / 10000.0)
+        return lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply(self, P, gscale=1.0):
+        ops.adam_clip(P.flat, P.m, P.v, P.grad, P.n, self.alpha(P.iterations), self.beta_1, self.beta_2,
+                      self.epsilon, gscale)
+        P.iterations += 1
+
+
+_DEFAULTS = dict(image_size=128, batch_size=1, filter_size=64, g_lr=0.00002, d_lr=0.00002, beta1=0.5, beta2=0.99,
+                 c_dim=5, num_epochs=200, num_iteration_decay=100000, n_critic=5, d_repeat_num=6, mode="train",
+                 data_dir="", model_save_dir="./models", checkpoint_save_dir="./checkpoints", result_dir="./results",
+                 log_dir="./logs/train", log_step=1, checkpoint_save_step=10)
+
+LOSS_NAMES = ["total_Generator_loss", "total_Discriminator_loss", "total_Classification_loss", "G_gan_loss",
+              "G_clsf_loss", "D1_RealFake_loss", "D3_RealFake_cyc", "D2_RealFake_target", "D4_RealFake_cyc",
+              "D1_classification_loss", "D3_classification_loss", "D4_classification_loss", "L1_loss_Gen",
+              "ssim_cyc_loss", "content_loss", "style_loss", "total_NST_loss"]
+
+
+class ShmGANwithSSpecSeg:
+    def __init__(self, args=None, device=None, **overrides):
+        a = dict(_DEFAULTS)
+        if args is not None:
+            a.update({k: v for k, v in vars(args).items()})
+        a.update(overrides)
+        self.args = SimpleNamespace(**a)
+        for k in ("c_dim", "image_size", "batch_size", "num_epochs", "num_iteration_decay", "g_lr", "d_lr", "n_critic",
+                  "beta1", "beta2", "d_repeat_num", "mode", "data_dir", "model_save_dir", "checkpoint_save_dir",
+                  "result_dir", "log_dir", "log_step", "checkpoint_save_step", "filter_size"):
+            setattr(self, k, a[k])
+        # SHM.py:157-212
+        self.seed, self.randomness, self.dropout_amnt = 25, 0.50, 0.2
+        self.TARGET_LABELS = 0.90
+        self.c_dim = 5
+        self.epoch, self.train_G_after = 0, 0
+        self.stddev_arr, self.mean_arr, self.variance_arr = [], [], []
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("shmgan_amd needs an MI355X (ROCm) device: there is no CPU path")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        # both optimisers use the schedule built from g_lr (SHM.py:169-174; d_lr is unused there)
+        self.optimizer_G = _Optimizer(self.g_lr, self.beta1, self.beta2)
+        self.optimizer_D = _Optimizer(self.g_lr, self.beta1, self.beta2)
+        self.arena = Arena(self.device)
+        self._ws = None
+        self.G = self.D = None
+        self.specular_candidate = None          # constant zero in the executed graph (finding 3)
+        self._rng = np.random.default_rng(self.seed)
+        self._comm_stream = None
+        self._loss_cache = None
+        self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, nbytes):
+        n = (nbytes + 3) // 4
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ builders
+    def build_generator(self):
+        """SHM.py:228-327."""
+        return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace)
+
+    def build_discriminator(self):
+        """SHM.py:343-380."""
+        return Discriminator(self.image_size, self.filter_size, self.device, self.arena, self._workspace,
+                             self.dropout_amnt)
+
+    def build(self, seed=42, beta_seed=43):
+        """Build G and D and give them the synthetic init of SURVEY 8(d): weights N(0,0.02) from
+        default_rng(seed) (RandomNormal(0,0.02), SHM.py:200), biases 0, IN beta N(0,0.02)."""
+        self.G = self.build_generator()
+        self.D = self.build_discriminator()
+        rng = np.random.default_rng(seed)
+        gw = [np.zeros(s, np.float32) if len(s) == 1 else rng.normal(0.0, 0.02, s).astype(np.float32)
+              for s in self.G.P.shapes]
+        dw = [rng.normal(0.0, 0.02, s).astype(np.float32) for s in self.D.P.shapes]
+        brng = np.random.default_rng(beta_seed)
+        gb = [brng.normal(0.0, 0.02, (c,)).astype(np.float32) for c in self.G.in_channels]
+        db = [brng.normal(0.0, 0.02, (c,)).astype(np.float32) for c in self.D.chan[1:]]
+        self.G.set_weights(gw)
+        self.D.set_weights(dw)
+        self.G.set_betas(gb)
+        self.D.set_betas(db)
+        return self
+
+    # ------------------------------------------------------------------ small reference helpers
+    def custom_per_image_standardization(self, image):
+        """SHM.py:1271-1309 on an already-YUV [B,S,S,3] tensor: x / max(std, 1/256), statistics
+        per sample, no mean subtraction.  API-parity helper for test.py:218 (off the hot path, plain
+        tensor arithmetic); train_step uses the fused rgb->yuv+standardise kernels (`preprocess`)."""
+        x = self._dev(image)
+        m = x.mean(dim=(1, 2, 3))
+        var = torch.relu((x * x).mean(dim=(1, 2, 3)) - m * m)
+        scale = torch.clamp(torch.sqrt(var), min=1.0 / 256.0)
+        self.stddev_arr = list(scale)
+        return x / scale.view(-1, 1, 1, 1)
+
+    def preprocess(self, rgb, name):
+        """tf.image.rgb_to_yuv + custom_per_image_standardization (SHM.py:480-484, 1271-1309)."""
+        B, S = rgb.shape[0], self.image_size
+        yuv = self.arena.get(f"pre/yuv/{name}", (B, S, S, 3))
+        acc = self.arena.get(f"pre/acc/{name}", (B * 2,), torch.float64)
+        scale = self.arena.get(f"pre/scale/{name}", (B,))
+        ops.rgb2yuv_std(rgb, yuv, acc, scale, B, S * S)
+        return yuv, scale
+
+    def gram_matrix(self, x):
+        """SHM.py:1176-1180 (host-side convenience on a torch tensor; not on the hot path)."""
+        return torch.einsum('bijc,bijd->bcd', x, x) / float(x.shape[1] * x.shape[2])
+
+    # ------------------------------------------------------------------ draws
+    def _default_draws(self, B):
+        S, s = self.image_size, self.image_size // 32
+        flags = tuple(bool(u < self.randomness) for u in self._rng.random(5))
+        noise = torch.randn((2 * B, S, S, 3), device=self.device) * 0.1
+        keep = (torch.rand((2 * B, s, s, 16 * self.filter_size), device=self.device) >= self.dropout_amnt).float()
+        return SimpleNamespace(flags=flags, target_label=float(self.TARGET_LABELS), noise=noise, keep_mask=keep)
+
+    def _dev(self, t):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return t.to(self.device, torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ data parallel
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _allreduce_async(self, flat):
+        """Sum `flat` over ranks on the side stream; returns an event to wait on (or None)."""
+        if self._world() == 1:
+            return None
+        import torch.distributed as dist
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ready)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            done.record(self._comm_stream)
+        return done
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True):
+        """One SHM.py:467-875 step: D update + G update from a 5-view batch [B,S,S,3] in [0,1]."""
+        if self.G is None:
+            self.build()
+        G, D, A = self.G, self.D, self.arena
+        S, F = self.image_size, self.filter_size
+        orig = [self._dev(t) for t in (orig0, orig45, orig90, orig135, origED)]
+        B = orig[0].shape[0]
+        npix = S * S
+        if draws is None:
+            draws = self._default_draws(B)
+        flags = [bool(f) for f in draws.flags]
+        fmask = sum(1 << k for k in range(5) if flags[k])
+        T = float(draws.target_label)
+        noise = self._dev(draws.noise)
+        keep = self._dev(draws.keep_mask)
+        sf = float(self.style_factor if style_factor is None else style_factor)
+        world = self._world()
+
+        G.zero_grad()
+        D.zero_grad()
+        G.prepare_weights()
+        D.prepare_weights()
+
+        # ---- pre-processing (outside the tape)  SHM.py:480-505
+        ds, scales = [], []
+        for k in range(5):
+            y, sc = self.preprocess(orig[k], k)
+            ds.append(y)
+            scales.append(sc)
+        cbcr = A.get("pre/cbcr", (B, S, S, 2))
+        ops.avg_cbcr(ds, cbcr, B * npix)
+
+        # ---- G(1)  SHM.py:517-538
+        gen_in = A.get("g1/in", (B, S, S, PAD_C))
+        ops.build_gen_input(ds, None, fmask, 0, gen_in, B, npix)
+        gen_Y = G.forward(gen_in, "g1")
+
+        # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
+        xd = A.get("d/x16", (12 * B, S, S, PAD_C))
+        gen_rgb = A.get("g1/rgb", (B, S, S, 3))
+        ops.yuv2rgb(gen_Y, cbcr, noise[:B], gen_rgb, xd[0:B], B, B, npix)                  # SHM.py:544-559
+
+        # ---- G(2): cyclic  SHM.py:576-624
+        cyc_in = A.get("cyc/in", (5 * B, S, S, PAD_C))
+        ops.build_gen_input(ds, gen_Y, fmask, 1, cyc_in, B, npix)
+        cyc_Y = G.forward(cyc_in, "cyc")
+        cyc_rgb = A.get("cyc/rgb", (5 * B, S, S, 3))
+        ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, xd[B:6 * B], 5 * B, B, npix)
+        ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
+        for k in range(5):                                                                 # D(4) SHM.py:638-642
+            ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
+
+        # ---- D on all 12B images (noise + dropout on the D1 and D2 slices only)
+        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)])
+        np_ = (S // 32) ** 2
+
+        # ---- losses  SHM.py:669-844
+        dl = A.get("loss/dhead", (16,), torch.float64)
+        drf_d = A.get("loss/drf_d", (12 * B, np_))
+        dcls_d = A.get("loss/dcls_d", (12 * B, 5))
+        drf_g = A.get("loss/drf_g", (6 * B, np_))
+        ops.dhead_losses(rf, cls, dl, drf_d, dcls_d, drf_g, B, np_, T)
+        il = A.get("loss/img", (32,), torch.float64)
+        dgen_y = A.get("loss/dgen_y", (B, S, S, 1))
+        dcyc_y = A.get("loss/dcyc_y", (5 * B, S, S, 1))
+        ws = self._img_ws(B)
+        optr = (C.c_void_p * 5)(*[t.data_ptr() for t in orig])
+        dptr = (C.c_void_p * 5)(*[t.data_ptr() for t in ds])
+        ops.image_losses(gen_rgb, cyc_rgb, cyc_Y, cbcr, optr, dptr, fmask, sf, il, dgen_y, dcyc_y, ws, B, S)
+
+        # ---- D backward (weights) then its all-reduce overlapped with everything below
+        D.backward_params(drf_d, dcls_d)
+        ev_d = self._allreduce_async(D.P.grad)
+
+        # ---- G-loss gradient through D (data gradient only), then G backward
+        dxd = D.backward_input(6 * B, drf_g)
+        ops.rgb16_to_dy(dxd[0:B], dgen_y, B * npix, 1)
+        ops.rgb16_to_dy(dxd[B:6 * B], dcyc_y, 5 * B * npix, 1)
+        dcyc_in = G.backward(dcyc_y, "cyc", need_dx=True)
+        ops.cyc_input_bwd(dcyc_in, fmask, dgen_y, B, npix)       # G o G chain  SHM.py:576-580
+        G.backward(dgen_y, "g1", need_dx=False)
+        G.finish_grads()
+        ev_g = self._allreduce_async(G.P.grad)
+
+        # ---- clip + Adam  SHM.py:859-872
+        if apply:
+            cur = torch.cuda.current_stream()
+            if ev_d is not None:
+                cur.wait_event(ev_d)
+            self.optimizer_D.apply(D.P, 1.0 / world)
+            D.weights_dirty = True
+            if self.epoch >= self.train_G_after:
+                if ev_g is not None:
+                    cur.wait_event(ev_g)
+                self.optimizer_G.apply(G.P, 1.0 / world)
+                G.weights_dirty = True
+        elif world > 1:
+            cur = torch.cuda.current_stream()
+            for ev in (ev_d, ev_g):
+                if ev is not None:
+                    cur.wait_event(ev)
+
+        # ---- attribute side effects (SHM.py:538-553, 620-624, 863, 872)
+        self.gen_input, self.gen_Y, self.gen_rgb = gen_in, gen_Y, gen_rgb
+        self.target_img = orig[4]
+        (self.cyc_gen0_rgb, self.cyc_gen45_rgb, self.cyc_gen90_rgb, self.cyc_gen135_rgb,
+         self.cyc_genED_rgb) = [cyc_rgb[k * B:(k + 1) * B] for k in range(5)]
+        self.RealFake_gen_D1, self.label_gen_D1 = rf[0:B], cls[0:B]
+        self.RealFake_target_D2, self.label_target_D2 = rf[6 * B:7 * B], cls[6 * B:7 * B]
+        self.gradmapD, self.gradmapG = D.P.grads, G.P.grads
+        self.stddev_arr = scales          # reference appends forever (a leak); we keep the last step's
+        self._last = SimpleNamespace(dl=dl, il=il, B=B, flags=flags, T=T, scales=scales, ds=ds, cbcr=cbcr)
+        self._loss_cache = None
+        return None
+
+    def _img_ws(self, B):
+        n = ops.image_losses_workspace(B, self.image_size)
+        return self.arena.get("loss/ws", ((n + 3) // 4,))
+
+    # ------------------------------------------------------------------ named losses (lazy D2H)
+    def losses(self):
+        """Compose the reference's named loss scalars (mean over the batch) from the two f64 loss
+        vectors the kernels filled.  Synchronises (device->host copy) -- call it off the hot path."""
+        if self._loss_cache is not None:
+            return self._loss_cache
+        L = self._last
+        d = (L.dl.cpu().numpy() / L.B).tolist()
+        i = (L.il.cpu().numpy() / L.B).tolist()
+        D1_RF, D3_RF = d[0], d[1]
+        D2_RF = d[4] + d[2]
+        D4_RF = d[5] + d[3] + D2_RF
+        D1_cls, D3_cls, D4_cls = d[6], d[7], d[8]
+        L1 = (i[1] + i[2] + i[3] + i[4] + i[0]) / 5.0 + i[5] * 10.0
+        ssim_loss = (i[11] + i[12] + i[13] + i[14] + i[15] * 10.0) / 5.0
+        content, style = i[16], i[17]
+        nst = 100.0 * style + content
+        out = {
+            "total_Generator_loss": (D1_RF + D3_RF) / 6.0 + 10.0 * L1 + 10.0 * ssim_loss + 10.0 * nst,
+            "total_Discriminator_loss": (D1_cls + D3_cls) / 6.0 + (D2_RF + D4_RF) / 6.0 + 0.5 * D4_cls + 10.0 * nst,
+            "total_Classification_loss": (D4_cls + nst) * 10.0,
+            "G_gan_loss": (D3_RF + D1_RF) / 6.0, "G_clsf_loss": (D3_cls + D1_cls) / 6.0,
+            "D1_RealFake_loss": D1_RF, "D3_RealFake_cyc": D3_RF, "D2_RealFake_target": D2_RF,
+            "D4_RealFake_cyc": D4_RF, "D1_classification_loss": D1_cls, "D3_classification_loss": D3_cls,
+            "D4_classification_loss": D4_cls, "L1_loss_Gen": L1, "ssim_cyc_loss": ssim_loss,
+            "content_loss": content, "style_loss": style, "total_NST_loss": nst,
+            "ssim": [i[6 + k] for k in range(5)],
+        }
+        self._loss_cache = out
+        return out
+
+    def __getattr__(self, name):
+        # reference attribute names for the loss scalars (self.total_Generator_loss, ...)
+        if name in LOSS_NAMES and self.__dict__.get("_last") is not None:
+            return self.losses()[name]
+        raise AttributeError(name)
+
+    @property
+    def gen_rgb_output(self):
+        """SHM.py:548-550: yuv_to_rgb(gen_YCbCr * mean(stddev_arr) * 255) (display only)."""
+        L = self._last
+        avg = torch.stack([s.mean() for s in self.stddev_arr]).mean()
+        yuv = torch.cat([self.gen_Y, L.cbcr], dim=3) * avg * 255.0
+        k = torch.tensor([[1.0, 1.0, 1.0], [0.0, -0.394642334, 2.03206185], [1.13988303, -0.58062185, 0.0]],
+                         device=yuv.device)
+        return yuv @ k

@@ -1,0 +1,224 @@
+"""GPU parity of the loss kernels, whole generator / discriminator passes and the whole
+train_step against the float64 oracle (SURVEY 8(c) tolerances)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_torch as st
+from util import cosine, dev, host, rel_l2, t64
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dhead_losses():
+    from shmgan_amd import ops
+    rng = np.random.default_rng(20)
+    B, npatch, T = 3, 4, 1.07
+    rf = rng.standard_normal((12 * B, npatch))
+    cls = rng.standard_normal((12 * B, 5))
+    rft, clst = t64(rf).requires_grad_(True), t64(cls).requires_grad_(True)
+    sl = lambda g, k=0: slice((g + k) * B, (g + k + 1) * B)       # group start in units of B
+    mse = lambda a, t: ((a - t) ** 2).mean(dim=1)
+    xent = lambda lg, k, w=1.0: -w * torch.log_softmax(lg, -1)[:, k]
+    D1, D2 = sl(0), sl(6)
+    D3 = [sl(1, k) for k in range(5)]
+    D4 = [sl(7, k) for k in range(5)]
+    D1_RF, D3_RF = mse(rft[D1], T), sum(mse(rft[s], T) for s in D3)
+    D2_RF = mse(rft[D2], T) + (rft[D1] ** 2).mean(dim=1)
+    D4_RF = sum(mse(rft[D4[k]], T) + (rft[D3[k]] ** 2).mean(dim=1) for k in range(5)) + D2_RF
+    D1_c, D3_c = xent(clst[D1], 4, T), sum(xent(clst[D3[k]], k) for k in range(5))
+    D4_c = sum(xent(clst[D4[k]], k) for k in range(5))
+    tot_d = ((D1_c + D3_c) / 6 + (D2_RF + D4_RF) / 6 + 0.5 * D4_c + 10 * D4_c).mean()
+    tot_g = ((D1_RF + D3_RF) / 6).mean()
+    gd_rf, gd_cls = torch.autograd.grad(tot_d, [rft, clst], retain_graph=True)
+    gg_rf, = torch.autograd.grad(tot_g, [rft])
+    loss = torch.empty(16, dtype=torch.float64, device="cuda")
+    drf_d = torch.empty((12 * B, npatch), device="cuda")
+    dcls_d = torch.empty((12 * B, 5), device="cuda")
+    drf_g = torch.empty((6 * B, npatch), device="cuda")
+    ops.dhead_losses(dev(rf), dev(cls), loss, drf_d, dcls_d, drf_g, B, npatch, T)
+    assert rel_l2(host(drf_d), gd_rf.numpy()) < 1e-5
+    assert rel_l2(host(dcls_d), gd_cls.numpy()) < 1e-5
+    assert rel_l2(host(drf_g), gg_rf.numpy()[:6 * B]) < 1e-5
+    L = host(loss)
+    ref = [D1_RF.sum(), D3_RF.sum(), (rft[D1] ** 2).mean(dim=1).sum(),
+           sum((rft[s] ** 2).mean(dim=1) for s in D3).sum(), mse(rft[D2], T).sum(),
+           sum(mse(rft[s], T) for s in D4).sum(), D1_c.sum(), D3_c.sum(), D4_c.sum()]
+    assert rel_l2(L[:9], [float(r) for r in ref]) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,flags", [(1, 32, (False, True, False, False, False)), (2, 48, (True, False, False, True, False))])
+def test_image_losses(B, S, flags):
+    from shmgan_amd import ops
+    rng = np.random.default_rng(21)
+    npix = S * S
+    orig = [rng.random((B, S, S, 3)) for _ in range(5)]
+    ds = [st.per_image_standardization(st.rgb_to_yuv(t64(o)))[0] for o in orig]
+    cbcr = sum(d[..., 1:] for d in ds) / 5.0
+    gen_y = t64(rng.standard_normal((B, S, S, 1)) * 0.5 + 1.0).requires_grad_(True)
+    cyc_y = t64(rng.standard_normal((5 * B, S, S, 1)) * 0.5 + 1.0).requires_grad_(True)
+    gen_rgb = st.yuv_to_rgb(torch.cat([gen_y, cbcr], 3))
+    cyuv = [torch.cat([cyc_y[k * B:(k + 1) * B], cbcr], 3) for k in range(5)]
+    crgb = [st.yuv_to_rgb(c) for c in cyuv]
+    l1 = lambda a, b: (a - b).abs().mean(dim=(1, 2, 3))
+    L1 = (sum(l1(crgb[k], t64(orig[k])) for k in range(4)) + l1(gen_rgb, t64(orig[4]))) / 5 + 10 * l1(crgb[4], t64(orig[4]))
+    ssims = [st.ssim(st.rescale_01(cyuv[k]), st.rescale_01(ds[k])) for k in range(5)]
+    sl = [torch.zeros(B, dtype=torch.float64) if flags[k] else -torch.log((1 + ssims[k]) / 2) for k in range(5)]
+    ssim_loss = (sl[0] + sl[1] + sl[2] + sl[3] + 10 * sl[4]) / 5
+    sf = 3.0e-3          # large enough that the style term is visible in the gradient
+    content = ((cyuv[4] - ds[0]) ** 2).mean(dim=(1, 2, 3))
+    style = sf * ((st.gram_matrix(cyuv[4]) - st.gram_matrix(ds[4])) ** 2).mean(dim=(1, 2))
+    tot = (10 * L1 + 10 * ssim_loss + 10 * (100 * style + content)).mean()
+    rg, rc = torch.autograd.grad(tot, [gen_y, cyc_y])
+
+    fmask = sum(1 << k for k in range(5) if flags[k])
+    od = [dev(o) for o in orig]
+    dd = [dev(d.numpy()) for d in ds]
+    loss = torch.empty(32, dtype=torch.float64, device="cuda")
+    dg = torch.empty((B, S, S, 1), device="cuda")
+    dc = torch.empty((5 * B, S, S, 1), device="cuda")
+    ws = torch.empty(ops.image_losses_workspace(B, S) // 4 + 1, device="cuda")
+    optr = (C.c_void_p * 5)(*[t.data_ptr() for t in od])
+    dptr = (C.c_void_p * 5)(*[t.data_ptr() for t in dd])
+    ops.image_losses(dev(gen_rgb.detach().numpy()), dev(torch.cat(crgb, 0).detach().numpy()), dev(cyc_y.detach().numpy()),
+                     dev(cbcr.numpy()), optr, dptr, fmask, sf, loss, dg, dc, ws, B, S)
+    L = host(loss)
+    assert abs(L[0] - float(l1(gen_rgb, t64(orig[4])).sum())) < 1e-5 * B
+    for k in range(5):
+        assert abs(L[1 + k] - float(l1(crgb[k], t64(orig[k])).sum())) < 1e-5 * B
+        assert abs(L[6 + k] - float(ssims[k].sum())) < 2e-5 * B, (k, L[6 + k], float(ssims[k].sum()))
+        assert abs(L[11 + k] - float(sl[k].sum())) < 2e-5 * B
+    assert abs(L[16] - float(content.sum())) < 1e-5 * B * max(1.0, float(content.max()))
+    assert abs(L[17] - float(style.sum())) < 1e-5 * max(1.0, float(style.sum()))
+    assert rel_l2(host(dg), rg.numpy()) < 1e-4
+    assert rel_l2(host(dc), rc.numpy()) < 1e-4, cosine(host(dc), rc.numpy())
+
+
+def _mk(S, F, B):
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+    g, d, gb, db = st.init_params(F, S)
+    # the product's own init must equal the oracle's (same seeds, same order)
+    for a, b in zip(m.G.get_weights(), g):
+        assert np.array_equal(a, b)
+    for a, b in zip(m.D.get_weights(), d):
+        assert np.array_equal(a, b)
+    return m, (g, d, gb, db)
+
+
+def test_generator_forward_backward():
+    S, F, B = 32, 16, 2
+    m, (g, d, gb, db) = _mk(S, F, B)
+    rng = np.random.default_rng(30)
+    x = rng.standard_normal((B, S, S, 10))
+    dy = rng.standard_normal((B, S, S, 1))
+    gv = [t64(a).requires_grad_(True) for a in g]
+    xt = t64(x).requires_grad_(True)
+    yt = st.generator_forward(gv, [t64(b) for b in gb], xt, F)
+    grads = torch.autograd.grad(yt, gv + [xt], t64(dy))
+    x16 = torch.zeros((B, S, S, 16), device="cuda")
+    x16[..., :10] = dev(x)
+    y = m.G.forward(x16, "t")
+    assert np.abs(host(y) - yt.detach().numpy()).max() < 1e-4
+    m.G.zero_grad()
+    dx = m.G.backward(dev(dy), "t", need_dx=True)
+    m.G.finish_grads()
+    torch.cuda.synchronize()
+    assert rel_l2(host(dx)[..., :10], grads[-1].numpy()) < 1e-3
+    for i, (got, ref) in enumerate(zip(m.G.P.grads, grads[:-1])):
+        r = rel_l2(host(got), ref.numpy())
+        assert r < 1e-3 and cosine(host(got), ref.numpy()) > 0.9999, (i, r)
+
+
+def test_discriminator_forward_backward():
+    S, F, B = 64, 16, 3
+    m, (g, d, gb, db) = _mk(S, F, B)
+    rng = np.random.default_rng(31)
+    x = rng.random((B, S, S, 3))
+    s = S // 32
+    noise = rng.standard_normal((B, S, S, 3)) * 0.1
+    keep = (rng.random((B, s, s, 16 * F)) >= 0.2).astype(np.float32)
+    dv = [t64(a).requires_grad_(True) for a in d]
+    xt = t64(x).requires_grad_(True)
+    rf, cls = st.discriminator_forward(dv, [t64(b) for b in db], xt, t64(noise), t64(keep))
+    g_rf, g_cls = rng.standard_normal(tuple(rf.shape)), rng.standard_normal(tuple(cls.shape))
+    grads = torch.autograd.grad([rf, cls], dv + [xt], [t64(g_rf), t64(g_cls)], retain_graph=True)
+    gx_only, = torch.autograd.grad([rf], [xt], [t64(g_rf)])
+    rfd, clsd = m.D(dev(x), training=True, noise=dev(noise), keep_mask=dev(keep))
+    assert np.abs(host(rfd) - rf.detach().numpy()).max() < 1e-4
+    assert np.abs(host(clsd) - cls.detach().numpy()).max() < 1e-4
+    m.D.zero_grad()
+    m.D.backward_params(dev(g_rf), dev(g_cls))
+    for i, (got, ref) in enumerate(zip(m.D.P.grads, grads[:-1])):
+        r = rel_l2(host(got), ref.numpy())
+        assert r < 1e-3 and cosine(host(got), ref.numpy()) > 0.9999, (i, r)
+    dx = m.D.backward_input(B, dev(g_rf))
+    assert rel_l2(host(dx)[..., :3], gx_only.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("S,F,B,step", [(64, 16, 1, 0), (64, 16, 2, 1)])
+def test_train_step_parity(S, F, B, step):
+    m, (g, d, gb, db) = _mk(S, F, B)
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(step, B, S, F)
+    sf = st.style_factor_intended(S)
+    ref = st.train_step(g, d, gb, db, inp, dr, sf, F)
+    m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
+    torch.cuda.synchronize()
+    got = m.losses()
+    for k, v in ref["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    assert np.abs(host(m.gen_Y) - ref["outs"]["gen_Y"].numpy()).max() < 1e-4
+    assert np.abs(host(m.gen_rgb) - ref["outs"]["gen_rgb"].numpy()).max() < 1e-4
+    for name, P, rg in (("D", m.D.P, ref["gD"]), ("G", m.G.P, ref["gG"])):
+        for i, (got_g, r) in enumerate(zip(P.grads, rg)):
+            r = r.numpy()
+            if np.linalg.norm(r) < 1e-12:
+                continue
+            e = rel_l2(host(got_g), r)
+            assert e < 1e-3 and cosine(host(got_g), r) > 0.9999, (name, i, e)
+    # optimizer: apply and compare with the oracle's clip+Adam
+    gv = [t64(a).clone() for a in g]
+    dvv = [t64(a).clone() for a in d]
+    sg = st.AdamState([torch.zeros_like(a) for a in gv], [torch.zeros_like(a) for a in gv])
+    sd = st.AdamState([torch.zeros_like(a) for a in dvv], [torch.zeros_like(a) for a in dvv])
+    st.adam_apply(dvv, ref["gD"], sd, 2e-5, 0.5, 0.99)
+    st.adam_apply(gv, ref["gG"], sg, 2e-5, 0.5, 0.99)
+    m.optimizer_D.apply(m.D.P)
+    m.optimizer_G.apply(m.G.P)
+    torch.cuda.synchronize()
+    for got_w, r in zip(m.G.P.vars + m.D.P.vars, gv + dvv):
+        assert np.abs(host(got_w) - r.numpy()).max() < 2e-5     # one Adam step moves a weight by <= lr*~1
+
+
+def test_train_step_properties_full_size():
+    """S=256, F=64, B=1: size-independent checks (no oracle at this size in the GPU suite):
+    finite losses, IN outputs normalised, and gradient linearity in the batch rule (B=2 of the same
+    sample twice == B=1)."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F = 256, 64
+    inp1 = st.make_inputs(1, S)
+    dr1 = st.make_draws(3, 1, S, F)
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=1).build()
+    m.train_step(*inp1, draws=dr1, apply=False)
+    torch.cuda.synchronize()
+    l1 = dict(m.losses())
+    g1 = m.G.P.grad.clone()
+    d1 = m.D.P.grad.clone()
+    assert all(np.isfinite(v) for k, v in l1.items() if k != "ssim")
+    assert m.G.count_params() == 18525569 and m.D.count_params() == 6605504
+    # the same sample twice -> identical mean loss and gradients
+    inp2 = [np.concatenate([a, a], 0) for a in inp1]
+    dr2 = st.StepDraws(dr1.flags, dr1.target_label, np.concatenate([dr1.noise[:1], dr1.noise[:1], dr1.noise[1:], dr1.noise[1:]], 0),
+                       np.concatenate([dr1.keep_mask[:1], dr1.keep_mask[:1], dr1.keep_mask[1:], dr1.keep_mask[1:]], 0))
+    m2 = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=2).build()
+    m2.train_step(*inp2, draws=dr2, apply=False)
+    torch.cuda.synchronize()
+    l2 = m2.losses()
+    for k in l1:
+        if k != "ssim":
+            assert abs(l1[k] - l2[k]) <= 1e-5 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
+    assert rel_l2(host(m2.G.P.grad), host(g1)) < 1e-4
+    assert rel_l2(host(m2.D.P.grad), host(d1)) < 1e-4
