@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""SHMGAN train_step benchmark on MI355X (BASELINE.json metric: images/sec of one full
+generator+discriminator step at 256x256, batch 8 per GPU, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`: one process per GPU, RCCL all-reduce of the D and G gradients (weak scaling: the
+per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
+
+A "step" = pre-processing + 6 generator forwards + 12 discriminator forwards + both backward
+passes + clip + 2 Adam updates (+ all-reduce) on one synthetic batch already resident in HBM.
+`roofline` is measured live: every MFMA conv launch of the timed steps is bracketed by HIP events
+on its stream; the dominant kernel symbol's algorithmic FLOPs / its summed duration is `achieved`.
+`cpu_baseline` times the CPU oracle (PyTorch-CPU/oneDNN restatement of the same step, fp32) on
+this box's host cores on a bounded sample (B=1 steps at the same image size).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE: 8)")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--filter-size", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from shmgan_amd import ShmGANwithSSpecSeg, ops
+
+    S, F, B = args.image_size, args.filter_size, args.batch
+    model = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, device=dev).build()
+
+    # synthetic inputs, resident in HBM before the timed region
+    rng = np.random.default_rng(1234 + rank)
+    inputs = [torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).to(dev) for _ in range(5)]
+    s = S // 32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7 + rank)
+
+    class Draws:
+        pass
+
+    def draws_for(step):
+        r = np.random.default_rng(7 + step)              # flags / TARGET_LABELS shared by all ranks
+        d = Draws()
+        d.flags = tuple(bool(u < 0.5) for u in r.random(5))
+        d.target_label = float(r.uniform(0.8, 1.2))
+        d.noise = torch.randn((2 * B, S, S, 3), device=dev, generator=gen) * 0.1
+        d.keep_mask = (torch.rand((2 * B, s, s, 16 * F), device=dev, generator=gen) >= 0.2).float()
+        return d
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.train_step(*inputs, draws=draws_for(i))
+    sync()
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.train_step(*inputs, draws=draws_for(args.warmup + i))
+    sync()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.losses()
+    finite = all(np.isfinite(v) for k, v in losses.items() if k != "ssim")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "images/sec (gen+disc train_step)", "value": round(value, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, fp32 "
+                                   "(BASELINE configs[1])",
+                       "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
+                       "losses_finite": bool(finite)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "flops_per_launch": d["flops"] / d["launches"],
+                "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
+            }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(S, F, steps):
+    """The oracle (PyTorch-CPU / oneDNN restatement of the step) in fp32 on the host cores."""
+    import torch
+    from oracle import step_torch as st
+    torch.set_num_threads(os.cpu_count() or 1)
+    g, d, gb, db = st.init_params(F, S)
+    inp = st.make_inputs(1, S)
+    sf = st.style_factor_intended(S)
+    st.train_step(g, d, gb, db, inp, st.make_draws(0, 1, S, F), sf, F, dtype=torch.float32)      # warm-up
+    t0 = time.perf_counter()
+    for i in range(steps):
+        st.train_step(g, d, gb, db, inp, st.make_draws(1 + i, 1, S, F), sf, F, dtype=torch.float32)
+    dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of B=1 at {S}x{S}, fp32, forward+both gradient passes (no optimizer apply), "
+                      "after 1 warm-up step"}
+
+
+if __name__ == "__main__":
+    main()

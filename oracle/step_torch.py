@@ -121,7 +121,7 @@ def conv2d_same(x, w_hwio, stride=1):
     pl, pr = _same_pads(x.shape[3], kw, stride)
     if pt or pb or pl or pr:
         x = F.pad(x, (pl, pr, pt, pb))
-    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), stride=stride)
+    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1).contiguous(), stride=stride)
 
 
 def conv2d_transpose_same(x, w_hwoi, stride=2):
@@ -131,7 +131,7 @@ def conv2d_transpose_same(x, w_hwoi, stride=2):
     H, W = x.shape[2] * stride, x.shape[3] * stride
     pt, _ = _same_pads(H, kh, stride)
     pl, _ = _same_pads(W, kw, stride)
-    y = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), stride=stride)
+    y = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1).contiguous(), stride=stride)
     return y[:, :, pt:pt + H, pl:pl + W]
 
 
@@ -143,8 +143,9 @@ def instance_norm(x, beta):
     return x * inv + (beta.view(1, -1, 1, 1) - mean * inv)
 
 
-def generator_forward(gvars, gbetas, x_nhwc, filter_size=64):
-    """SHM.py:228-327.  x [B,S,S,10] -> [B,S,S,1]."""
+def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None):
+    """SHM.py:228-327.  x [B,S,S,10] -> [B,S,S,1].  record: optional list that receives, per
+    Conv->LReLU->IN block, (pre-activation z, IN output) with retain_grad (test diagnostics)."""
     spec = generator_spec(filter_size)
     x = x_nhwc.permute(0, 3, 1, 2)
     vi = [0]
@@ -157,8 +158,12 @@ def generator_forward(gvars, gbetas, x_nhwc, filter_size=64):
 
     def cnl(x):           # Conv2D(act=leaky_relu) -> InstanceNormalization
         w, b = nxt()
-        x = F.leaky_relu(conv2d_same(x, w) + b.view(1, -1, 1, 1), LRELU)
-        x = instance_norm(x, gbetas[bi[0]])
+        z = conv2d_same(x, w) + b.view(1, -1, 1, 1)
+        x = instance_norm(F.leaky_relu(z, LRELU), gbetas[bi[0]])
+        if record is not None:
+            z.retain_grad()
+            x.retain_grad()
+            record.append((z, x))
         bi[0] += 1
         return x
 
@@ -432,6 +437,10 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
                     "ssim": [s_.detach() for s_ in ssims], "scales": [s_.detach() for s_ in scales]}}
     if need_grads:
         gD = torch.autograd.grad((total_D + total_C).mean(), dv, retain_graph=True)
+        # intermediate generator-loss gradients (test diagnostics): wrt the 5 cyclic outputs and
+        # the total derivative wrt gen_Y (direct terms + the G o G chain through the cyclic inputs)
+        mid = torch.autograd.grad(total_G.mean(), cyc_Y + [gen_Y], retain_graph=True)
+        out["dcyc_Y"], out["dgen_Y"] = [m_.detach() for m_ in mid[:5]], mid[5].detach()
         gG = torch.autograd.grad(total_G.mean(), gv)
         out["gD"], out["gG"] = list(gD), list(gG)
     return out

@@ -153,6 +153,7 @@ class Generator(_ModelBase):
                 self.wk[i] = torch.zeros(9 * cin * cout, dtype=torch.float32, device=device)
         self.weights_dirty = True
         self.ctx = {}
+        self.debug = None
 
     # -- parameter plumbing ---------------------------------------------------------------
     def set_betas(self, arrays):
@@ -193,7 +194,7 @@ class Generator(_ModelBase):
         ahat = A.get(f"{tag}/h{li}", (n, h, w, cout))
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
         ops.conv2d_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
-                       k, 1, LRELU)
+                       k, 1, LRELU, cin_real=cin)
         ops.in_stats(a, cout, stats, n, h * w, cout, IN_EPS)
         ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
@@ -262,6 +263,8 @@ class Generator(_ModelBase):
         red = A.get(f"bwd/red/{n * cout}", (n * cout * 2,), torch.float64)
         ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
                    h, w, cout, LRELU)
+        if self.debug is not None:           # test diagnostics: keep the per-layer gradients
+            self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
         cin_p = _pad16(cin)
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
         ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout, self.P.grads[2 * li], n,
@@ -408,7 +411,8 @@ class Discriminator(_ModelBase):
             a = A.get(f"d/a{i}/{n}", (n, ho, ho, cout))
             ahat = A.get(f"d/h{i}/{n}", (n, ho, ho, cout))
             stats = A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)
-            ops.conv2d_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU)
+            ops.conv2d_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU,
+                           cin_real=cin)
             ops.in_stats(a, cout, stats, n, ho * ho, cout, IN_EPS)
             ops.in_apply(a, cout, stats, self.betas[i], ahat, cout, n, ho * ho, cout)
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))

@@ -15,6 +15,47 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of the MFMA conv launches on the stream they run on (bench.py
+    `roofline`).  Enabled by setting ops.TIMER = KernelTimer(); records (kernel symbol,
+    algorithmic flops, start event, end event) per launch."""
+
+    def __init__(self):
+        self.recs = []
+
+    def wrap(self, sym, flops, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.recs.append((sym, flops, e0, e1))
+
+    def summary(self):
+        """{symbol: dict(launches, ms, flops)} -- call after a device synchronize."""
+        out = {}
+        for sym, flops, e0, e1 in self.recs:
+            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+TIMER = None
+
+
+def _tile(nout):
+    return "tapgemm_kernel<128,128>" if nout > 64 else "tapgemm_kernel<128,64>"
+
+
+def _timed(sym, flops, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.wrap(sym, flops, fn)
+
+
 def _p(t):
     return 0 if t is None else t.data_ptr()
 
@@ -23,19 +64,29 @@ def transpose_taps(w, wt, ntaps, rows, cols, rows_pad):
     check(lib().shm_transpose_taps(_p(w), _p(wt), ntaps, rows, cols, rows_pad, _stream()), "shm_transpose_taps")
 
 
-def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope):
-    check(lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                               cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd")
+def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope,
+               cin_real=None):
+    """cin_real: un-padded input channels, only used for the algorithmic flop count."""
+    ho, wo = -(-hi // stride), -(-wi // stride)
+    flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
+    _timed(_tile(cout), flops, lambda: check(
+        lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                             cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd"))
 
 
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
-    check(lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
-                                 cout, ksize, stride, _stream()), "shm_conv2d_dgrad")
+    ho, wo = -(-hi // stride), -(-wi // stride)
+    flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
+    _timed(_tile(cin), flops, lambda: check(
+        lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
+                               cout, ksize, stride, _stream()), "shm_conv2d_dgrad"))
 
 
 def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
-    check(lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
-                                         slope, _stream()), "shm_conv2d_transpose_fwd")
+    flops = 2.0 * batch * hi * wi * 9 * cin * cout
+    _timed(_tile(cout), flops, lambda: check(
+        lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
+                                       slope, _stream()), "shm_conv2d_transpose_fwd"))
 
 
 def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
@@ -44,9 +95,12 @@ def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
 
 def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride,
                  accumulate, ws):
-    check(lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
-                                 cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
-                                 _stream()), "shm_conv2d_wgrad")
+    ho, wo = -(-hi // stride), -(-wi // stride)
+    flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
+    _timed("wgrad_kernel<%d>" % (ksize * ksize), flops, lambda: check(
+        lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
+                               cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
+                               _stream()), "shm_conv2d_wgrad"))
 
 
 def in_stats(a, lda, stats, batch, hw, c, eps):

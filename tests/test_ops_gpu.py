@@ -259,10 +259,12 @@ def test_lrelu_bwd_head_patch_dense_mask():
     hp, cp = 4, 256
     x = rng.standard_normal((n, hp, hp, cp))
     w = rng.standard_normal((3, 3, cp, 1)) * 0.05
-    xt, wt = nchw(x).requires_grad_(True), t64(w).requires_grad_(True)
-    yt = F.leaky_relu(st.conv2d_same(xt, wt, 1), 0.2)
+    xt = nchw(x).requires_grad_(True)
+    wo = t64(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)      # OIHW leaf (Cout = 1)
+    yt = F.leaky_relu(F.conv2d(xt, wo, padding=1), 0.2)
     g = rng.standard_normal((n, hp, hp, 1))
-    rdx, rdw = torch.autograd.grad(yt, [xt, wt], nchw(g))
+    rdx, rdw = torch.autograd.grad(yt, [xt, wo], nchw(g))
+    rdw = rdw.permute(2, 3, 1, 0)
     yd = torch.empty((n, hp, hp, 1), device="cuda")
     ops.patch_fwd(dev(x), cp, dev(w), yd, n, hp, hp, cp, 0.2)
     assert rel_l2(host(yd), nhwc(yt.detach())) < TOL
