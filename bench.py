@@ -45,6 +45,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,8 +87,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model built, arena {model.arena.nbytes() / 2**30:.2f} GiB")
     for i in range(args.warmup):
         model.train_step(*inputs, draws=draws_for(i))
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
     sync()
     timer = None
     if not args.no_kernel_timer and rank == 0:
@@ -99,6 +107,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.TIMER = None
+    note(f"timed {args.steps} steps in {dt:.3f}s")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,24 +142,27 @@ def main():
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
             }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(S, F, steps):
+def cpu_baseline(S, F, steps, note=lambda m: None):
     """The oracle (PyTorch-CPU / oneDNN restatement of the step) in fp32 on the host cores."""
     import torch
     from oracle import step_torch as st
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than that only oversubscribe
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
     g, d, gb, db = st.init_params(F, S)
     inp = st.make_inputs(1, S)
     sf = st.style_factor_intended(S)
     st.train_step(g, d, gb, db, inp, st.make_draws(0, 1, S, F), sf, F, dtype=torch.float32)      # warm-up
+    note("cpu baseline warm-up step done")
     t0 = time.perf_counter()
     for i in range(steps):
         st.train_step(g, d, gb, db, inp, st.make_draws(1 + i, 1, S, F), sf, F, dtype=torch.float32)
+        note(f"cpu baseline step {i} done")
     dt = time.perf_counter() - t0
     return {"value": round(steps / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} steps of B=1 at {S}x{S}, fp32, forward+both gradient passes (no optimizer apply), "

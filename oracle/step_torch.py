@@ -143,7 +143,20 @@ def instance_norm(x, beta):
     return x * inv + (beta.view(1, -1, 1, 1) - mean * inv)
 
 
-def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None):
+def _act(z, masks, idx):
+    """LeakyReLU(0.2).  `masks` (optional list of NHWC bool arrays, one per activation in layer
+    order) pins which side of the kink every element is evaluated on: a float32 device can round a
+    |z| < 1e-6 pre-activation to the other side of 0, where the derivative jumps 0.2 <-> 1; giving
+    the oracle the device's sign pattern removes those (legitimate) discontinuity events from a
+    gradient comparison.  The forward value changes by at most 0.8*|z| ~ 1e-6 there."""
+    if masks is None:
+        return F.leaky_relu(z, LRELU)
+    m = torch.as_tensor(np.asarray(masks[idx])).bool()
+    m = m.permute(0, 3, 1, 2) if m.dim() == 4 else m
+    return torch.where(m, z, LRELU * z)
+
+
+def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None, masks=None):
     """SHM.py:228-327.  x [B,S,S,10] -> [B,S,S,1].  record: optional list that receives, per
     Conv->LReLU->IN block, (pre-activation z, IN output) with retain_grad (test diagnostics)."""
     spec = generator_spec(filter_size)
@@ -159,10 +172,11 @@ def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None):
     def cnl(x):           # Conv2D(act=leaky_relu) -> InstanceNormalization
         w, b = nxt()
         z = conv2d_same(x, w) + b.view(1, -1, 1, 1)
-        x = instance_norm(F.leaky_relu(z, LRELU), gbetas[bi[0]])
+        x = instance_norm(_act(z, masks, vi[0] // 2 - 1), gbetas[bi[0]])
         if record is not None:
-            z.retain_grad()
-            x.retain_grad()
+            if z.requires_grad:
+                z.retain_grad()
+                x.retain_grad()
             record.append((z, x))
         bi[0] += 1
         return x
@@ -175,16 +189,16 @@ def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None):
     x = cnl(cnl(x))                           # the two 1x1 layers (SHM.py:280-282)
     for lvl in range(4):
         w, b = nxt()
-        x = F.leaky_relu(conv2d_transpose_same(x, w) + b.view(1, -1, 1, 1), LRELU)
+        x = _act(conv2d_transpose_same(x, w) + b.view(1, -1, 1, 1), masks, vi[0] // 2 - 1)
         x = torch.cat([x, downs[3 - lvl]], dim=1)       # upsampled first, skip second
         x = cnl(cnl(x))
     w, b = nxt()
-    x = F.leaky_relu(conv2d_same(x, w) + b.view(1, -1, 1, 1), LRELU)
+    x = _act(conv2d_same(x, w) + b.view(1, -1, 1, 1), masks, vi[0] // 2 - 1)
     assert vi[0] == len(spec) * 2 and bi[0] == len(gbetas)
     return x.permute(0, 2, 3, 1)
 
 
-def discriminator_forward(dvars, dbetas, x_nhwc, noise=None, keep_mask=None, dropout=0.2):
+def discriminator_forward(dvars, dbetas, x_nhwc, noise=None, keep_mask=None, dropout=0.2, masks=None):
     """SHM.py:343-389.  x [B,S,S,3] -> ([B,s,s,1], [B,5]).  training=True <=> noise and
     keep_mask given: GaussianNoise adds `noise`; Dropout multiplies by keep_mask/(1-rate)."""
     x = x_nhwc
@@ -192,11 +206,11 @@ def discriminator_forward(dvars, dbetas, x_nhwc, noise=None, keep_mask=None, dro
         x = x + noise
     x = x.permute(0, 3, 1, 2)
     for i in range(5):
-        x = F.leaky_relu(conv2d_same(x, dvars[i], stride=2), LRELU)
+        x = _act(conv2d_same(x, dvars[i], stride=2), masks, i)
         x = instance_norm(x, dbetas[i])       # (+ attn_disc == + 0 after block 4)
     if keep_mask is not None:
         x = x * keep_mask.permute(0, 3, 1, 2) / (1.0 - dropout)
-    rf = F.leaky_relu(conv2d_same(x, dvars[5]), LRELU).permute(0, 2, 3, 1)
+    rf = _act(conv2d_same(x, dvars[5]), masks, 5).permute(0, 2, 3, 1)
     flat = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)       # Flatten of NHWC
     cls = flat @ dvars[6]
     return rf, cls
@@ -333,13 +347,20 @@ def adam_apply(params, grads, st: AdamState, lr0, beta1, beta2, eps=1e-7):
 # ---------------------------------------------------------------------------
 # the step
 # ---------------------------------------------------------------------------
+def _mslice(masks, lo, hi):
+    return None if masks is None else [np.asarray(m)[lo:hi] for m in masks]
+
+
 def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_factor,
-               filter_size=64, dtype=torch.float64, need_grads=True):
+               filter_size=64, dtype=torch.float64, need_grads=True, masks=None):
     """One SHM.py:467-875 forward + both tape.gradient calls (no optimizer apply).
 
     gvars/dvars/gbetas/dbetas: lists of numpy arrays or tensors (TF layouts).
     inputs: 5 x [B,S,S,3] in [0,1].  Returns dict(losses=..., gG=[...], gD=[...], outs=...).
+    masks: optional {"g1": [23 x [B,...]], "cyc": [23 x [5B,...]], "d": [6 x [12B,...]]} LeakyReLU
+    sign patterns taken from the device run (see _act); D batch order [D1][D3 x5][D2][D4 x5].
     """
+    mk = masks or {}
     T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype)
     gv = [T(a).clone().requires_grad_(need_grads) for a in gvars]
     dv = [T(a).clone().requires_grad_(need_grads) for a in dvars]
@@ -366,13 +387,14 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     # G(1)  SHM.py:517-538
     rand_inp = [zeros if flags[k] else Ych[k] for k in range(5)]
     gen_input = torch.cat(rand_inp + [zeros, zeros, zeros, zeros, ones], dim=3)
-    gen_Y = generator_forward(gv, gb, gen_input, filter_size)
+    gen_Y = generator_forward(gv, gb, gen_input, filter_size, masks=mk.get("g1"))
     gen_yuv = torch.cat([gen_Y, avgCbCr], dim=3)
     gen_rgb = yuv_to_rgb(gen_yuv)
 
     # D(1), D(2): training=True  SHM.py:559-563
-    rf_D1, cls_D1 = discriminator_forward(dv, db, gen_rgb, noise[:B], keep[:B])
-    rf_D2, cls_D2 = discriminator_forward(dv, db, orig[4], noise[B:], keep[B:])
+    md = mk.get("d")
+    rf_D1, cls_D1 = discriminator_forward(dv, db, gen_rgb, noise[:B], keep[:B], masks=_mslice(md, 0, B))
+    rf_D2, cls_D2 = discriminator_forward(dv, db, orig[4], noise[B:], keep[B:], masks=_mslice(md, 6 * B, 7 * B))
 
     # G(2): cyclic inputs  SHM.py:576-607
     sub = [gen_Y if flags[k] else Ych[k] for k in range(5)]
@@ -380,13 +402,14 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     for k in range(5):
         chans = [zeros if j == k else sub[j] for j in range(5)]
         onehot = [ones if j == k else zeros for j in range(5)]
-        cyc_Y.append(generator_forward(gv, gb, torch.cat(chans + onehot, dim=3), filter_size))
+        cyc_Y.append(generator_forward(gv, gb, torch.cat(chans + onehot, dim=3), filter_size,
+                                       masks=_mslice(mk.get("cyc"), k * B, (k + 1) * B)))
     cyc_yuv = [torch.cat([cy, avgCbCr], dim=3) for cy in cyc_Y]
     cyc_rgb = [yuv_to_rgb(c) for c in cyc_yuv]
 
     # D(3), D(4): training=False  SHM.py:627-642
-    D3 = [discriminator_forward(dv, db, c) for c in cyc_rgb]
-    D4 = [discriminator_forward(dv, db, o) for o in orig]
+    D3 = [discriminator_forward(dv, db, c, masks=_mslice(md, (1 + k) * B, (2 + k) * B)) for k, c in enumerate(cyc_rgb)]
+    D4 = [discriminator_forward(dv, db, o, masks=_mslice(md, (7 + k) * B, (8 + k) * B)) for k, o in enumerate(orig)]
 
     def mse(a, t):      # per-sample mean -> [B]
         return ((a - t) ** 2).mean(dim=(1, 2, 3))

@@ -343,6 +343,18 @@ class Generator(_ModelBase):
                 self._cnl_bwd(tag, r1, dmid, None, n, False)
         return None
 
+    def lrelu_masks(self, tag):
+        """Sign pattern (a > 0) of the 23 LeakyReLU outputs of the forward tagged `tag`, in layer
+        order (test diagnostics: lets the float64 oracle take the same side of every kink)."""
+        c = self.ctx[tag]
+        out = [None] * len(self.layers)
+        for r in c["recs"]:
+            out[r["li"]] = (r["a"] > 0).cpu().numpy()
+        for u in c["ups"]:
+            out[u["li"]] = (u["u"] > 0).cpu().numpy()
+        out[-1] = (c["y"] > 0).cpu().numpy()
+        return out
+
     def __call__(self, x, training=False, tag="call"):
         """Keras-style call on a [N,S,S,10] tensor (reference: self.G(x, training=...))."""
         n = x.shape[0]
@@ -474,6 +486,11 @@ class Discriminator(_ModelBase):
     def backward_input(self, n, drf):
         """G-loss backward (data gradient only) through the first n samples."""
         return self._backward(n, drf, None, False, True)
+
+    def lrelu_masks(self):
+        """Sign pattern of the 6 LeakyReLU outputs of the last forward (5 convs + patch logits)."""
+        c = self.ctx
+        return [(r["a"] > 0).cpu().numpy() for r in c["recs"]] + [(c["rf"] > 0).cpu().numpy()]
 
     def __call__(self, x, training=False, noise=None, keep_mask=None):
         """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""

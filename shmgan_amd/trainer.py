@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .dist import GradReducer, world_size
 from .model import PAD_C, Arena, Discriminator, Generator
 
 
@@ -87,7 +88,7 @@ class ShmGANwithSSpecSeg:
         self.G = self.D = None
         self.specular_candidate = None          # constant zero in the executed graph (finding 3)
         self._rng = np.random.default_rng(self.seed)
-        self._comm_stream = None
+        self._reducer = GradReducer(self.device)
         self._loss_cache = None
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
@@ -166,24 +167,11 @@ class ShmGANwithSSpecSeg:
 
     # ------------------------------------------------------------------ data parallel
     def _world(self):
-        import torch.distributed as dist
-        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return world_size()
 
     def _allreduce_async(self, flat):
         """Sum `flat` over ranks on the side stream; returns an event to wait on (or None)."""
-        if self._world() == 1:
-            return None
-        import torch.distributed as dist
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self.device)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
-        done = torch.cuda.Event()
-        with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(ready)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            done.record(self._comm_stream)
-        return done
+        return self._reducer.allreduce_async(flat)
 
     # ------------------------------------------------------------------ the step
     def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True):

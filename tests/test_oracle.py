@@ -1,0 +1,214 @@
+"""CPU tests of the oracle: structural known answers from the reference's committed Keras
+summaries, two independent restatements against each other (NumPy explicit vs PyTorch autograd),
+finite differences, and the committed golden fixtures."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_torch as st
+from oracle import tf_ops_np as tn
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+# Known answers transcribed from /root/reference/Generator_summary.txt and
+# Discriminator_summary.txt (Keras .summary() at image_size 128, filter_size 64):
+# (layer name, output H, output C, param count)
+G_KAT = [
+    ("conv2d", 128, 64, 5824), ("conv2d_1", 128, 64, 36928), ("conv2d_4", 64, 128, 73856),
+    ("conv2d_5", 64, 128, 147584), ("conv2d_8", 32, 256, 295168), ("conv2d_9", 32, 256, 590080),
+    ("conv2d_12", 16, 512, 1180160), ("conv2d_13", 16, 512, 2359808), ("conv2d_16", 8, 512, 262656),
+    ("conv2d_17", 8, 512, 262656), ("conv2d_transpose", 16, 512, 2359808), ("conv2d_18", 16, 512, 4719104),
+    ("conv2d_19", 16, 512, 2359808), ("conv2d_transpose_1", 32, 256, 1179904), ("conv2d_20", 32, 256, 1179904),
+    ("conv2d_21", 32, 256, 590080), ("conv2d_transpose_2", 64, 128, 295040), ("conv2d_22", 64, 128, 295040),
+    ("conv2d_23", 64, 128, 147584), ("conv2d_transpose_3", 128, 64, 73792), ("conv2d_24", 128, 64, 73792),
+    ("conv2d_25", 128, 64, 36928), ("conv2d_26", 128, 1, 65),
+]
+D_KAT = [("conv2d_27", 1728), ("conv2d_28", 73728), ("conv2d_29", 294912), ("conv2d_30", 1179648),
+         ("conv2d_33", 4718592), ("conv2d_34", 9216), ("dense", 81920)]
+
+
+def test_known_answers_param_counts():
+    spec = st.generator_spec(64)
+    shapes = st.generator_var_shapes(64)
+    assert [s[0] for s in spec] == [k[0] for k in G_KAT]
+    for i, (name, h, c, cnt) in enumerate(G_KAT):
+        assert int(np.prod(shapes[2 * i])) + int(np.prod(shapes[2 * i + 1])) == cnt, name
+        assert spec[i][4] == c
+    assert sum(int(np.prod(s)) for s in shapes) == 18525569          # Generator_summary.txt:621
+    d128 = st.discriminator_spec(64, 128)
+    assert [(n, int(np.prod(s))) for n, _, s in d128] == D_KAT
+    assert sum(int(np.prod(s)) for _, _, s in d128) == 6359744       # Discriminator_summary.txt:179
+    assert sum(int(np.prod(s)) for _, _, s in st.discriminator_spec(64, 256)) == 6605504
+    assert len(st.generator_in_channels(64)) == 18 and len(st.discriminator_in_channels(64)) == 5
+
+
+def test_generator_output_shapes():
+    F, S = 16, 32
+    g, d, gb, db = st.init_params(F, 64)
+    x = torch.zeros(1, S, S, 10, dtype=torch.float64)
+    rec = []
+    y = st.generator_forward([torch.from_numpy(a).double() for a in g], [torch.from_numpy(b).double() for b in gb], x, F, record=rec)
+    assert tuple(y.shape) == (1, S, S, 1)
+    hs = [z.shape[2] for z, _ in rec]
+    assert hs == [32, 32, 16, 16, 8, 8, 4, 4, 2, 2, 4, 4, 8, 8, 16, 16, 32, 32]      # x S/128 of G_KAT
+
+
+def test_same_padding_rule():
+    assert tn.same_pads(256, 3, 1) == (256, 1, 1)
+    assert tn.same_pads(256, 3, 2) == (128, 0, 1)        # asymmetric: NOT PyTorch's symmetric pad 1
+    assert tn.same_pads(7, 3, 2) == (4, 1, 1)
+    assert tn.same_pads(8, 1, 1) == (8, 0, 0)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_numpy_vs_torch(stride):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 8, 6, 5))
+    w = rng.standard_normal((3, 3, 5, 7))
+    a = tn.conv2d_same(x, w, stride)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).requires_grad_(True)
+    b = st.conv2d_same(xt, wt, stride)
+    assert np.abs(a - b.detach().permute(0, 2, 3, 1).numpy()).max() < 1e-12
+    dy = rng.standard_normal(a.shape)
+    dx, dw = tn.conv2d_same_bwd(x, w, dy, stride)
+    gx, gw = torch.autograd.grad(b, [xt, wt], torch.from_numpy(dy).permute(0, 3, 1, 2))
+    assert np.abs(dx - gx.permute(0, 2, 3, 1).numpy()).max() < 1e-12
+    assert np.abs(dw - gw.numpy()).max() < 1e-11
+
+
+def test_conv_transpose_is_gradient_of_strided_conv():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 4, 5, 3))
+    w = rng.standard_normal((3, 3, 6, 3))            # Keras [kh,kw,Cout,Cin]
+    a = tn.conv2d_transpose_same(x, w)
+    b = st.conv2d_transpose_same(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w)).permute(0, 2, 3, 1).numpy()
+    assert a.shape == (2, 8, 10, 6) and np.abs(a - b).max() < 1e-12
+    big = torch.zeros(2, 6, 8, 10, dtype=torch.float64, requires_grad=True)
+    y = st.conv2d_same(big, torch.from_numpy(w), 2)      # w read as HWIO with I=6, O=3
+    g, = torch.autograd.grad(y, big, torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert np.abs(g.permute(0, 2, 3, 1).numpy() - a).max() < 1e-12
+    # a symmetric-pad-1 stride-2 conv is NOT the same operator
+    y2 = torch.nn.functional.conv2d(big, torch.from_numpy(w).permute(3, 2, 0, 1), stride=2, padding=1)
+    g2, = torch.autograd.grad(y2, big, torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert np.abs(g2.permute(0, 2, 3, 1).numpy() - a).max() > 1e-3
+
+
+def test_instance_norm_and_pool_and_ssim():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 6, 6, 4)) * 3 + 1
+    beta = rng.standard_normal(4)
+    a = tn.instance_norm(x, beta)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    b = st.instance_norm(xt, torch.from_numpy(beta))
+    assert np.abs(a - b.detach().permute(0, 2, 3, 1).numpy()).max() < 1e-12
+    # normalised output: mean = beta, variance = var/(var+eps)
+    assert np.abs(a.mean(axis=(1, 2)) - beta).max() < 1e-12
+    dy = rng.standard_normal(x.shape)
+    g, = torch.autograd.grad(b, xt, torch.from_numpy(dy).permute(0, 3, 1, 2))
+    assert np.abs(tn.instance_norm_bwd(x, dy) - g.permute(0, 2, 3, 1).numpy()).max() < 1e-10
+    p = tn.avg_pool2(x)
+    assert np.abs(p - torch.nn.functional.avg_pool2d(xt, 2).detach().permute(0, 2, 3, 1).numpy()).max() < 1e-12
+    u, v = rng.random((2, 16, 16, 3)), rng.random((2, 16, 16, 3))
+    assert np.abs(tn.ssim(u, v) - st.ssim(torch.from_numpy(u), torch.from_numpy(v)).numpy()).max() < 1e-12
+    assert abs(float(tn.ssim(u, u)[0]) - 1.0) < 1e-12
+    assert abs(tn.gauss_window().sum() - 1.0) < 1e-12
+
+
+def test_colour_standardise_rescale_gram_xent_adam():
+    rng = np.random.default_rng(3)
+    x = rng.random((2, 8, 8, 3))
+    yuv = tn.rgb_to_yuv(x)
+    assert np.abs(tn.yuv_to_rgb(yuv) - x).max() < 1e-6           # TF's two matrices are inverse to ~1e-7
+    assert np.abs(yuv - st.rgb_to_yuv(torch.from_numpy(x)).numpy()).max() < 1e-14
+    s_np, sc_np = tn.per_image_standardization(yuv)
+    s_t, sc_t = st.per_image_standardization(torch.from_numpy(yuv))
+    assert np.abs(s_np - s_t.numpy()).max() < 1e-12 and np.abs(sc_np - sc_t.numpy()).max() < 1e-14
+    flat = np.full((1, 4, 4, 3), 0.5)
+    assert tn.per_image_standardization(flat)[1][0] == 1.0 / 256.0     # min_stddev clamp (SHM.py:1293)
+    r = tn.rescale_01(yuv)
+    assert r.min() == 0.0 and r.max() == 1.0
+    assert np.abs(r - st.rescale_01(torch.from_numpy(yuv)).numpy()).max() < 1e-14
+    assert np.abs(tn.rescale_01(flat)).max() == 0.0                     # divide_no_nan
+    assert np.abs(tn.gram_matrix(yuv) - st.gram_matrix(torch.from_numpy(yuv)).numpy()).max() < 1e-14
+    lg = rng.standard_normal((3, 5))
+    lab = np.zeros((3, 5)); lab[:, 4] = 1.1
+    ref = -1.1 * torch.log_softmax(torch.from_numpy(lg), -1)[:, 4].numpy()
+    assert np.abs(tn.softmax_xent(lab, lg) - ref).max() < 1e-12
+    # Adam: oracle list form == numpy scalar form
+    w, g = rng.standard_normal(50), rng.standard_normal(50) * 3
+    wt = [torch.from_numpy(w.copy())]
+    stt = st.AdamState([torch.zeros(50, dtype=torch.float64)], [torch.zeros(50, dtype=torch.float64)], iterations=7)
+    st.adam_apply(wt, [torch.from_numpy(g)], stt, 2e-5, 0.5, 0.99)
+    w2, m2, v2 = tn.adam_update(w, np.zeros(50), np.zeros(50), g, 7, 2e-5, 0.5, 0.99)
+    assert np.abs(wt[0].numpy() - w2).max() < 1e-15 and stt.iterations == 8
+
+
+def test_style_factor_int32_wrap():
+    """SURVEY finding 7: tf.math.square(2*9*S*S) on a Python int is an int32 op."""
+    assert st.style_factor_as_executed(256) == float("inf")
+    assert abs(st.style_factor_as_executed(128) - 1.0 / 2 ** 30) < 1e-18
+    assert abs(st.style_factor_intended(128) - 1.0 / (2 * 9 * 128 * 128) ** 2) < 1e-30
+
+
+def test_train_step_gradient_finite_difference():
+    """Directional finite difference of total_G and total_D+total_C through the oracle itself."""
+    S, F, B = 64, 16, 1
+    g, d, gb, db = st.init_params(F, S)
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(0, B, S, F)
+    sf = st.style_factor_intended(S)
+    r = st.train_step(g, d, gb, db, inp, dr, sf, F)
+    rng = np.random.default_rng(4)
+    eps = 1e-5
+    for which in ("G", "D"):
+        vars_ = g if which == "G" else d
+        dirs = [rng.standard_normal(v.shape) * (np.abs(v).max() + 1e-3) for v in vars_]
+        plus = [v + eps * u for v, u in zip(vars_, dirs)]
+        minus = [v - eps * u for v, u in zip(vars_, dirs)]
+        if which == "G":
+            lp = st.train_step(plus, d, gb, db, inp, dr, sf, F, need_grads=False)["losses"]["total_Generator_loss"]
+            lm = st.train_step(minus, d, gb, db, inp, dr, sf, F, need_grads=False)["losses"]["total_Generator_loss"]
+            an = sum(float((gr * torch.from_numpy(u)).sum()) for gr, u in zip(r["gG"], dirs))
+        else:
+            f = lambda L: L["total_Discriminator_loss"] + L["total_Classification_loss"]
+            lp = f(st.train_step(g, plus, gb, db, inp, dr, sf, F, need_grads=False)["losses"])
+            lm = f(st.train_step(g, minus, gb, db, inp, dr, sf, F, need_grads=False)["losses"])
+            an = sum(float((gr * torch.from_numpy(u)).sum()) for gr, u in zip(r["gD"], dirs))
+        fd = (lp - lm) / (2 * eps)
+        # the loss has kinks (|.| in L1, LeakyReLU, min/max): a finite step crosses a few of them
+        assert abs(fd - an) <= 1e-2 * max(abs(an), 1e-6), (which, fd, an)
+
+
+def test_batch_rule_is_mean_of_single_sample_steps():
+    """a B=2 step == mean of two independent B=1 steps (losses and gradients)."""
+    S, F = 64, 16
+    g, d, gb, db = st.init_params(F, S)
+    inp = st.make_inputs(2, S)
+    dr = st.make_draws(1, 2, S, F)
+    sf = st.style_factor_intended(S)
+    r2 = st.train_step(g, d, gb, db, inp, dr, sf, F)
+    acc = None
+    for b in range(2):
+        drb = st.StepDraws(dr.flags, dr.target_label, dr.noise[[b, 2 + b]], dr.keep_mask[[b, 2 + b]])
+        rb = st.train_step(g, d, gb, db, [a[b:b + 1] for a in inp], drb, sf, F)
+        gs = [t / 2 for t in rb["gG"] + rb["gD"]]
+        acc = gs if acc is None else [a + t for a, t in zip(acc, gs)]
+    for a, t in zip(acc, r2["gG"] + r2["gD"]):
+        assert float((a - t).abs().max()) <= 1e-10 * max(1.0, float(t.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["step_S64_F16_B1.npz", "step_S64_F16_B2.npz"])
+def test_golden_step_fixture(name):
+    gold = np.load(GOLD / name)
+    S, F, B, step = [int(v) for v in gold["meta"]]
+    g, d, gb, db = st.init_params(F, S)
+    r = st.train_step(g, d, gb, db, st.make_inputs(B, S), st.make_draws(step, B, S, F), st.style_factor_intended(S), F)
+    for k, v in r["losses"].items():
+        assert abs(v - float(gold[f"loss/{k}"])) <= 1e-9 * max(1.0, abs(v)), k
+    assert np.abs(r["outs"]["gen_Y"].numpy() - gold["gen_Y"]).max() < 1e-6
+    for nm, gr in (("gG", r["gG"]), ("gD", r["gD"])):
+        n = np.array([float(t.norm()) for t in gr])
+        assert np.abs(n - gold[f"{nm}/norm"]).max() <= 1e-8 * max(1.0, n.max())

@@ -164,10 +164,18 @@ def test_train_step_parity(S, F, B, step):
     inp = st.make_inputs(B, S)
     dr = st.make_draws(step, B, S, F)
     sf = st.style_factor_intended(S)
-    ref = st.train_step(g, d, gb, db, inp, dr, sf, F)
     m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
     torch.cuda.synchronize()
+    # The oracle evaluates every LeakyReLU on the side of the kink the device took (see
+    # oracle.step_torch._act): at |z| ~ 1e-7 float32 rounding can flip the sign, the derivative
+    # jumps 5x there, and a single such element moved a whole layer's gradient by 1e-2 in
+    # rel-L2 (DESIGN.md "parity").  Values are unaffected (<= 1e-6).
+    masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
+    ref = st.train_step(g, d, gb, db, inp, dr, sf, F, masks=masks)
+    free = st.train_step(g, d, gb, db, inp, dr, sf, F, need_grads=False)      # un-pinned oracle: values
     got = m.losses()
+    for k, v in free["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
     for k, v in ref["losses"].items():
         assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
     assert np.abs(host(m.gen_Y) - ref["outs"]["gen_Y"].numpy()).max() < 1e-4
@@ -222,3 +230,29 @@ def test_train_step_properties_full_size():
             assert abs(l1[k] - l2[k]) <= 1e-5 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
     assert rel_l2(host(m2.G.P.grad), host(g1)) < 1e-4
     assert rel_l2(host(m2.D.P.grad), host(d1)) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["step_S64_F16_B1.npz", "step_S64_F16_B2.npz"])
+def test_golden_fixture_on_device(name):
+    """HIP path against the committed golden vectors (tests/golden, made by oracle/make_golden.py):
+    named losses, gen_Y, SSIM values, gradient norms and random projections."""
+    from pathlib import Path
+    gold = np.load(Path(__file__).resolve().parent / "golden" / name)
+    S, F, B, step = [int(v) for v in gold["meta"]]
+    m, _ = _mk(S, F, B)
+    m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    got = m.losses()
+    for k in got:
+        if k != "ssim":
+            v = float(gold[f"loss/{k}"])
+            assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    assert np.abs(host(m.gen_Y) - gold["gen_Y"]).max() < 1e-4
+    assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
+    # gradient norms: LeakyReLU kink events (see test_train_step_parity) can move a layer by ~1e-2
+    for nm, P in (("gD", m.D.P), ("gG", m.G.P)):
+        n = np.array([float(t.norm()) for t in P.grads])
+        ref = gold[f"{nm}/norm"]
+        ok = ref > 1e-12
+        assert np.abs(n[ok] / ref[ok] - 1).max() < 5e-2
+        assert np.median(np.abs(n[ok] / ref[ok] - 1)) < 1e-3
