@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: all ranks share GPU 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -52,8 +55,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -141,6 +149,12 @@ def main():
                 "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
             }
+            if args.per_shape:
+                ps = timer.per_shape()
+                rows = [dict(kernel=k[0], shape=k[1], launches=v["launches"], ms_per_step=v["ms"] / args.steps,
+                             tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in ps.items()]
+                rows.sort(key=lambda r: -r["ms_per_step"])
+                Path(args.per_shape).write_text(json.dumps(rows, indent=1))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)
         print(json.dumps(out), flush=True)

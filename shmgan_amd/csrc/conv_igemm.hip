@@ -14,9 +14,12 @@
 //   feeds four consecutive MFMAs from one 16-byte LDS read (the k order inside an 8-wide
 //   group is permuted identically for A and B, which a dot product does not see).
 //
-// Block = 256 threads = 2x2 waves, tile BM x BN (128x64 or 128x128), BK = 16, two LDS
-// stages, register prefetch of the next stage's global loads under the current MFMAs.
+// Block = 256 threads = 4 waves of 64x64 outputs each (2x2 MFMA tiles), block tile 128x128
+// (2x2 waves) or 256x64 (4x1 waves, for Cout <= 64), BK = 16, two LDS stages and two register
+// sets: global loads run two K-steps ahead of the MFMAs that consume them.
 #include "common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct TapPhase {
     int oph, opw, ntaps;
@@ -37,17 +40,19 @@ struct TapGemmArgs {
     int ho, wo, nout;   // full output dims
     int is, os;         // A stride, output stride
     int M;              // batch*hg*wg
+    unsigned xbytes, x2bytes, wbytes;   // buffer-descriptor extents (bytes)
     float slope;
     TapPhase ph[4];
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
+// BM x BN block tile, WGM x WGN waves (4 waves), every wave owns a 64x64 sub-tile (2x2 MFMA tiles).
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
+    static_assert(WGM * WGN == 4 && BM / WGM == 64 && BN / WGN == 64, "wave tile must be 64x64");
     constexpr int LDK = 20;          // 16 + 4 pad floats per LDS row
     constexpr int AR = BM / 64;      // A rows staged per thread
     constexpr int BR = BN / 64;      // B rows staged per thread
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TM = 2, TN = 2;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
     const int tid = threadIdx.x, quad = tid & 3, lrow = tid >> 2;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     int pixbase[AR], ih0[AR], iw0[AR];
@@ -71,41 +76,68 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
         iw0[j] = ow * a.is;
         pixbase[j] = (n * a.hi + ih0[j]) * a.wi + iw0[j];
     }
+    const int ntaps = P.ntaps;
+    const int ksteps = ntaps * (a.K >> 4);
 
-    const int nchunks = a.K >> 4;
-    const int ksteps = P.ntaps * nchunks;
-
-    f32x4 ra[AR], rb[BR];
-    auto gload = [&](int s) {
-        int chunk = s / P.ntaps, tap = s - chunk * P.ntaps;
-        int c0 = chunk << 4;
-        const float* src = a.x;
-        int ld = a.ldx, cc = c0;
-        if (c0 >= a.c1) {
-            src = a.x2;
-            ld = a.ldx2;
-            cc = c0 - a.c1;
+    // K-step order: (32-channel group, tap, 16-channel half).  The two halves of a 128-byte line
+    // are read in consecutive steps (second one hits L1), and the 9 shifted reads of a group reuse
+    // the same input rows.  Everything advances incrementally; the tap-table entries of the NEXT
+    // load are fetched one step ahead so their scalar-load latency sits behind an MFMA block.
+    const int nch = a.K >> 4;
+    int ld_g = 0, ld_tap = 0, ld_sub = 0, ld_c0 = 0;    // position of the next gload
+    int t_dh = P.dh[0], t_dw = P.dw[0], t_wi = P.widx[0];
+    auto advance = [&]() {
+        const int nsub = (nch - ld_g) >= 2 ? 2 : 1;
+        if (++ld_sub == nsub) {
+            ld_sub = 0;
+            if (++ld_tap == ntaps) {
+                ld_tap = 0;
+                ld_g += 2;
+            }
+            t_dh = P.dh[ld_tap];
+            t_dw = P.dw[ld_tap];
+            t_wi = P.widx[ld_tap];
         }
-        const int dh = P.dh[tap], dw = P.dw[tap];
+        ld_c0 = (ld_g + ld_sub) << 4;
+    };
+    // Operands are fetched with raw buffer loads: a lane whose tap falls outside the image (SAME
+    // padding), whose row is past M or whose weight row is past N gets byte offset 0xffffffff,
+    // which the hardware range check turns into zeros.  No divergent branch around a load, so
+    // hipcc can wait with counted s_waitcnt vmcnt(N) and the loads really stay two steps ahead.
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    unsigned wrow[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        int nn = n0 + lrow + 64 * j;
+        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + quad * 4) * 4u : 0xffffffffu;
+    }
+    auto gload = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
+        const int c0 = ld_c0;
+        const bool second = c0 >= a.c1;
+        const int ld = second ? a.ldx2 : a.ldx;
+        const int cc = (second ? c0 - a.c1 : c0) + quad * 4;
+        const int dh = t_dh, dw = t_dw;
         const int doff = dh * a.wi + dw;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             int ih = ih0[j] + dh, iw = iw0[j] + dw;
             bool ok = mval[j] && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(src + (size_t)(pixbase[j] + doff) * ld + cc + quad * 4);
-            ra[j] = v;
+            unsigned off = ok ? (unsigned)((pixbase[j] + doff) * ld + cc) * 4u : 0xffffffffu;
+            u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsx2, (int)off, 0, 0)
+                             : __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
+            ra[j] = __builtin_bit_cast(f32x4, v);
         }
-        const float* wb = a.w + (size_t)P.widx[tap] * a.nout * a.K + c0 + quad * 4;
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * 4u;
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            int nn = n0 + lrow + 64 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (nn < a.nout) v = *(const f32x4*)(wb + (size_t)nn * a.K);
-            rb[j] = v;
+            unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)off, 0, 0));
         }
+        advance();
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) *(f32x4*)(&As[buf][(lrow + 64 * j) * LDK + quad * 4]) = ra[j];
 #pragma unroll
@@ -120,14 +152,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int s = 0; s < ksteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < ksteps) gload(s + 1);
-        const float* Ab = &As[buf][(wm * WM + l31) * LDK + h * 4];
-        const float* Bb = &Bs[buf][(wn * WN + l31) * LDK + h * 4];
+    auto compute = [&](int buf) {
+        const float* Ab = &As[buf][(wm * 64 + l31) * LDK + h * 4];
+        const float* Bb = &Bs[buf][(wn * 64 + l31) * LDK + h * 4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f32x4 av[TM], bv[TN];
@@ -143,8 +170,61 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < ksteps) sstore(buf ^ 1);
+    };
+
+    // Two LDS stages, two register sets: the global loads of step s+2 are issued while step s is
+    // computed and are written to LDS at the end of step s+1 (two MFMA phases of flight time).
+    f32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
+    gload(ra0, rb0);
+    if (ksteps > 1) gload(ra1, rb1);
+    sstore(0, ra0, rb0);
+    __syncthreads();
+    int s = 0;
+#ifdef SHM_ABL_NOBAR
+#define SHM_BAR()
+#else
+#define SHM_BAR() __syncthreads()
+#endif
+#ifdef SHM_ABL_NOLOAD
+#define SHM_GLOAD(a_, b_)
+#else
+#define SHM_GLOAD(a_, b_) gload(a_, b_)
+#endif
+#ifdef SHM_ABL_NOSTORE
+#define SHM_SSTORE(i_, a_, b_)
+#else
+#define SHM_SSTORE(i_, a_, b_) sstore(i_, a_, b_)
+#endif
+#ifdef SHM_SCHED_PIN
+#define SHM_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SHM_PIN()
+#endif
+    for (; s + 3 < ksteps; s += 2) {      // steady state: steps s, s+1 computed, s+2, s+3 fetched
+        SHM_GLOAD(ra0, rb0);
+        compute(0);
+        SHM_PIN();
+        SHM_SSTORE(1, ra1, rb1);
+        SHM_BAR();
+        SHM_GLOAD(ra1, rb1);
+        compute(1);
+        SHM_PIN();
+        SHM_SSTORE(0, ra0, rb0);
+        SHM_BAR();
+    }
+    // tail: 1..3 steps left; buf0 holds step s, (ra1, rb1) hold step s+1 if it exists
+    const int left = ksteps - s;
+    if (left >= 3) gload(ra0, rb0);
+    compute(0);
+    if (left >= 2) {
+        sstore(1, ra1, rb1);
         __syncthreads();
+        compute(1);
+        if (left >= 3) {
+            sstore(0, ra0, rb0);
+            __syncthreads();
+            compute(0);
+        }
     }
 
     // epilogue: bias + LeakyReLU + store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
@@ -154,7 +234,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + wm * WM + i * 32 + row;
+            const int m = m0 + wm * 64 + i * 32 + row;
             if (m >= a.M) continue;
             size_t opix;
             if (direct) {
@@ -166,7 +246,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 32 + l31;
+                const int n = n0 + wn * 64 + j * 32 + l31;
                 if (n < a.nout) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[n];
@@ -188,12 +268,26 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     SHM_REQUIRE((size_t)batch * a.hi * a.wi < (1u << 31) && (size_t)batch * a.ho * a.wo < (1u << 31), SHM_E_SHAPE, "%s: pixel count overflows int32", who);
     a.M = batch * a.hg * a.wg;
     if (a.M == 0 || a.nout == 0) return SHM_OK;
+    {
+        const size_t lim = 0xfffffff0ull;
+        size_t xb = (size_t)batch * a.hi * a.wi * a.ldx * 4, x2b = a.x2 ? (size_t)batch * a.hi * a.wi * a.ldx2 * 4 : 0;
+        size_t wb = 0;
+        for (int p = 0; p < nphase; ++p)
+            for (int t = 0; t < a.ph[p].ntaps; ++t) {
+                size_t e = (size_t)(a.ph[p].widx[t] + 1) * a.nout * a.K * 4;
+                if (e > wb) wb = e;
+            }
+        SHM_REQUIRE(xb < lim && x2b < lim && wb < lim, SHM_E_SHAPE, "%s: operand larger than 4 GiB (32-bit buffer offsets)", who);
+        a.xbytes = (unsigned)xb;
+        a.x2bytes = (unsigned)x2b;
+        a.wbytes = (unsigned)wb;
+    }
     if (a.nout > 64) {
         dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<128, 128>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((tapgemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 64), nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<128, 64>), grid, dim3(256), 0, st, a);
+        dim3 grid(shm_cdiv(a.M, 256), 1, nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, a);
     }
     SHM_LAUNCH_CHECK(who);
     return SHM_OK;

@@ -14,6 +14,8 @@
 // wgrad_reduce_kernel (deterministic, no float atomics).
 #include "common.h"
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct WgradArgs {
     const float* x;
     const float* x2;
@@ -26,13 +28,21 @@ struct WgradArgs {
     int is, ntaps;
     int dh[9], dw[9];
     int M, pix_per_split;
+    unsigned xbytes, x2bytes, dybytes;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    constexpr int BKP = 16;
-    __shared__ __attribute__((aligned(16))) float Xs[NT][BKP][64];
-    __shared__ __attribute__((aligned(16))) float Ds[BKP][64];
+// Stage = 8 pixels.  Thread -> (half, k, c4): pixel slot k (0..7), 4-channel lane c4 (0..15), and
+// the taps {half, half+2, ...}.  Two LDS stages + two register sets (loads two stages ahead),
+// raw buffer loads with out-of-range offsets for padding / tails (no divergent load branches).
+// STRADDLE: the 64-channel tile may contain channels of both concat sources (c1 % 64 != 0; only the
+// small-filter test configurations): every X load is then issued against both descriptors with one
+// of them masked out of range, so the descriptor stays wave-uniform (no waterfall loop).
+template <int NT, bool STRADDLE>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int BKP = 8;
+    constexpr int NTL = (NT + 1) / 2;          // tap loads per thread
+    __shared__ __attribute__((aligned(16))) float Xs[2][NT][BKP][64];
+    __shared__ __attribute__((aligned(16))) float Ds[2][BKP][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -40,19 +50,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
     const int p_begin = blockIdx.z * a.pix_per_split;
     const int p_end = min(a.M, p_begin + a.pix_per_split);
+    const int nstages = (p_end - p_begin + BKP - 1) / BKP;
 
-    const int k = tid >> 4, c4 = tid & 15;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);      // wave-uniform: waves 0,1 / 2,3
+    const int k = (tid >> 4) & 7, c4 = tid & 15;
     const int c = ci0 + c4 * 4;
+    const bool second = STRADDLE ? (c >= a.c1) : (ci0 >= a.c1);
     const bool xvalid = c < a.cin_ld;
-    const float* src = a.x;
-    int ld = a.ldx, cc = c;
-    if (c >= a.c1) {
-        src = a.x2;
-        ld = a.ldx2;
-        cc = c - a.c1;
+    const int ld = second ? a.ldx2 : a.ldx;
+    const int cc = second ? c - a.c1 : c;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    // tap table of this wave pair, hoisted out of the loop (wave-uniform -> SGPRs)
+    int tdh[NTL], tdw[NTL], tof[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int t = half + 2 * j;
+        const bool tv = t < NT;
+        tdh[j] = tv ? a.dh[tv ? t : 0] : (1 << 28);          // invalid tap: always out of the image
+        tdw[j] = tv ? a.dw[tv ? t : 0] : 0;
+        tof[j] = tv ? (tdh[j] * a.wi + tdw[j]) : 0;
     }
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     const int co = co0 + c4 * 4;
-    const bool dvalid = co < a.cout;
+    const bool dvalid = (co < a.cout) && half == 0;
+
+    // running pixel coordinate of this thread's slot (advances by BKP per stage)
+    int p = p_begin + k;
+    int ow, oh, n;
+    {
+        const int pp = p < a.M ? p : 0;
+        ow = pp % a.wo;
+        const int t2 = pp / a.wo;
+        oh = t2 % a.ho;
+        n = t2 / a.ho;
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -60,43 +92,87 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    f32x4 rx[NT], rd;
-    auto gload = [&](int p0) {
-        const int p = p0 + k;
+    auto gload = [&](f32x4 (&rx)[NTL], f32x4& rd) {
         const bool ok = p < p_end;
-        const int pp = ok ? p : 0;
-        const int ow = pp % a.wo, t2 = pp / a.wo;
-        const int oh = t2 % a.ho, n = t2 / a.ho;
         const int ihb = oh * a.is, iwb = ow * a.is;
+        const int base = ((n * a.hi + ihb) * a.wi + iwb) * ld + cc;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ih = ihb + a.dh[t], iw = iwb + a.dw[t];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && xvalid && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi)
-                v = *(const f32x4*)(src + ((size_t)(n * a.hi + ih) * a.wi + iw) * ld + cc);
-            rx[t] = v;
+        for (int j = 0; j < NTL; ++j) {
+            const int ih = ihb + tdh[j], iw = iwb + tdw[j];
+            const bool v = ok && xvalid && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
+            const unsigned off = v ? (unsigned)(base + tof[j] * ld) * 4u : 0xffffffffu;
+            if (STRADDLE) {
+                u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(second ? 0xffffffffu : off), 0, 0);
+                u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(second ? off : 0xffffffffu), 0, 0);
+                rx[j] = __builtin_bit_cast(f32x4, v1 | v2);
+            } else {
+                u32x4 v1 = second ? __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)off, 0, 0)
+                                  : __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)off, 0, 0);
+                rx[j] = __builtin_bit_cast(f32x4, v1);
+            }
         }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok && dvalid) v = *(const f32x4*)(a.dy + (size_t)p * a.lddy + co);
-        rd = v;
+        const unsigned offd = (ok && dvalid) ? (unsigned)(p * a.lddy + co) * 4u : 0xffffffffu;
+        rd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)offd, 0, 0));
+        // advance to the next stage
+        p += BKP;
+        ow += BKP;
+        while (ow >= a.wo) {
+            ow -= a.wo;
+            if (++oh == a.ho) {
+                oh = 0;
+                ++n;
+            }
+        }
     };
-
-    if (p_begin < p_end) gload(p_begin);
-    for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
-        __syncthreads();   // previous step's LDS reads are done
+    auto sstore = [&](int buf, const f32x4 (&rx)[NTL], const f32x4& rd) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) *(f32x4*)(&Xs[t][k][c4 * 4]) = rx[t];
-        *(f32x4*)(&Ds[k][c4 * 4]) = rd;
-        __syncthreads();
-        if (p0 + BKP < p_end) gload(p0 + BKP);
+        for (int j = 0; j < NTL; ++j) {
+            const int t = half + 2 * j;
+            if (t < NT) *(f32x4*)(&Xs[buf][t][k][c4 * 4]) = rx[j];
+        }
+        if (half == 0) *(f32x4*)(&Ds[buf][k][c4 * 4]) = rd;
+    };
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BKP / 2; ++kk) {
             const int kr = 2 * kk + h;
-            const float bv = Ds[kr][ni * 32 + l31];
+            const float bv = Ds[buf][kr][ni * 32 + l31];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float av = Xs[t][kr][mi * 32 + l31];
+                const float av = Xs[buf][t][kr][mi * 32 + l31];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        f32x4 rx0[NTL], rx1[NTL], rd0, rd1;
+        gload(rx0, rd0);
+        if (nstages > 1) gload(rx1, rd1);
+        sstore(0, rx0, rd0);
+        __syncthreads();
+        int s = 0;
+        for (; s + 3 < nstages; s += 2) {
+            gload(rx0, rd0);
+            compute(0);
+            sstore(1, rx1, rd1);
+            __syncthreads();
+            gload(rx1, rd1);
+            compute(1);
+            sstore(0, rx0, rd0);
+            __syncthreads();
+        }
+        const int left = nstages - s;
+        if (left >= 3) gload(rx0, rd0);
+        compute(0);
+        if (left >= 2) {
+            sstore(1, rx1, rd1);
+            __syncthreads();
+            compute(1);
+            if (left >= 3) {
+                sstore(0, rx0, rd0);
+                __syncthreads();
+                compute(0);
             }
         }
     }
@@ -114,12 +190,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? dw[i] : 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-    dw[i] = s;
+// dw[i] (+)= sum_k part[k][i], summed in a fixed order (4 interleaved chains, then 0+1+2+3).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
+    float s = 0.f;
+    if (i < n)
+        for (int k = g; k < nsplit; k += 4) s += part[(size_t)k * n + i];
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        dw[i] = accumulate ? dw[i] + t : t;
+    }
 }
 
 static int wgrad_splits(int batch, int ho, int wo, int cin, int cout) {
@@ -179,19 +263,36 @@ extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx
     int ns = wgrad_splits(batch, ho, wo, cin, cout);
     size_t need = (size_t)ns * a.ntaps * cin * cout * sizeof(float);
     SHM_REQUIRE(ws_bytes >= need, SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    {
+        const size_t lim = 0xfffffff0ull;
+        size_t xb = (size_t)batch * hi * wi * ldx * 4, x2b = x2 ? (size_t)batch * hi * wi * ldx2 * 4 : 0;
+        size_t db = (size_t)batch * ho * wo * lddy * 4;
+        SHM_REQUIRE(xb < lim && x2b < lim && db < lim, SHM_E_SHAPE, "shm_conv2d_wgrad: operand larger than 4 GiB (32-bit buffer offsets)");
+        a.xbytes = (unsigned)xb;
+        a.x2bytes = (unsigned)x2b;
+        a.dybytes = (unsigned)db;
+    }
     int pps = shm_cdiv(a.M, ns);
     pps = (pps + 15) / 16 * 16;
     ns = shm_cdiv(a.M, pps);
     a.pix_per_split = pps;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
-    if (ksize == 3)
-        hipLaunchKernelGGL((wgrad_kernel<9>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, st, a);
+    const bool straddle = x2 && (c1 % 64 != 0);
+    if (ksize == 3) {
+        if (straddle)
+            hipLaunchKernelGGL((wgrad_kernel<9, true>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (straddle)
+            hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, st, a);
+    }
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad");
     size_t n = (size_t)a.ntaps * cin * cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, st, (const float*)workspace, dw, n, ns, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shm_cdiv((long)n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n, ns, accumulate);
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad(reduce)");
     return SHM_OK;
 }

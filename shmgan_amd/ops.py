@@ -23,18 +23,28 @@ class KernelTimer:
     def __init__(self):
         self.recs = []
 
-    def wrap(self, sym, flops, fn):
+    def wrap(self, sym, flops, fn, label=""):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.recs.append((sym, flops, e0, e1))
+        self.recs.append((sym, flops, e0, e1, label))
+
+    def per_shape(self):
+        """{(symbol, label): dict(launches, ms, flops)} for tuning."""
+        out = {}
+        for sym, flops, e0, e1, label in self.recs:
+            d = out.setdefault((sym, label), dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
 
     def summary(self):
         """{symbol: dict(launches, ms, flops)} -- call after a device synchronize."""
         out = {}
-        for sym, flops, e0, e1 in self.recs:
+        for sym, flops, e0, e1, _ in self.recs:
             d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -46,14 +56,14 @@ TIMER = None
 
 
 def _tile(nout):
-    return "tapgemm_kernel<128,128>" if nout > 64 else "tapgemm_kernel<128,64>"
+    return "tapgemm_kernel<128,128,2,2>" if nout > 64 else "tapgemm_kernel<256,64,4,1>"
 
 
-def _timed(sym, flops, fn):
+def _timed(sym, flops, fn, label=""):
     if TIMER is None:
         fn()
     else:
-        TIMER.wrap(sym, flops, fn)
+        TIMER.wrap(sym, flops, fn, label)
 
 
 def _p(t):
@@ -71,7 +81,8 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
     _timed(_tile(cout), flops, lambda: check(
         lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                             cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd"))
+                             cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd"),
+           f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
@@ -79,14 +90,16 @@ def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
     _timed(_tile(cin), flops, lambda: check(
         lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
-                               cout, ksize, stride, _stream()), "shm_conv2d_dgrad"))
+                               cout, ksize, stride, _stream()), "shm_conv2d_dgrad"),
+           f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}")
 
 
 def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
     flops = 2.0 * batch * hi * wi * 9 * cin * cout
     _timed(_tile(cout), flops, lambda: check(
         lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
-                                       slope, _stream()), "shm_conv2d_transpose_fwd"))
+                                       slope, _stream()), "shm_conv2d_transpose_fwd"),
+           f"convT n{batch} h{hi} {cin}->{cout}")
 
 
 def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
@@ -100,7 +113,8 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
     _timed("wgrad_kernel<%d>" % (ksize * ksize), flops, lambda: check(
         lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
                                cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
-                               _stream()), "shm_conv2d_wgrad"))
+                               _stream()), "shm_conv2d_wgrad"),
+           f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}")
 
 
 def in_stats(a, lda, stats, batch, hw, c, eps):
