@@ -19,6 +19,8 @@
 // sets: global loads run two K-steps ahead of the MFMAs that consume them.
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct TapPhase {
@@ -125,6 +127,12 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
             int ih = ih0[j] + dh, iw = iw0[j] + dw;
             bool ok = mval[j] && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
             unsigned off = ok ? (unsigned)((pixbase[j] + doff) * ld + cc) * 4u : 0xffffffffu;
+#ifdef SHM_ABL_SAMELINE
+            off = ok ? (unsigned)(quad * 16 + (off & 0x40u)) : 0xffffffffu;      // timing only: every lane hits one line
+#endif
+#ifdef SHM_ABL_NOADDR
+            off = (unsigned)(pixbase[j] * ld + quad * 4) * 4u;                  // timing only: no per-step address work
+#endif
             u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsx2, (int)off, 0, 0)
                              : __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
             ra[j] = __builtin_bit_cast(f32x4, v);
@@ -261,6 +269,199 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant: operands go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR
+// staging and no ds_write.  One wave-instruction fills 16 LDS rows of 64 bytes (lane l -> byte
+// 16*l of the destination), so rows are unpadded; bank conflicts of the ds_read_b128 fragment
+// reads are removed by an XOR swizzle applied on the SOURCE side: LDS chunk q of row r holds
+// channel chunk q ^ ((r >> 2) & 3).  Out-of-image taps / tail rows use byte offset 0xffffffff:
+// the descriptor's range check makes the DMA write zeros (tools/ldsdma_probe.hip).
+// Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
+// counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NA = BM / 64, NB = BN / 64;        // DMA instructions per wave and stage
+    constexpr int NLD = NA + NB;
+    constexpr int STAGE = (BM + BN) * 16;            // floats
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
+
+    const TapPhase& P = a.ph[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // DMA lane mapping: instruction j of this wave covers rows wave*(BM/4)+16j .. +15
+    const int drow = lane >> 2, dq = lane & 3;
+    // Per row: byte offset of the centre pixel in each source, and a bitmask of the taps that fall
+    // inside the image (bit t of okm) -- the per-step address work is one add and one select.
+    unsigned rowb1[NA], rowb2[NA], okm[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = wave * (BM / 4) + 16 * j + drow;
+        const int m = m0 + row;
+        const bool mv = m < a.M;
+        const int mm = mv ? m : 0;
+        const int ow = mm % a.wg, t = mm / a.wg;
+        const int oh = t % a.hg, n = t / a.hg;
+        const int ih0 = oh * a.is, iw0 = ow * a.is;
+        const int pixbase = (n * a.hi + ih0) * a.wi + iw0;
+        const int acoff = (dq ^ ((row >> 2) & 3)) * 4;       // swizzled channel offset inside the 16-chunk
+        rowb1[j] = (unsigned)(pixbase * a.ldx + acoff) * 4u;
+        rowb2[j] = (unsigned)(pixbase * a.ldx2 + acoff) * 4u;
+        unsigned mk = 0;
+        for (int tp = 0; tp < P.ntaps; ++tp) {
+            const int ih = ih0 + P.dh[tp], iw = iw0 + P.dw[tp];
+            mk |= (mv && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi) ? (1u << tp) : 0u;
+        }
+        okm[j] = mk;
+    }
+    unsigned wrow[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = wave * (BN / 4) + 16 * j + drow;
+        const int nn = n0 + row;
+        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * 4) * 4u : 0xffffffffu;
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+
+    const int ntaps = P.ntaps;
+    const int nch = a.K >> 4;
+    const int ksteps = ntaps * nch;
+    int ld_g = 0, ld_tap = 0, ld_sub = 0, ld_c0 = 0;
+    int t_dh = P.dh[0], t_dw = P.dw[0], t_wi = P.widx[0];
+    auto advance = [&]() {
+        const int nsub = (nch - ld_g) >= 2 ? 2 : 1;
+        if (++ld_sub == nsub) {
+            ld_sub = 0;
+            if (++ld_tap == ntaps) {
+                ld_tap = 0;
+                ld_g += 2;
+            }
+            t_dh = P.dh[ld_tap];
+            t_dw = P.dw[ld_tap];
+            t_wi = P.widx[ld_tap];
+        }
+        ld_c0 = (ld_g + ld_sub) << 4;
+    };
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto dma = [&](int stage) {
+        float* sa = smem + stage * STAGE + wave * (BM / 4) * 16;
+        float* sb = smem + stage * STAGE + BM * 16 + wave * (BN / 4) * 16;
+        const int c0 = ld_c0;
+        const bool second = c0 >= a.c1;
+        const int ld = second ? a.ldx2 : a.ldx;
+        const int cc = second ? c0 - a.c1 : c0;
+        const unsigned stepb = (unsigned)((t_dh * a.wi + t_dw) * ld + cc) * 4u;     // wave-uniform
+        const unsigned tbit = 1u << ld_tap;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const unsigned off = (okm[j] & tbit) ? (second ? rowb2[j] : rowb1[j]) + stepb : 0xffffffffu;
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(sa + j * 256), 16, (int)off, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sa + j * 256), 16, (int)off, 0, 0, 0);
+        }
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * 4u;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * 256), 16, (int)off, 0, 0, 0);
+        }
+        advance();
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: row = tile row (l31 + 32*i), logical chunk 2*kk+h, physical chunk ^ ((row>>2)&3)
+    const int sw = (l31 >> 2) & 3;
+    const int fo0 = l31 * 16 + ((0 + h) ^ sw) * 4;       // floats, kk = 0
+    const int fo1 = l31 * 16 + ((2 + h) ^ sw) * 4;       // kk = 1
+    auto compute = [&](int stage) {
+        const float* Ab = smem + stage * STAGE + wm * WTM * 16;
+        const float* Bb = smem + stage * STAGE + BM * 16 + wn * WTN * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int fo = kk ? fo1 : fo0;
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 512 + fo);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + fo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    dma(0);
+    if (ksteps > 1) dma(1);
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < ksteps; ++s) {
+        // stage s must have landed: everything but the newest NLD DMAs (those of stage s+1)
+        if (s + 1 < ksteps)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // all waves: stage s landed, compute(s-1) finished
+        asm volatile("" ::: "memory");
+        if (s + 2 < ksteps) dma(nxt2);         // overwrites the buffer compute(s-1) was reading
+        compute(cur);
+        asm volatile("" ::: "memory");
+        cur = (cur == NST - 1) ? 0 : cur + 1;
+        nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+    }
+
+    const bool direct = (a.os == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * WTM + i * 32 + row;
+            if (m >= a.M) continue;
+            size_t opix;
+            if (direct) {
+                opix = (size_t)m;
+            } else {
+                int ow = m % a.wg, t = m / a.wg;
+                int oh = t % a.hg, n = t / a.hg;
+                opix = ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n < a.nout) {
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    v = shm_lrelu(v, a.slope);
+                    if (n < a.n1)
+                        a.y[opix * a.ldy + n] = v;
+                    else
+                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
+                }
+            }
+        }
+    }
+}
+
 static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
     SHM_REQUIRE(a.K % 16 == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of 16", who, a.K);
     SHM_REQUIRE(a.c1 % 16 == 0, SHM_E_SHAPE, "%s: concat split %d must be a multiple of 16", who, a.c1);
@@ -281,6 +482,22 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
         a.xbytes = (unsigned)xb;
         a.x2bytes = (unsigned)x2b;
         a.wbytes = (unsigned)wb;
+    }
+    static const int use_dma = getenv("SHM_TAPGEMM_REG") ? 0 : 1;
+    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 0;
+    if (use_dma) {
+        if (a.nout > 64) {
+            dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        } else if (dma_small == 0) {
+            dim3 grid(shm_cdiv(a.M, 256), 1, nphase);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, a);
+        } else {
+            dim3 grid(shm_cdiv(a.M, 128), 1, nphase);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a);
+        }
+        SHM_LAUNCH_CHECK(who);
+        return SHM_OK;
     }
     if (a.nout > 64) {
         dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);

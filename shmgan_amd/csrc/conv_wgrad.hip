@@ -62,14 +62,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     // tap table of this wave pair, hoisted out of the loop (wave-uniform -> SGPRs)
-    int tdh[NTL], tdw[NTL], tof[NTL];
+    constexpr int KS = NT == 9 ? 3 : 1;
+    int tofb[NTL];            // byte offset of tap j relative to the centre pixel
+    unsigned tbit[NTL];       // its bit in the 9-bit validity mask (0: tap not owned by this wave)
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
         const int t = half + 2 * j;
         const bool tv = t < NT;
-        tdh[j] = tv ? a.dh[tv ? t : 0] : (1 << 28);          // invalid tap: always out of the image
-        tdw[j] = tv ? a.dw[tv ? t : 0] : 0;
-        tof[j] = tv ? (tdh[j] * a.wi + tdw[j]) : 0;
+        const int tt = tv ? t : 0;
+        tofb[j] = (a.dh[tt] * a.wi + a.dw[tt]) * ld * 4;
+        tbit[j] = tv ? (1u << tt) : 0u;
+    }
+    int rdh[KS], cdw[KS];     // the KS distinct row / column displacements (tap = kh*KS + kw)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        rdh[i] = a.dh[i * KS];
+        cdw[i] = a.dw[i];
     }
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     const int co = co0 + c4 * 4;
@@ -95,12 +103,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     auto gload = [&](f32x4 (&rx)[NTL], f32x4& rd) {
         const bool ok = p < p_end;
         const int ihb = oh * a.is, iwb = ow * a.is;
-        const int base = ((n * a.hi + ihb) * a.wi + iwb) * ld + cc;
+        const unsigned base = (unsigned)(((n * a.hi + ihb) * a.wi + iwb) * ld + cc) * 4u;
+        // 9-bit tap validity mask of this pixel: bit kh*KS+kw = row kh inside AND column kw inside
+        unsigned rm = 0, cm = 0;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            rm |= ((unsigned)(ihb + rdh[i]) < (unsigned)a.hi ? 1u : 0u) << i;
+            cm |= ((unsigned)(iwb + cdw[i]) < (unsigned)a.wi ? 1u : 0u) << i;
+        }
+        unsigned m9 = 0;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) m9 |= (rm & (1u << i)) ? (cm << (i * KS)) : 0u;
+        if (!(ok && xvalid)) m9 = 0;
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-            const int ih = ihb + tdh[j], iw = iwb + tdw[j];
-            const bool v = ok && xvalid && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
-            const unsigned off = v ? (unsigned)(base + tof[j] * ld) * 4u : 0xffffffffu;
+            unsigned off = (m9 & tbit[j]) ? base + (unsigned)tofb[j] : 0xffffffffu;
+#ifdef SHM_ABL_SAMELINE
+            off = (m9 & tbit[j]) ? (unsigned)(c4 * 16 + (off & 0x300u)) : 0xffffffffu;        // timing only
+#endif
             if (STRADDLE) {
                 u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(second ? 0xffffffffu : off), 0, 0);
                 u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(second ? off : 0xffffffffu), 0, 0);
@@ -116,12 +136,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         // advance to the next stage
         p += BKP;
         ow += BKP;
-        while (ow >= a.wo) {
-            ow -= a.wo;
-            if (++oh == a.ho) {
-                oh = 0;
-                ++n;
-            }
+        if (ow >= a.wo) {                      // at most one wrap when wo >= BKP (every real layer)
+            do {
+                ow -= a.wo;
+                if (++oh == a.ho) {
+                    oh = 0;
+                    ++n;
+                }
+            } while (ow >= a.wo);
         }
     };
     auto sstore = [&](int buf, const f32x4 (&rx)[NTL], const f32x4& rd) {
@@ -152,15 +174,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         sstore(0, rx0, rd0);
         __syncthreads();
         int s = 0;
+#ifdef SHM_ABL_NOBAR
+#define WG_BAR()
+#else
+#define WG_BAR() __syncthreads()
+#endif
+#ifdef SHM_ABL_NOLOAD
+#define WG_GLOAD(a_, b_)
+#else
+#define WG_GLOAD(a_, b_) gload(a_, b_)
+#endif
+#ifdef SHM_ABL_NOSTORE
+#define WG_SSTORE(i_, a_, b_)
+#else
+#define WG_SSTORE(i_, a_, b_) sstore(i_, a_, b_)
+#endif
         for (; s + 3 < nstages; s += 2) {
-            gload(rx0, rd0);
+            WG_GLOAD(rx0, rd0);
             compute(0);
-            sstore(1, rx1, rd1);
-            __syncthreads();
-            gload(rx1, rd1);
+            WG_SSTORE(1, rx1, rd1);
+            WG_BAR();
+            WG_GLOAD(rx1, rd1);
             compute(1);
-            sstore(0, rx0, rd0);
-            __syncthreads();
+            WG_SSTORE(0, rx0, rd0);
+            WG_BAR();
         }
         const int left = nstages - s;
         if (left >= 3) gload(rx0, rd0);
