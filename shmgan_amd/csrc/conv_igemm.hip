@@ -484,7 +484,7 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
         a.wbytes = (unsigned)wb;
     }
     static const int use_dma = getenv("SHM_TAPGEMM_REG") ? 0 : 1;
-    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 0;
+    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
     if (use_dma) {
         if (a.nout > 64) {
             dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);

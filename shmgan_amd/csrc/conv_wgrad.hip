@@ -14,6 +14,8 @@
 // wgrad_reduce_kernel (deterministic, no float atomics).
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {
@@ -227,6 +229,166 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride-1 weight gradient with an LDS halo patch.
+//
+// A stage is a patch of 2 x 16 output pixels of one image.  Its 4 x 18 input halo (64 channels)
+// and its 2 x 16 dY pixels are brought in ONCE by LDS-DMA (buffer_load ... lds, out-of-image
+// pixels read as zeros through the descriptor range check); the nine taps are then nine shifted
+// views of the same LDS image, i.e. only an immediate offset on the ds_read_b32 that feeds each
+// MFMA.  Compared with fetching nine shifted tiles through L1 this moves 3x fewer bytes and
+// needs ~5x fewer address instructions per MFMA.  Three stages, DMA two stages ahead, counted
+// s_waitcnt vmcnt, raw s_barrier.  Work split: block = (64 ci, 64 co, slice of patches); wave w
+// owns the 32x32 sub-tile (w>>1, w&1) of all nine taps; partial slabs as in wgrad_kernel.
+struct WgradHaloArgs {
+    const float* x;
+    const float* x2;
+    int c1, ldx, ldx2;
+    const float* dy;
+    int lddy;
+    float* part;
+    int h, w, cin_ld, cin, cout;
+    int npatch, patches_per_split;
+    unsigned xbytes, x2bytes, dybytes;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs a) {
+    constexpr int PW = 16, HC = PW + 2;                 // patch 2 x 16, halo 4 x 18
+    constexpr int NHP = 4 * HC, NPX = 2 * PW;           // 72 halo pixels, 32 output pixels
+    constexpr int STAGE = (NHP + NPX) * 64;             // floats per stage
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int mi = wave >> 1, ni = wave & 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int pid0 = blockIdx.z * a.patches_per_split;
+    const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
+    const int nstages = pid1 - pid0;
+
+    // DMA lane mapping: one instruction = 4 pixel rows x 64 channels; lane -> (pixel l>>4, c4 = l&15)
+    const int dpx = lane >> 4, c4 = lane & 15;
+    const bool second = ci0 >= a.c1;
+    const int ldX = second ? a.ldx2 : a.ldx;
+    const int cX = ci0 + c4 * 4;
+    const bool xvalid = cX < a.cin_ld;
+    const int ccX = second ? cX - a.c1 : cX;
+    const int coD = co0 + c4 * 4;
+    const bool dvalid = coD < a.cout;
+    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    // items 0..17: halo rows [4i,4i+4); items 18..25: dY rows.  Wave w takes items w, w+4, ...
+    // per-lane constants of the X items (j = 0..4): halo coordinates of this lane's pixel
+    int hr[5], hc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int hp = 4 * (wave + 4 * j) + dpx;
+        hr[j] = hp / HC;
+        hc[j] = hp - hr[j] * HC;
+    }
+
+    // running patch coordinate (block-uniform)
+    int n, pr, pc;
+    {
+        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int p = pid0 < a.npatch ? pid0 : 0;
+        n = p / ppi;
+        const int r = p - n * ppi;
+        pr = (r / ppr) * 2;
+        pc = (r % ppr) * PW;
+    }
+    auto dma = [&](int stage) {
+        float* sx = smem + stage * STAGE;
+        float* sd = sx + NHP * 64;
+        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int item = wave + 4 * j;
+            if (item < 18) {
+                const int iy = pr - 1 + hr[j < 5 ? j : 0], ix = pc - 1 + hc[j < 5 ? j : 0];
+                const bool v = xvalid && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+                const unsigned off = v ? (unsigned)((org + hr[j < 5 ? j : 0] * a.w + hc[j < 5 ? j : 0]) * ldX + ccX) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
+            } else if (item < 26) {
+                const int q = 4 * (item - 18) + dpx;
+                const int oy = pr + (q >> 4), ox = pc + (q & 15);
+                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - 18) * 256), 16, (int)off, 0, 0, 0);
+            }
+        }
+        pc += PW;
+        if (pc == a.w) {
+            pc = 0;
+            pr += 2;
+            if (pr == a.h) {
+                pr = 0;
+                ++n;
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int xl = hh * 64 + mi * 32 + l31;       // + ((qr+kh)*18 + qc + kw)*64, qc even part
+    const int dl = hh * 64 + ni * 32 + l31;       // + 2*kk*64
+    auto compute = [&](int stage) {
+        const float* X = smem + stage * STAGE + xl;
+        const float* D = smem + stage * STAGE + NHP * 64 + dl;
+#pragma unroll
+        for (int kk = 0; kk < NPX / 2; ++kk) {
+            const int qr = kk >> 3, qc = 2 * (kk & 7);
+            const float bv = D[kk * 128];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float av = X[((qr + t / 3) * HC + qc + t % 3) * 64];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        dma(0);
+        if (nstages > 1) dma(1);
+        int cur = 0, nxt2 = 2;
+        for (int s = 0; s < nstages; ++s) {
+            if (s + 1 < nstages) {
+                if (wave < 2)
+                    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + 2 < nstages) dma(nxt2);
+            compute(cur);
+            asm volatile("" ::: "memory");
+            cur = (cur == NST - 1) ? 0 : cur + 1;
+            nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+        }
+    }
+
+    float* out = a.part + (size_t)blockIdx.z * 9 * a.cin * a.cout;
+    const int con = co0 + ni * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+        }
+    }
+}
+
 // dw[i] (+)= sum_k part[k][i], summed in a fixed order (4 interleaved chains, then 0+1+2+3).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
     __shared__ float red[4][64];
@@ -314,8 +476,35 @@ extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx
     ns = shm_cdiv(a.M, pps);
     a.pix_per_split = pps;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
     const bool straddle = x2 && (c1 % 64 != 0);
+    static const int no_halo = getenv("SHM_WGRAD_NOHALO") ? 1 : 0;
+    if (ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo) {
+        WgradHaloArgs hgs{};
+        hgs.x = x;
+        hgs.x2 = x2;
+        hgs.c1 = a.c1;
+        hgs.ldx = ldx;
+        hgs.ldx2 = ldx2;
+        hgs.dy = dy;
+        hgs.lddy = lddy;
+        hgs.part = (float*)workspace;
+        hgs.h = hi;
+        hgs.w = wi;
+        hgs.cin_ld = cin_ld;
+        hgs.cin = cin;
+        hgs.cout = cout;
+        hgs.npatch = batch * (hi / 2) * (wi / 16);
+        int nsh = ns < hgs.npatch ? ns : hgs.npatch;
+        hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        hgs.xbytes = a.xbytes;
+        hgs.x2bytes = a.x2bytes;
+        hgs.dybytes = a.dybytes;
+        ns = nsh;
+        dim3 gridh(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
+        hipLaunchKernelGGL(wgrad_halo_kernel, gridh, dim3(256), 0, st, hgs);
+    } else {
+    dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
     if (ksize == 3) {
         if (straddle)
             hipLaunchKernelGGL((wgrad_kernel<9, true>), grid, dim3(256), 0, st, a);
@@ -326,6 +515,7 @@ extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx
             hipLaunchKernelGGL((wgrad_kernel<1, true>), grid, dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, st, a);
+    }
     }
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad");
     size_t n = (size_t)a.ntaps * cin * cout;

@@ -57,10 +57,12 @@ struct PixMap {
 };
 
 static int pix_chunks(long npix_per_sample, int batch, int c) {
+    // enough blocks to fill the chip (~4k), but at least 16 pixel iterations per thread so the
+    // per-block LDS reduction + f64 atomics (one per channel and block) stay a small fraction
     int lanes_c = c / 4;
     int PP = 256 / lanes_c;
-    long want = (2048 + batch - 1) / batch;
-    long maxc = (npix_per_sample + (long)PP * 4 - 1) / ((long)PP * 4);
+    long want = (4096 + batch - 1) / batch;
+    long maxc = npix_per_sample / ((long)PP * 16);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
     return (int)want;

@@ -56,7 +56,7 @@ TIMER = None
 
 
 def _tile(nout):
-    return "tapgemm_kernel<128,128,2,2>" if nout > 64 else "tapgemm_kernel<256,64,4,1>"
+    return "tapgemm_dma_kernel<128,128,2,2>" if nout > 64 else "tapgemm_dma_kernel<128,64,2,2>"
 
 
 def _timed(sym, flops, fn, label=""):
