@@ -50,6 +50,15 @@ int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, c
                    const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
                    int cout, int ksize, int stride, float slope, void* stream);
 
+/* The same convolution fused with the InstanceNormalization statistics of its output
+ * (Conv2D -> LeakyReLU -> InstanceNormalization, SHM.py:244-245): the epilogue accumulates
+ * sum / sum of squares per (sample, channel); on return (stream order) stats holds
+ * (mean, rsqrt(var + eps)) exactly as shm_in_stats would leave it.  stats = f64 [batch*cout*2]. */
+int shm_conv2d_in_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
+                      const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+                      int cout, int ksize, int stride, float slope, double* stats, float eps,
+                      void* stream);
+
 /* Input-gradient of the same conv.  dy [batch,ho,wo,cout] (pitch lddy), w = HWIO
  * [k*k][cin][cout] as stored (it is already K-contiguous for this product), cout % 16 == 0.
  * dx channels [0,n1) go to dx (pitch lddx), [n1,cin) to dx2 (pitch lddx2): the split of a

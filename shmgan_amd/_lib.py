@@ -27,6 +27,7 @@ SIGNATURES = {
     "shm_last_error": (C.c_char_p, []),
     "shm_transpose_taps": (I, [P, P, I, I, I, I, P]),
     "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P]),
+    "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, F, P]),
     "shm_conv2d_dgrad": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "shm_conv2d_transpose_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, P]),
     "shm_conv2d_wgrad_workspace": (Z, [I, I, I, I, I, I]),

@@ -43,6 +43,8 @@ struct TapGemmArgs {
     int is, os;         // A stride, output stride
     int M;              // batch*hg*wg
     unsigned xbytes, x2bytes, wbytes;   // buffer-descriptor extents (bytes)
+    double* stats;      // optional [batch][nout][2] (sum, sum of squares) of the stored outputs
+    int hw;             // pixels per sample (stats only; hw % 64 == 0)
     float slope;
     TapPhase ph[4];
 };
@@ -430,6 +432,9 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
     }
 
     const bool direct = (a.os == 1);
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -452,6 +457,8 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[n];
                     v = shm_lrelu(v, a.slope);
+                    s1[j] += v;
+                    s2[j] += v * v;
                     if (n < a.n1)
                         a.y[opix * a.ldy + n] = v;
                     else
@@ -460,9 +467,33 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
             }
         }
     }
+    // InstanceNorm statistics of the tile just written: the 64 rows of a wave belong to one sample
+    // (hw % 64 == 0), so one f64 atomic per (wave, column, moment).
+    if (a.stats) {
+        const int mw = m0 + wm * WTM;
+        if (mw < a.M) {
+            const int img = mw / a.hw;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+                float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (h == 0 && n < a.nout) {
+                    double* dst = a.stats + ((size_t)img * a.nout + n) * 2;
+                    atomicAdd(dst, (double)t1);
+                    atomicAdd(dst + 1, (double)t2);
+                }
+            }
+        }
+    }
 }
 
+static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
+static thread_local int g_conv_hw = 0;
+
 static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
+    a.stats = g_conv_stats;
+    a.hw = g_conv_hw;
     SHM_REQUIRE(a.K % 16 == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of 16", who, a.K);
     SHM_REQUIRE(a.c1 % 16 == 0, SHM_E_SHAPE, "%s: concat split %d must be a multiple of 16", who, a.c1);
     SHM_REQUIRE(a.ldx % 4 == 0 && (a.x2 == nullptr || a.ldx2 % 4 == 0), SHM_E_SHAPE, "%s: input pitch must be a multiple of 4", who);
@@ -580,6 +611,33 @@ extern "C" int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, 
             P.widx[t] = t;
         }
     return launch_tapgemm(a, batch, 1, (hipStream_t)stream, "shm_conv2d_fwd");
+}
+
+int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipStream_t st);
+
+extern "C" int shm_conv2d_in_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
+                                 const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+                                 int cout, int ksize, int stride, float slope, double* stats, float eps,
+                                 void* stream) {
+    SHM_REQUIRE(stats, SHM_E_SHAPE, "shm_conv2d_in_fwd: null stats");
+    int ho, wo, pt;
+    shm_same_pad(hi, ksize, stride, &ho, &pt);
+    shm_same_pad(wi, ksize, stride, &wo, &pt);
+    const int hw = ho * wo;
+    static const int fuse = getenv("SHM_NO_STATS_FUSION") ? 0 : 1;
+    if (!fuse || hw % 64 != 0 || getenv("SHM_TAPGEMM_REG")) {       // tiny maps: separate statistics pass
+        int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stream);
+        if (r) return r;
+        return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, stream);
+    }
+    int r = shm_zero(stats, (size_t)batch * cout * 2 * sizeof(double), stream);
+    if (r) return r;
+    g_conv_stats = stats;
+    g_conv_hw = hw;
+    r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stream);
+    g_conv_stats = nullptr;
+    if (r) return r;
+    return shm_in_finalize_internal(stats, batch * cout, hw, (double)eps, (hipStream_t)stream);
 }
 
 // Transposed stride-2 product shared by Conv2DTranspose forward and the stride-2 dgrad:

@@ -125,6 +125,12 @@ __global__ void in_finalize_kernel(double* __restrict__ stats, int total, int hw
     stats[2 * i + 1] = 1.0 / sqrt(var + eps);
 }
 
+int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipStream_t st) {
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, total, hw, eps);
+    SHM_LAUNCH_CHECK("shm_in_finalize");
+    return SHM_OK;
+}
+
 extern "C" int shm_in_stats(const float* a, int lda, double* stats, int batch, int hw, int c, float eps, void* stream) {
     SHM_CHECK_C(c, "shm_in_stats");
     SHM_REQUIRE(lda % 4 == 0 && lda >= c, SHM_E_SHAPE, "shm_in_stats: bad pitch %d", lda);
@@ -472,24 +478,28 @@ __global__ void patch_dx_kernel(const float* __restrict__ dz, const float* __res
     *(f32x4*)(dx + q * lddx + cl * 4) = s;
 }
 
-// dw[tap][c] = sum_{n,i,j} x[n,i+kh-1,j+kw-1,c] * dz[n,i,j]; thread per (tap, c)
-__global__ void patch_dw_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, float* __restrict__ dw, int batch, int h, int wd, int c) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 9 * c) return;
-    int tap = idx / c, ch = idx - tap * c;
-    int dh = tap / 3 - 1, dwv = tap % 3 - 1;
+// dw[tap][c] = sum_{n,i,j} x[n,i+kh-1,j+kw-1,c] * dz[n,i,j]; block = (tap, 64 channels), 16 pixel groups
+__global__ __launch_bounds__(1024) void patch_dw_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, float* __restrict__ dw, int batch, int h, int wd, int c) {
+    __shared__ double red[16][64];
+    const int tap = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int dh = tap / 3 - 1, dwv = tap % 3 - 1;
+    const int npx = batch * h * wd;
     double s = 0.0;
-    for (int n = 0; n < batch; ++n)
-        for (int i = 0; i < h; ++i) {
-            int ii = i + dh;
-            if ((unsigned)ii >= (unsigned)h) continue;
-            for (int j = 0; j < wd; ++j) {
-                int jj = j + dwv;
-                if ((unsigned)jj >= (unsigned)wd) continue;
-                s += (double)x[((size_t)(n * h + ii) * wd + jj) * ldx + ch] * (double)dz[(n * h + i) * wd + j];
-            }
+    if (ch < c)
+        for (int q = g; q < npx; q += 16) {
+            const int j = q % wd, t = q / wd;
+            const int i = t % h, n = t / h;
+            const int ii = i + dh, jj = j + dwv;
+            if ((unsigned)ii < (unsigned)h && (unsigned)jj < (unsigned)wd)
+                s += (double)x[((size_t)(n * h + ii) * wd + jj) * ldx + ch] * (double)dz[q];
         }
-    dw[idx] = (float)s;
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && ch < c) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x & 63];
+        dw[(size_t)tap * c + ch] = (float)t;
+    }
 }
 
 extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
@@ -504,7 +514,7 @@ extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const floa
     hipLaunchKernelGGL(patch_dx_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, (const float*)dz, w, dx, lddx, h, wd, c / 4, total);
     SHM_LAUNCH_CHECK("shm_patch_bwd(dx)");
     if (dw) {
-        hipLaunchKernelGGL(patch_dw_kernel, dim3(shm_cdiv(9 * c, 64)), dim3(64), 0, st, x, ldx, (const float*)dz, dw, batch, h, wd, c);
+        hipLaunchKernelGGL(patch_dw_kernel, dim3(9, shm_cdiv(c, 64)), dim3(1024), 0, st, x, ldx, (const float*)dz, dw, batch, h, wd, c);
         SHM_LAUNCH_CHECK("shm_patch_bwd(dw)");
     }
     return SHM_OK;

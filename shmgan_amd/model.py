@@ -193,9 +193,8 @@ class Generator(_ModelBase):
         a = A.get(f"{tag}/a{li}", (n, h, w, cout))
         ahat = A.get(f"{tag}/h{li}", (n, h, w, cout))
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
-        ops.conv2d_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
-                       k, 1, LRELU, cin_real=cin)
-        ops.in_stats(a, cout, stats, n, h * w, cout, IN_EPS)
+        ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
+                          k, 1, LRELU, stats, IN_EPS, cin_real=cin)
         ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
         return ahat, rec
@@ -423,9 +422,8 @@ class Discriminator(_ModelBase):
             a = A.get(f"d/a{i}/{n}", (n, ho, ho, cout))
             ahat = A.get(f"d/h{i}/{n}", (n, ho, ho, cout))
             stats = A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)
-            ops.conv2d_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU,
-                           cin_real=cin)
-            ops.in_stats(a, cout, stats, n, ho * ho, cout, IN_EPS)
+            ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU,
+                              stats, IN_EPS, cin_real=cin)
             ops.in_apply(a, cout, stats, self.betas[i], ahat, cout, n, ho * ho, cout)
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
             cur, ld, h = ahat, cout, ho

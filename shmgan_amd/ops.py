@@ -85,6 +85,17 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
+def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, eps,
+                  cin_real=None):
+    """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std)."""
+    ho, wo = -(-hi // stride), -(-wi // stride)
+    flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
+    _timed(_tile(cout), flops, lambda: check(
+        lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                                cin, cout, ksize, stride, slope, _p(stats), eps, _stream()), "shm_conv2d_in_fwd"),
+           f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
+
+
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
