@@ -163,7 +163,20 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     }
     const float* base = a + (size_t)n * hw * lda + pm.cl * 4;
     float* ob = out + (size_t)n * hw * ldo + pm.cl * 4;
-    for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+    int p = p0 + pm.pp;
+    for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(base + (size_t)(p + u * pm.PP) * lda);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (x[u][e] - mean[e]) * inv[e] + bt[e];
+            *(f32x4*)(ob + (size_t)(p + u * pm.PP) * ldo) = y;
+        }
+    }
+    for (; p < p1; p += pm.PP) {
         f32x4 x = *(const f32x4*)(base + (size_t)p * lda);
         f32x4 y;
 #pragma unroll
@@ -221,7 +234,30 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             mean[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2];
             inv[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2 + 1];
         }
-        for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+        // 4 pixels per iteration: 8-12 independent 16-byte loads in flight per thread; the per-pixel
+        // partial sums are combined in fp32 (4 terms) before the fp64 accumulation
+        int p = p0 + pm.pp;
+        for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
+            f32x4 g[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = in_bwd_dout(k, n, p + u * pm.PP, pm.cl);
+                x[u] = *(const f32x4*)(k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sg = 0.f, sx = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float xh = (x[u][e] - mean[e]) * inv[e];
+                    sg += g[u][e];
+                    sx += g[u][e] * xh;
+                }
+                v[0][e] += (double)sg;
+                v[1][e] += (double)sx;
+            }
+        }
+        for (; p < p1; p += pm.PP) {
             f32x4 g = in_bwd_dout(k, n, p, pm.cl);
             f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
 #pragma unroll
@@ -250,7 +286,31 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             m1[e] = (float)(k.red[i] / hw);
             m2[e] = (float)(k.red[i + 1] / hw);
         }
-        for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
+        int p = p0 + pm.pp;
+        for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
+            f32x4 g[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = in_bwd_dout(k, n, p + u * pm.PP, pm.cl);
+                x[u] = *(const f32x4*)(k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
+            }
+            float sd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xh = (x[u][e] - mean[e]) * inv[e];
+                    float da = inv[e] * (g[u][e] - m1[e] - xh * m2[e]);
+                    d[e] = x[u][e] > 0.f ? da : da * k.slope;
+                    sd[e] += d[e];
+                }
+                *(f32x4*)(k.dz + ((size_t)n * hw + p + u * pm.PP) * k.lddz + pm.cl * 4) = d;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
+        }
+        for (; p < p1; p += pm.PP) {
             f32x4 g = in_bwd_dout(k, n, p, pm.cl);
             f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
             f32x4 d;
