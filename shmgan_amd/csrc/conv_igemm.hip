@@ -281,11 +281,12 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
 // Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
 // counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
-    static_assert(WGM * WGN == 4, "4 waves");
+__global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGemmArgs a) {
+    constexpr int NW = WGM * WGN;                    // waves per block (4 or 8)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int NA = BM / 64, NB = BN / 64;        // DMA instructions per wave and stage
+    constexpr int NA = BM / (16 * NW), NB = BN / (16 * NW);   // DMA instructions per wave and stage
+    static_assert(NA >= 1 && NB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "16 rows per DMA instruction");
     constexpr int NLD = NA + NB;
     constexpr int STAGE = (BM + BN) * 16;            // floats
     constexpr int NST = 3;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
     unsigned rowb1[NA], rowb2[NA], okm[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int row = wave * (BM / 4) + 16 * j + drow;
+        const int row = wave * (BM / NW) + 16 * j + drow;
         const int m = m0 + row;
         const bool mv = m < a.M;
         const int mm = mv ? m : 0;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
     unsigned wrow[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int row = wave * (BN / 4) + 16 * j + drow;
+        const int row = wave * (BN / NW) + 16 * j + drow;
         const int nn = n0 + row;
         wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * 4) * 4u : 0xffffffffu;
     }
@@ -355,8 +356,8 @@ __global__ __launch_bounds__(256) void tapgemm_dma_kernel(const TapGemmArgs a) {
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto dma = [&](int stage) {
-        float* sa = smem + stage * STAGE + wave * (BM / 4) * 16;
-        float* sb = smem + stage * STAGE + BM * 16 + wave * (BN / 4) * 16;
+        float* sa = smem + stage * STAGE + wave * (BM / NW) * 16;
+        float* sb = smem + stage * STAGE + BM * 16 + wave * (BN / NW) * 16;
         const int c0 = ld_c0;
         const bool second = c0 >= a.c1;
         const int ld = second ? a.ldx2 : a.ldx;
@@ -516,8 +517,12 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     }
     static const int use_dma = getenv("SHM_TAPGEMM_REG") ? 0 : 1;
     static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
+    static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
     if (use_dma) {
-        if (a.nout > 64) {
+        if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
+            dim3 grid(shm_cdiv(a.M, 256), shm_cdiv(a.nout, 128), nphase);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2>), grid, dim3(512), 0, st, a);
+        } else if (a.nout > 64) {
             dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
             hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
         } else if (dma_small == 0) {

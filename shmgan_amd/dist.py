@@ -27,7 +27,8 @@ class GradReducer:
         self.device = device
         self.stream = None
 
-    def allreduce_async(self, flat):
+    def allreduce_async(self, flat, after=None):
+        """`after`: optional extra event (e.g. the wgrad lane) the collective must also wait for."""
         if world_size() == 1:
             return None
         if not flat.is_cuda:
@@ -40,6 +41,8 @@ class GradReducer:
         done = torch.cuda.Event()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
+            if after is not None:
+                self.stream.wait_event(after)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             done.record(self.stream)
         return done

@@ -48,6 +48,40 @@ class Arena:
         return sum(t.numel() * t.element_size() for t in self.t.values())
 
 
+class WgradLane:
+    """Second HIP stream for the weight-gradient launches.  In a backward pass only the
+    in_bwd -> dgrad chain is on the critical path; every wgrad just needs its layer's dz.  Issuing
+    them on their own stream lets the hardware fill the tail of each (dependent) kernel on the main
+    stream with wgrad workgroups.  Buffers a wgrad reads (dz per layer, forward activations) are not
+    rewritten before `join()`."""
+
+    def __init__(self, device, enabled=True):
+        self.stream = torch.cuda.Stream(device=device) if enabled else None
+
+    def submit(self, fn):
+        if self.stream is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                   # everything issued so far on the main stream
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            fn()
+
+    def event(self):
+        """Event marking the completion of everything submitted so far (None if disabled)."""
+        if self.stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def join(self):
+        ev = self.event()
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
 def generator_layers(f):
     """(keras_name, kind, k, cin, cout) in Keras creation order (Generator_summary.txt)."""
     return [
@@ -126,9 +160,10 @@ class _ModelBase:
 class Generator(_ModelBase):
     name = "SHM_Generator"
 
-    def __init__(self, image_size, filter_size, device, arena, ws_provider):
+    def __init__(self, image_size, filter_size, device, arena, ws_provider, lane=None):
         self.S, self.F, self.dev = image_size, filter_size, device
         self.arena, self.ws_provider = arena, ws_provider
+        self.lane = lane or WgradLane(device, enabled=False)
         assert image_size % 16 == 0 and filter_size % 16 == 0, "image_size and filter_size must be multiples of 16"
         self.layers = generator_layers(filter_size)
         shapes = []
@@ -258,7 +293,7 @@ class Generator(_ModelBase):
         li, h, w = rec["li"], rec["h"], rec["w"]
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
-        dz = A.get(f"bwd/dz/{n}x{h}x{cout}", (n, h, w, cout))
+        dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout))       # per layer: read later by the wgrad lane
         red = A.get(f"bwd/red/{n * cout}", (n * cout * 2,), torch.float64)
         ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
                    h, w, cout, LRELU)
@@ -266,8 +301,8 @@ class Generator(_ModelBase):
             self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
         cin_p = _pad16(cin)
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
-        ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout, self.P.grads[2 * li], n,
-                         h, w, cin, cin_p, cout, k, 1, 1, ws)
+        self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
+                                                  self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
         if need_dx:
             lddx = rec["ldx"]
             ops.conv2d_dgrad(dz, cout, self.P.vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
@@ -305,11 +340,11 @@ class Generator(_ModelBase):
             # Conv2DTranspose: LeakyReLU', bias grad, wgrad (roles swapped), dgrad = stride-2 conv
             tli = up["li"]
             _, _, _, tcin, tcout = self.layers[tli]
-            dzu = A.get(f"bwd/dzu/{n}x{h}x{cu}", (n, h, h, cu))
+            dzu = A.get(f"bwd/dzu/L{tli}/{n}", (n, h, h, cu))
             ops.lrelu_bwd(du, cu, up["u"], cu, dzu, cu, self._acc_slice(2 * tli + 1), n * h * h, cu, LRELU)
             ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, tcout, tcin, 3))
-            ops.conv2d_wgrad(dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout,
-                             tcin, 3, 2, 1, ws)
+            self.lane.submit(lambda dzu=dzu, up=up, tli=tli, tcout=tcout, tcin=tcin, h=h, ws=ws: ops.conv2d_wgrad(
+                dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout, tcin, 3, 2, 1, ws))
             hin = up["h"]
             dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin))
             ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0)
@@ -376,9 +411,10 @@ class Generator(_ModelBase):
 class Discriminator(_ModelBase):
     name = "SHM_Discriminator"
 
-    def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2):
+    def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2, lane=None):
         self.S, self.F, self.dev = image_size, filter_size, device
         self.arena, self.ws_provider = arena, ws_provider
+        self.lane = lane or WgradLane(device, enabled=False)
         self.dropout = dropout
         assert image_size % 32 == 0
         f, s = filter_size, image_size // 32
@@ -468,8 +504,8 @@ class Discriminator(_ModelBase):
             ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
             if params:
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))
-                ops.conv2d_wgrad(rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _pad16(cin),
-                                 cout, 3, 2, 0, ws)
+                self.lane.submit(lambda rec=rec, dz=dz, i=i, h=h, cin=cin, cout=cout, ws=ws: ops.conv2d_wgrad(
+                    rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _pad16(cin), cout, 3, 2, 0, ws))
             if i > 0 or need_dx:
                 ldx = rec["ldx"]
                 dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx))

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .dist import GradReducer, world_size
-from .model import PAD_C, Arena, Discriminator, Generator
+from .model import PAD_C, Arena, Discriminator, Generator, WgradLane
 
 
 class _Optimizer:
@@ -85,6 +85,7 @@ class ShmGANwithSSpecSeg:
         self.optimizer_D = _Optimizer(self.g_lr, self.beta1, self.beta2)
         self.arena = Arena(self.device)
         self._ws = None
+        self._lane = None
         self.G = self.D = None
         self.specular_candidate = None          # constant zero in the executed graph (finding 3)
         self._rng = np.random.default_rng(self.seed)
@@ -94,20 +95,32 @@ class ShmGANwithSSpecSeg:
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, nbytes):
+        """Split-K slab workspace of the wgrad launches (they run in order on one stream)."""
         n = (nbytes + 3) // 4
         if self._ws is None or self._ws.numel() < n:
-            self._ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+            # 128 MiB covers every layer at S=256/B=8; growing mid-step would hand memory still in
+            # use on the wgrad lane back to the allocator, hence the join before re-allocating
+            if self._lane is not None:
+                self._lane.join()
+                torch.cuda.current_stream().synchronize()
+            self._ws = torch.empty(max(n, 32 << 20), dtype=torch.float32, device=self.device)
         return self._ws
+
+    def _get_lane(self):
+        import os
+        if self._lane is None:
+            self._lane = WgradLane(self.device, enabled=os.environ.get("SHM_NO_WGRAD_LANE") is None)
+        return self._lane
 
     # ------------------------------------------------------------------ builders
     def build_generator(self):
         """SHM.py:228-327."""
-        return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace)
+        return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace, self._get_lane())
 
     def build_discriminator(self):
         """SHM.py:343-380."""
         return Discriminator(self.image_size, self.filter_size, self.device, self.arena, self._workspace,
-                             self.dropout_amnt)
+                             self.dropout_amnt, self._get_lane())
 
     def build(self, seed=42, beta_seed=43):
         """Build G and D and give them the synthetic init of SURVEY 8(d): weights N(0,0.02) from
@@ -169,9 +182,9 @@ class ShmGANwithSSpecSeg:
     def _world(self):
         return world_size()
 
-    def _allreduce_async(self, flat):
+    def _allreduce_async(self, flat, after=None):
         """Sum `flat` over ranks on the side stream; returns an event to wait on (or None)."""
-        return self._reducer.allreduce_async(flat)
+        return self._reducer.allreduce_async(flat, after)
 
     # ------------------------------------------------------------------ the step
     def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True):
@@ -247,7 +260,7 @@ class ShmGANwithSSpecSeg:
 
         # ---- D backward (weights) then its all-reduce overlapped with everything below
         D.backward_params(drf_d, dcls_d)
-        ev_d = self._allreduce_async(D.P.grad)
+        ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event())
 
         # ---- G-loss gradient through D (data gradient only), then G backward
         dxd = D.backward_input(6 * B, drf_g)
@@ -257,6 +270,7 @@ class ShmGANwithSSpecSeg:
         ops.cyc_input_bwd(dcyc_in, fmask, dgen_y, B, npix)       # G o G chain  SHM.py:576-580
         G.backward(dgen_y, "g1", need_dx=False)
         G.finish_grads()
+        self._get_lane().join()                 # all weight gradients (both models) are complete
         ev_g = self._allreduce_async(G.P.grad)
 
         # ---- clip + Adam  SHM.py:859-872

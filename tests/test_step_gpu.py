@@ -151,6 +151,7 @@ def test_discriminator_forward_backward():
     assert np.abs(host(clsd) - cls.detach().numpy()).max() < 1e-4
     m.D.zero_grad()
     m.D.backward_params(dev(g_rf), dev(g_cls))
+    torch.cuda.synchronize()          # weight gradients run on the wgrad lane (second stream)
     for i, (got, ref) in enumerate(zip(m.D.P.grads, grads[:-1])):
         r = rel_l2(host(got), ref.numpy())
         assert r < 1e-3 and cosine(host(got), ref.numpy()) > 0.9999, (i, r)
