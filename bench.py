@@ -10,8 +10,13 @@ per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
 
 A "step" = pre-processing + 6 generator forwards + 12 discriminator forwards + both backward
 passes + clip + 2 Adam updates (+ all-reduce) on one synthetic batch already resident in HBM.
-`roofline` is measured live: every MFMA conv launch of the timed steps is bracketed by HIP events
-on its stream; the dominant kernel symbol's algorithmic FLOPs / its summed duration is `achieved`.
+`roofline` is measured live with HIP events bracketing every MFMA conv launch on its stream; the
+dominant kernel symbol's algorithmic FLOPs / its summed duration is `achieved`.  Because the step
+runs weight gradients on a second stream (kernel lifetimes overlap, so a per-kernel duration is not
+a property of the kernel any more), the event pass is a serialized replay of the same K steps in
+the same process right after the timed region (`roofline.region`); `--serialize` runs the timed
+region itself without the second stream, which is the command the committed rocprofv3 summaries
+(profiles/) were taken with.
 `cpu_baseline` times the CPU oracle (PyTorch-CPU/oneDNN restatement of the same step, fp32) on
 this box's host cores on a bounded sample (B=1 steps at the same image size).
 """
@@ -38,6 +43,7 @@ def main():
     ap.add_argument("--filter-size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--serialize", action="store_true", help="no second stream for weight gradients (profiling)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
@@ -99,23 +105,39 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    lane = model._get_lane()
+    lane_stream = lane.stream
+    if args.serialize:
+        lane.stream = None
     note(f"model built, arena {model.arena.nbytes() / 2**30:.2f} GiB")
     for i in range(args.warmup):
         model.train_step(*inputs, draws=draws_for(i))
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     sync()
-    timer = None
-    if not args.no_kernel_timer and rank == 0:
-        timer = ops.KernelTimer()
-        ops.TIMER = timer
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.train_step(*inputs, draws=draws_for(args.warmup + i))
     sync()
     dt = time.perf_counter() - t0
-    ops.TIMER = None
     note(f"timed {args.steps} steps in {dt:.3f}s")
+    # per-kernel HIP-event pass: serialized replay (single stream) of the same number of steps
+    timer = None
+    dt_serial = 0.0
+    if not args.no_kernel_timer:               # every rank replays (the steps contain collectives)
+        lane.stream = None
+        if rank == 0:
+            timer = ops.KernelTimer()
+            ops.TIMER = timer
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            model.train_step(*inputs, draws=draws_for(args.warmup + args.steps + i))
+        torch.cuda.synchronize()
+        dt_serial = time.perf_counter() - t1
+        ops.TIMER = None
+        lane.stream = lane_stream
+        note(f"serialized event replay: {args.steps} steps in {dt_serial:.3f}s")
+    sync()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,6 +166,9 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "region": "serialized replay of the timed steps (single stream), same process",
+                "replay_ms_per_step": round(dt_serial / args.steps * 1e3, 3),
+                "whole_step_conv_tflops": round(sum(v["flops"] for v in summ.values()) / args.steps / (ms * 1e-3) / 1e12, 2),
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "flops_per_launch": d["flops"] / d["launches"],
                 "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),

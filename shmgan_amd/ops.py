@@ -121,7 +121,8 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
                  accumulate, ws):
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
-    _timed("wgrad_kernel<%d>" % (ksize * ksize), flops, lambda: check(
+    halo = ksize == 3 and stride == 1 and wi % 16 == 0 and hi % 2 == 0 and not (x2 is not None and c1 % 64 != 0)
+    _timed("wgrad_halo_kernel(+reduce)" if halo else "wgrad_kernel<%d>(+reduce)" % (ksize * ksize), flops, lambda: check(
         lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
                                cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
                                _stream()), "shm_conv2d_wgrad"),
