@@ -406,9 +406,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static int wgrad_splits(int batch, int ho, int wo, int cin, int cout) {
+    // two 256-thread blocks fit per CU (LDS): two rounds of 512 blocks keep every CU busy and
+    // the split-K slab traffic (ns * 9*cin*cout floats written + read) small
     long M = (long)batch * ho * wo;
     int tiles = shm_cdiv(cin, 64) * shm_cdiv(cout, 64);
-    int want = shm_cdiv(1024, tiles);            // ~4 blocks per CU in flight
+    static const int target = getenv("SHM_WGRAD_BLOCKS") ? atoi(getenv("SHM_WGRAD_BLOCKS")) : 1024;
+    int want = shm_cdiv(target, tiles);
     long maxs = (M + 255) / 256;                 // at least 256 pixels per split
     if (want > maxs) want = (int)maxs;
     if (want < 1) want = 1;
