@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serialize", action="store_true", help="no second stream for weight gradients (profiling)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: all ranks share GPU 0")
@@ -163,9 +163,16 @@ def main():
             dom = max(summ, key=lambda k: summ[k]["ms"])
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic = None
+            tpath = ROOT / "profiles" / "r01_v2_traffic_pmc.json"      # rocprofv3 --pmc passes (see profiles/README.md)
+            if tpath.exists():
+                tj = json.loads(tpath.read_text())
+                for name, rec in tj.items():
+                    if name.replace("void ", "").replace(" ", "") == dom.replace(" ", ""):
+                        traffic = rec["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "region": "serialized replay of the timed steps (single stream), same process",
                 "replay_ms_per_step": round(dt_serial / args.steps * 1e3, 3),
                 "whole_step_conv_tflops": round(sum(v["flops"] for v in summ.values()) / args.steps / (ms * 1e-3) / 1e12, 2),
