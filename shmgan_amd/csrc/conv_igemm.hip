@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
 // the descriptor's range check makes the DMA write zeros (tools/ldsdma_probe.hip).
 // Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
 // counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NST>
 __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGemmArgs a) {
     constexpr int NW = WGM * WGN;                    // waves per block (4 or 8)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     static_assert(NA >= 1 && NB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "16 rows per DMA instruction");
     constexpr int NLD = NA + NB;
     constexpr int STAGE = (BM + BN) * 16;            // floats
-    constexpr int NST = 3;
+    static_assert(NST == 2 || NST == 3, "2 stages: DMA one step ahead; 3 stages: two steps ahead");
     __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
 
     const TapPhase& P = a.ph[blockIdx.z];
@@ -414,22 +414,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         }
     };
 
+    constexpr int AHEAD = NST - 1;                  // stages in flight beyond the one being computed
     dma(0);
-    if (ksteps > 1) dma(1);
-    int cur = 0, nxt2 = 2;
+    if (AHEAD > 1 && ksteps > 1) dma(1);
+    int cur = 0, nxt = AHEAD % NST;
     for (int s = 0; s < ksteps; ++s) {
-        // stage s must have landed: everything but the newest NLD DMAs (those of stage s+1)
-        if (s + 1 < ksteps)
+        // stage s must have landed: everything but the DMAs of the stages issued after it
+        if (AHEAD > 1 && s + 1 < ksteps)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // all waves: stage s landed, compute(s-1) finished
         asm volatile("" ::: "memory");
-        if (s + 2 < ksteps) dma(nxt2);         // overwrites the buffer compute(s-1) was reading
+        if (s + AHEAD < ksteps) dma(nxt);      // overwrites the buffer compute(s-1) was reading
         compute(cur);
         asm volatile("" ::: "memory");
         cur = (cur == NST - 1) ? 0 : cur + 1;
-        nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+        nxt = (nxt == NST - 1) ? 0 : nxt + 1;
     }
 
     const bool direct = (a.os == 1);
@@ -521,16 +522,16 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     if (use_dma) {
         if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
             dim3 grid(shm_cdiv(a.M, 256), shm_cdiv(a.nout, 128), nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2>), grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3>), grid, dim3(512), 0, st, a);
         } else if (a.nout > 64) {
             dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, a);
         } else if (dma_small == 0) {
             dim3 grid(shm_cdiv(a.M, 256), 1, nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2>), grid, dim3(256), 0, st, a);
         } else {
             dim3 grid(shm_cdiv(a.M, 128), 1, nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, st, a);
         }
         SHM_LAUNCH_CHECK(who);
         return SHM_OK;
