@@ -153,8 +153,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, fp32 "
-                                   "(BASELINE configs[1])",
+            "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, fp32"
+                                   + (" (BASELINE configs[1])" if (S, B, F) == (256, 8, 64) else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "losses_finite": bool(finite)},
         }
