@@ -467,3 +467,31 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
         gG = torch.autograd.grad(total_G.mean(), gv)
         out["gD"], out["gG"] = list(gD), list(gG)
     return out
+
+
+# ---------------------------------------------------------------------------
+# inference path of the evaluation script
+# ---------------------------------------------------------------------------
+def infer(gvars, gbetas, rgb, filter_size=64, dtype=torch.float64):
+    """/root/reference/test.py:218-297 restated: one RGB image in, the generated (ED) image and the
+    five cyclic reconstructions out.  rgb [B,S,S,3] in [0,1].  Returns dict of NHWC tensors."""
+    T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype)
+    gv = [T(a) for a in gvars]
+    gb = [T(a) for a in gbetas]
+    x = T(rgb)
+    B, S = x.shape[0], x.shape[1]
+    yuv, scale = per_image_standardization(rgb_to_yuv(x))                 # test.py:218
+    cbcr = yuv[..., 1:]                                                   # test.py:224
+    zeros = torch.zeros(B, S, S, 1, dtype=dtype)
+    ones = torch.ones(B, S, S, 1, dtype=dtype)
+    gen_input = torch.cat([yuv[..., 0:1]] + [zeros] * 8 + [ones], dim=3)  # test.py:227-237
+    gen_Y = generator_forward(gv, gb, gen_input, filter_size)             # test.py:243
+    gen_rgb = yuv_to_rgb(torch.cat([gen_Y, cbcr], dim=3))                 # test.py:244-250
+    orig_Ych = gen_rgb[..., 0:1]                                          # test.py:252 (channel 0 of the RGB)
+    cyc_rgb = []
+    for k in range(5):                                                    # test.py:260-297
+        chans = [zeros if j == k else orig_Ych for j in range(5)]
+        onehot = [ones if j == k else zeros for j in range(5)]
+        cy = generator_forward(gv, gb, torch.cat(chans + onehot, dim=3), filter_size)
+        cyc_rgb.append(yuv_to_rgb(torch.cat([cy, cbcr], dim=3)))
+    return {"gen_Y": gen_Y, "gen_rgb": gen_rgb, "cyc_rgb": cyc_rgb, "scale": scale}

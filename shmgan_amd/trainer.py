@@ -304,6 +304,65 @@ class ShmGANwithSSpecSeg:
         self._loss_cache = None
         return None
 
+    # ------------------------------------------------------------------ inference (test.py:218-297)
+    def infer(self, rgb):
+        """Forward-only path of the reference's evaluation script (/root/reference/test.py:218-297):
+        standardised YUV of ONE rgb image -> G once with only view 0 populated (target ED) -> the
+        generated RGB, whose channel 0 feeds five cyclic G calls.  rgb [B,S,S,3] in [0,1].
+        Returns (gen_rgb [B,S,S,3], [5 x cyc_rgb [B,S,S,3]]); sets the same attributes as test.py."""
+        if self.G is None:
+            self.build()
+        G, A = self.G, self.arena
+        S = self.image_size
+        x = self._dev(rgb)
+        B = x.shape[0]
+        npix = S * S
+        G.prepare_weights()
+        yuv, scale = self.preprocess(x, "inf")
+        cbcr = yuv[..., 1:].contiguous()                       # averageCbCr = the input's own CbCr (test.py:224)
+        ys = [yuv] * 5
+        gen_in = A.get("inf/in", (B, S, S, PAD_C))
+        ops.build_gen_input(ys, None, 0b11110, 0, gen_in, B, npix)          # views 1..4 zero, one-hot = ED
+        gen_Y = G.forward(gen_in, "inf1")
+        gen_rgb = A.get("inf/rgb", (B, S, S, 3))
+        ops.yuv2rgb(gen_Y, cbcr, None, gen_rgb, None, B, B, npix)
+        orig_Ych = gen_rgb[..., 0:1].contiguous()              # test.py:252
+        cyc_in = A.get("inf/cyc_in", (5 * B, S, S, PAD_C))
+        ops.build_gen_input(ys, orig_Ych, 0b11111, 1, cyc_in, B, npix)      # view k zero, the others = orig_Ych
+        cyc_Y = G.forward(cyc_in, "inf5")
+        cyc_rgb = A.get("inf/cyc_rgb", (5 * B, S, S, 3))
+        ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, None, 5 * B, B, npix)
+        self.gen_input, self.gen_Y, self.gen_rgb = gen_in, gen_Y, gen_rgb
+        self.stddev_arr = [scale]
+        outs = [cyc_rgb[k * B:(k + 1) * B] for k in range(5)]
+        (self.cyc_gen0_rgb, self.cyc_gen45_rgb, self.cyc_gen90_rgb, self.cyc_gen135_rgb, self.cyc_genED_rgb) = outs
+        return gen_rgb, outs
+
+    # ------------------------------------------------------------------ weights interchange (SURVEY N3)
+    def save_npz(self, path):
+        """Weights + IN betas + Adam state in a neutral .npz (Keras variable order and layouts)."""
+        d = {}
+        for name, M in (("G", self.G), ("D", self.D)):
+            for i, w in enumerate(M.get_weights()):
+                d[f"{name}/var{i:02d}"] = w
+            for i, b in enumerate(M.betas):
+                d[f"{name}/beta{i:02d}"] = b.cpu().numpy()
+            d[f"{name}/adam_m"] = M.P.m.cpu().numpy()
+            d[f"{name}/adam_v"] = M.P.v.cpu().numpy()
+            d[f"{name}/iterations"] = np.int64(M.P.iterations)
+        np.savez(path, **d)
+
+    def load_npz(self, path):
+        z = np.load(path)
+        if self.G is None:
+            self.build()
+        for name, M in (("G", self.G), ("D", self.D)):
+            M.set_weights([z[f"{name}/var{i:02d}"] for i in range(len(M.P.vars))])
+            M.set_betas([z[f"{name}/beta{i:02d}"] for i in range(len(M.betas))])
+            M.P.m.copy_(torch.from_numpy(z[f"{name}/adam_m"]))
+            M.P.v.copy_(torch.from_numpy(z[f"{name}/adam_v"]))
+            M.P.iterations = int(z[f"{name}/iterations"])
+
     def _img_ws(self, B):
         n = ops.image_losses_workspace(B, self.image_size)
         return self.arena.get("loss/ws", ((n + 3) // 4,))

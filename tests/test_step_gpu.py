@@ -257,3 +257,31 @@ def test_golden_fixture_on_device(name):
         ok = ref > 1e-12
         assert np.abs(n[ok] / ref[ok] - 1).max() < 5e-2
         assert np.median(np.abs(n[ok] / ref[ok] - 1)) < 1e-3
+
+
+def test_inference_path_matches_oracle(tmp_path):
+    """test.py:218-297: forward-only G x6, plus the .npz weight round trip (N3)."""
+    S, F, B = 64, 16, 2
+    m, (g, d, gb, db) = _mk(S, F, B)
+    rng = np.random.default_rng(40)
+    rgb = rng.random((B, S, S, 3))
+    ref = st.infer(g, gb, rgb, F)
+    gen_rgb, cyc = m.infer(rgb)
+    torch.cuda.synchronize()
+    assert np.abs(host(gen_rgb) - ref["gen_rgb"].numpy()).max() < 1e-4
+    for k in range(5):
+        assert np.abs(host(cyc[k]) - ref["cyc_rgb"][k].numpy()).max() < 1e-4
+    # weights / optimizer state interchange
+    m.train_step(*st.make_inputs(B, S), draws=st.make_draws(0, B, S, F))
+    torch.cuda.synchronize()
+    p = tmp_path / "ckpt.npz"
+    m.save_npz(p)
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m2 = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build(seed=1, beta_seed=2)
+    m2.load_npz(p)
+    assert torch.equal(m2.G.P.flat, m.G.P.flat) and torch.equal(m2.D.P.flat, m.D.P.flat)
+    assert torch.equal(m2.G.P.m, m.G.P.m) and m2.G.P.iterations == 1
+    a, _ = m.infer(rgb)
+    a = host(a).copy()
+    b, _ = m2.infer(rgb)
+    assert np.array_equal(a, host(b))
