@@ -297,6 +297,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
+    // (an XCD-aware tile order -- contiguous M ranges per XCD, N tiles innermost -- was measured
+    // 1 % slower: the kernel is not L2/HBM bound)
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // DMA lane mapping: instruction j of this wave covers rows wave*(BM/4)+16j .. +15
@@ -338,8 +340,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     const int ntaps = P.ntaps;
     const int nch = a.K >> 4;
     const int ksteps = ntaps * nch;
+    // The tap table lives in two VGPRs (lane t holds tap t) and is read with v_readlane: a scalar
+    // memory load inside the K loop would share lgkmcnt with the ds_reads and force every fragment
+    // wait to lgkmcnt(0) (SMEM returns out of order).
+    const int tl = lane < ntaps ? lane : 0;
+    const int tapoff_v = P.dh[tl] * a.wi + P.dw[tl];      // pixel displacement of tap `lane`
+    const int tapw_v = P.widx[tl];                        // its weight slice
     int ld_g = 0, ld_tap = 0, ld_sub = 0, ld_c0 = 0;
-    int t_dh = P.dh[0], t_dw = P.dw[0], t_wi = P.widx[0];
     auto advance = [&]() {
         const int nsub = (nch - ld_g) >= 2 ? 2 : 1;
         if (++ld_sub == nsub) {
@@ -348,9 +355,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 ld_tap = 0;
                 ld_g += 2;
             }
-            t_dh = P.dh[ld_tap];
-            t_dw = P.dw[ld_tap];
-            t_wi = P.widx[ld_tap];
         }
         ld_c0 = (ld_g + ld_sub) << 4;
     };
@@ -362,11 +366,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const bool second = c0 >= a.c1;
         const int ld = second ? a.ldx2 : a.ldx;
         const int cc = second ? c0 - a.c1 : c0;
-        const unsigned stepb = (unsigned)((t_dh * a.wi + t_dw) * ld + cc) * 4u;     // wave-uniform
+        const int t_off = __builtin_amdgcn_readlane(tapoff_v, ld_tap);
+        const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
+        const unsigned stepb = (unsigned)(t_off * ld + cc) * 4u;                     // wave-uniform
         const unsigned tbit = 1u << ld_tap;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const unsigned off = (okm[j] & tbit) ? (second ? rowb2[j] : rowb1[j]) + stepb : 0xffffffffu;
+            unsigned off = (okm[j] & tbit) ? (second ? rowb2[j] : rowb1[j]) + stepb : 0xffffffffu;
+#ifdef SHM_ABL_FIXADDR
+            off = rowb1[j];                       // timing only: constant address, no per-step work
+#endif
+#ifdef SHM_ABL_SAMELINE
+            off = (okm[j] & tbit) ? (unsigned)(dq * 16 + (off & 0x40u)) : 0xffffffffu;      // timing only
+#endif
             if (second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(sa + j * 256), 16, (int)off, 0, 0, 0);
             else
@@ -375,10 +387,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * 4u;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
+            unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
+#if defined(SHM_ABL_FIXADDR) || defined(SHM_ABL_SAMELINE)
+            off = wrow[j] == 0xffffffffu ? 0xffffffffu : (unsigned)(dq * 16);
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * 256), 16, (int)off, 0, 0, 0);
         }
+#ifndef SHM_ABL_FIXADDR
         advance();
+#endif
     };
 
     f32x16 acc[TM][TN];
@@ -426,7 +443,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // all waves: stage s landed, compute(s-1) finished
         asm volatile("" ::: "memory");
+#ifndef SHM_ABL_NODMA
         if (s + AHEAD < ksteps) dma(nxt);      // overwrites the buffer compute(s-1) was reading
+#endif
         compute(cur);
         asm volatile("" ::: "memory");
         cur = (cur == NST - 1) ? 0 : cur + 1;
@@ -520,18 +539,15 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
     static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
     if (use_dma) {
+        auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
         if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
-            dim3 grid(shm_cdiv(a.M, 256), shm_cdiv(a.nout, 128), nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3>), grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3>), grid1d(256, 128), dim3(512), 0, st, a);
         } else if (a.nout > 64) {
-            dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3>), grid1d(128, 128), dim3(256), 0, st, a);
         } else if (dma_small == 0) {
-            dim3 grid(shm_cdiv(a.M, 256), 1, nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2>), grid1d(256, 64), dim3(256), 0, st, a);
         } else {
-            dim3 grid(shm_cdiv(a.M, 128), 1, nphase);
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3>), grid1d(128, 64), dim3(256), 0, st, a);
         }
         SHM_LAUNCH_CHECK(who);
         return SHM_OK;

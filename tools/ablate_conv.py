@@ -4,7 +4,7 @@ from pathlib import Path
 import torch
 ROOT = Path(__file__).resolve().parent.parent
 src = ROOT / "shmgan_amd" / "csrc"
-variants = {"base": [], "pin": ["-DSHM_SCHED_PIN"], "sameline": ["-DSHM_ABL_SAMELINE"], "noaddr": ["-DSHM_ABL_NOADDR"], "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"], "nostore": ["-DSHM_ABL_NOSTORE"]
+variants = {"base": [], "nodma": ["-DSHM_ABL_NODMA"], "fixaddr": ["-DSHM_ABL_FIXADDR"], "pin": ["-DSHM_SCHED_PIN"], "sameline": ["-DSHM_ABL_SAMELINE"], "noaddr": ["-DSHM_ABL_NOADDR"], "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"], "nostore": ["-DSHM_ABL_NOSTORE"]
             }
 import os
 if os.environ.get("ABL_ONLY"): variants = {k: v for k, v in variants.items() if k in os.environ["ABL_ONLY"].split(",")}
