@@ -444,25 +444,63 @@ class Discriminator(_ModelBase):
     def zero_grad(self):
         ops.zero(self.P.grad)
 
-    def forward(self, xd16, keep_mask=None, mask_rows=()):
+    def forward(self, xd16, keep_mask=None, mask_rows=(), parts=None):
         """xd16 [N,S,S,16] (rgb + zeros).  keep_mask [len(mask_rows)...] is the Dropout keep mask of
-        the `training=True` samples: mask_rows = list of (row_start, nrows, mask_row_start)."""
+        the `training=True` samples: mask_rows = list of (row_start, nrows, mask_row_start).
+        parts: optional list of (row0, row1, run) -- the conv trunk is evaluated per row range (samples
+        are independent: InstanceNorm) through `run(fn)`; the trainer uses it to push the real-image
+        half onto the second stream while the generator is still producing the fake half."""
+        n = xd16.shape[0]
+        self.start(xd16, keep_mask, mask_rows)
+        if parts is None:
+            parts = [(0, n, lambda fn: fn())]
+        for r0, r1, run in parts:
+            run(lambda r0=r0, r1=r1: self.trunk_rows(r0, r1))
+        return self.heads()
+
+    def start(self, xd16, keep_mask=None, mask_rows=()):
+        """Declare the batch of the next forward (buffers only); follow with trunk_rows(...) over
+        every row and heads()."""
         n, S = xd16.shape[0], self.S
         self.prepare_weights()
         A = self.arena
-        cur, ld, h = xd16, PAD_C, S
-        recs = []
+        bufs = []
+        h = S
+        for i in range(5):
+            cout = self.chan[i + 1]
+            ho = h // 2
+            bufs.append((A.get(f"d/a{i}/{n}", (n, ho, ho, cout)), A.get(f"d/h{i}/{n}", (n, ho, ho, cout)),
+                         A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)))
+            h = ho
+        self._pending = dict(n=n, xd16=xd16, bufs=bufs, keep_mask=keep_mask, mask_rows=mask_rows)
+
+    def trunk_rows(self, r0, r1):
+        """The five Conv(3x3, s2) -> LeakyReLU -> InstanceNorm blocks on samples [r0, r1)."""
+        xd16, bufs = self._pending["xd16"], self._pending["bufs"]
+        nb = r1 - r0
+        cur, ld, h = xd16[r0:r1], PAD_C, self.S
         for i in range(5):
             cin, cout = self.chan[i], self.chan[i + 1]
             ho = h // 2
-            a = A.get(f"d/a{i}/{n}", (n, ho, ho, cout))
-            ahat = A.get(f"d/h{i}/{n}", (n, ho, ho, cout))
-            stats = A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)
-            ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a, cout, n, h, h, _pad16(cin), cout, 3, 2, LRELU,
-                              stats, IN_EPS, cin_real=cin)
-            ops.in_apply(a, cout, stats, self.betas[i], ahat, cout, n, ho * ho, cout)
+            a, ahat, stats = bufs[i]
+            st = stats[r0 * cout * 2:r1 * cout * 2]
+            ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a[r0:r1], cout, nb, h, h, _pad16(cin), cout, 3, 2,
+                              LRELU, st, IN_EPS, cin_real=cin)
+            ops.in_apply(a[r0:r1], cout, st, self.betas[i], ahat[r0:r1], cout, nb, ho * ho, cout)
+            cur, ld, h = ahat[r0:r1], cout, ho
+
+    def heads(self):
+        """Dropout (training=True rows), PatchGAN logits and the Dense(5) classifier on the whole batch."""
+        pd = self._pending
+        n, xd16, bufs = pd["n"], pd["xd16"], pd["bufs"]
+        keep_mask, mask_rows = pd["keep_mask"], pd["mask_rows"]
+        A = self.arena
+        recs = []
+        cur, ld, h = xd16, PAD_C, self.S
+        for i in range(5):
+            a, ahat, stats = bufs[i]
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
-            cur, ld, h = ahat, cout, ho
+            cur, ld, h = ahat, self.chan[i + 1], h // 2
         c5 = self.chan[5]
         per = h * h * c5
         scale = 1.0 / (1.0 - self.dropout)
