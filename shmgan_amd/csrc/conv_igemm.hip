@@ -280,16 +280,21 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
 // the descriptor's range check makes the DMA write zeros (tools/ldsdma_probe.hip).
 // Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
 // counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, int BK>
 __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGemmArgs a) {
+    static_assert(BK == 16 || BK == 32, "K step of 16 (64-byte LDS rows) or 32 (128-byte rows)");
     constexpr int NW = WGM * WGN;                    // waves per block (4 or 8)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int NA = BM / (16 * NW), NB = BN / (16 * NW);   // DMA instructions per wave and stage
-    static_assert(NA >= 1 && NB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "16 rows per DMA instruction");
+    constexpr int RPI = 256 / BK;                    // rows per DMA instruction (1 KiB)
+    constexpr int CPR = BK / 4;                      // 16-byte chunks per row
+    constexpr int SWS = BK == 16 ? 2 : 1, SWM = CPR - 1;      // swizzle: chunk ^= (row >> SWS) & SWM
+    constexpr int NKK = BK / 8;                      // 8-wide k groups per step
+    constexpr int NA = BM / (RPI * NW), NB = BN / (RPI * NW);   // DMA instructions per wave and stage
+    static_assert(NA >= 1 && NB >= 1 && BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "whole DMA instructions per wave");
     constexpr int NLD = NA + NB;
-    constexpr int STAGE = (BM + BN) * 16;            // floats
-    static_assert(NST == 2 || NST == 3, "2 stages: DMA one step ahead; 3 stages: two steps ahead");
+    constexpr int STAGE = (BM + BN) * BK;            // floats
+    static_assert(NST >= 2 && NST <= 4, "NST stages: DMA NST-1 steps ahead");
     __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
 
     const TapPhase& P = a.ph[blockIdx.z];
@@ -302,13 +307,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // DMA lane mapping: instruction j of this wave covers rows wave*(BM/4)+16j .. +15
-    const int drow = lane >> 2, dq = lane & 3;
+    const int drow = lane / CPR, dq = lane % CPR;
     // Per row: byte offset of the centre pixel in each source, and a bitmask of the taps that fall
     // inside the image (bit t of okm) -- the per-step address work is one add and one select.
     unsigned rowb1[NA], rowb2[NA], okm[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int row = wave * (BM / NW) + 16 * j + drow;
+        const int row = wave * (BM / NW) + RPI * j + drow;
         const int m = m0 + row;
         const bool mv = m < a.M;
         const int mm = mv ? m : 0;
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const int oh = t % a.hg, n = t / a.hg;
         const int ih0 = oh * a.is, iw0 = ow * a.is;
         const int pixbase = (n * a.hi + ih0) * a.wi + iw0;
-        const int acoff = (dq ^ ((row >> 2) & 3)) * 4;       // swizzled channel offset inside the 16-chunk
+        const int acoff = (dq ^ ((row >> SWS) & SWM)) * 4;   // swizzled channel offset inside the K step
         rowb1[j] = (unsigned)(pixbase * a.ldx + acoff) * 4u;
         rowb2[j] = (unsigned)(pixbase * a.ldx2 + acoff) * 4u;
         unsigned mk = 0;
@@ -329,16 +334,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     unsigned wrow[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int row = wave * (BN / NW) + 16 * j + drow;
+        const int row = wave * (BN / NW) + RPI * j + drow;
         const int nn = n0 + row;
-        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * 4) * 4u : 0xffffffffu;
+        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> SWS) & SWM)) * 4) * 4u : 0xffffffffu;
     }
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
 
     const int ntaps = P.ntaps;
-    const int nch = a.K >> 4;
+    const int nch = a.K / BK;
     const int ksteps = ntaps * nch;
     // The tap table lives in two VGPRs (lane t holds tap t) and is read with v_readlane: a scalar
     // memory load inside the K loop would share lgkmcnt with the ds_reads and force every fragment
@@ -348,6 +353,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     const int tapw_v = P.widx[tl];                        // its weight slice
     int ld_g = 0, ld_tap = 0, ld_sub = 0, ld_c0 = 0;
     auto advance = [&]() {
+        if (BK == 32) {                          // (chunk, tap): a step already covers a whole 128-B line
+            if (++ld_tap == ntaps) {
+                ld_tap = 0;
+                ld_c0 += 32;
+            }
+            return;
+        }
         const int nsub = (nch - ld_g) >= 2 ? 2 : 1;
         if (++ld_sub == nsub) {
             ld_sub = 0;
@@ -360,8 +372,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto dma = [&](int stage) {
-        float* sa = smem + stage * STAGE + wave * (BM / NW) * 16;
-        float* sb = smem + stage * STAGE + BM * 16 + wave * (BN / NW) * 16;
+        float* sa = smem + stage * STAGE + wave * (BM / NW) * BK;
+        float* sb = smem + stage * STAGE + BM * BK + wave * (BN / NW) * BK;
         const int c0 = ld_c0;
         const bool second = c0 >= a.c1;
         const int ld = second ? a.ldx2 : a.ldx;
@@ -406,21 +418,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment reads: row = tile row (l31 + 32*i), logical chunk 2*kk+h, physical chunk ^ ((row>>2)&3)
-    const int sw = (l31 >> 2) & 3;
-    const int fo0 = l31 * 16 + ((0 + h) ^ sw) * 4;       // floats, kk = 0
-    const int fo1 = l31 * 16 + ((2 + h) ^ sw) * 4;       // kk = 1
-    auto compute = [&](int stage) {
-        const float* Ab = smem + stage * STAGE + wm * WTM * 16;
-        const float* Bb = smem + stage * STAGE + BM * 16 + wn * WTN * 16;
+    // fragment reads: row = tile row (l31 + 32*i), logical chunk 2*kk+h, physical chunk ^ swizzle(row)
+    const int sw = (l31 >> SWS) & SWM;
+    int fo[NKK];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int fo = kk ? fo1 : fo0;
+    for (int kk = 0; kk < NKK; ++kk) fo[kk] = l31 * BK + ((2 * kk + h) ^ sw) * 4;       // floats
+    auto compute = [&](int stage) {
+        const float* Ab = smem + stage * STAGE + wm * WTM * BK;
+        const float* Bb = smem + stage * STAGE + BM * BK + wn * WTN * BK;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
             f32x4 av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 512 + fo);
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 32 * BK + fo[kk]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + fo);
+            for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 32 * BK + fo[kk]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -432,12 +444,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     };
 
     constexpr int AHEAD = NST - 1;                  // stages in flight beyond the one being computed
-    dma(0);
-    if (AHEAD > 1 && ksteps > 1) dma(1);
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+        if (t < ksteps) dma(t);
     int cur = 0, nxt = AHEAD % NST;
     for (int s = 0; s < ksteps; ++s) {
-        // stage s must have landed: everything but the DMAs of the stages issued after it
-        if (AHEAD > 1 && s + 1 < ksteps)
+        // stage s must have landed: everything but the DMAs of the (up to AHEAD-1) stages issued after it
+        const int younger = min(AHEAD - 1, ksteps - 1 - s);
+        if (younger >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        else if (younger == 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -540,14 +556,20 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
     if (use_dma) {
         auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
-        if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3>), grid1d(256, 128), dim3(512), 0, st, a);
+        static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
+        if (a.nout > 64 && bk32 && a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0)) {
+            if (bk32 == 2)
+                hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
+        } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
         } else if (a.nout > 64) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3>), grid1d(128, 128), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
         } else if (dma_small == 0) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2>), grid1d(256, 64), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2, 16>), grid1d(256, 64), dim3(256), 0, st, a);
         } else {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3>), grid1d(128, 64), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
         }
         SHM_LAUNCH_CHECK(who);
         return SHM_OK;
