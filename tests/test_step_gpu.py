@@ -285,3 +285,60 @@ def test_inference_path_matches_oracle(tmp_path):
     a = host(a).copy()
     b, _ = m2.infer(rgb)
     assert np.array_equal(a, host(b))
+
+
+def test_three_steps_track_the_oracle():
+    """Three consecutive train_steps (clip + Adam applied, transposed weight copies refreshed):
+    named losses of every step and the final weights follow the float64 oracle."""
+    S, F, B = 64, 16, 1
+    m, (g, d, gb, db) = _mk(S, F, B)
+    gv = [t64(a).clone() for a in g]
+    dv = [t64(a).clone() for a in d]
+    sg = st.AdamState([torch.zeros_like(a) for a in gv], [torch.zeros_like(a) for a in gv])
+    sd = st.AdamState([torch.zeros_like(a) for a in dv], [torch.zeros_like(a) for a in dv])
+    sf = st.style_factor_intended(S)
+    for step in range(3):
+        inp = st.make_inputs(B, S, rank=step)
+        dr = st.make_draws(step, B, S, F)
+        m.train_step(*inp, draws=dr, style_factor=sf)
+        torch.cuda.synchronize()
+        masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
+        ref = st.train_step(gv, dv, gb, db, inp, dr, sf, F, masks=masks)
+        got = m.losses()
+        for k, v in ref["losses"].items():
+            assert abs(got[k] - v) <= 2e-4 * max(1.0, abs(v)), (step, k, got[k], v)
+        st.adam_apply(dv, ref["gD"], sd, 2e-5, 0.5, 0.99)
+        st.adam_apply(gv, ref["gG"], sg, 2e-5, 0.5, 0.99)
+    assert m.G.P.iterations == 3 and m.D.P.iterations == 3
+    # Adam's first steps move every weight by ~lr*sign(g): an element whose gradient is at the fp32
+    # noise floor can legitimately step the other way, so compare the update as a whole (rel-L2 of
+    # w - w0) and bound the fraction of elements that disagree by more than 10 % of their movement
+    for i, (got_w, r, w0) in enumerate(zip(m.G.P.vars + m.D.P.vars, gv + dv, g + d)):
+        mv_ref = r.numpy() - w0
+        mv_got = host(got_w) - w0.astype(np.float64)
+        if np.abs(mv_ref).max() == 0:
+            continue
+        assert rel_l2(mv_got, mv_ref) < 0.05, (i, rel_l2(mv_got, mv_ref))
+        bad = np.abs(mv_got - mv_ref) > 0.1 * np.abs(mv_ref).max()
+        assert bad.mean() < 2e-3, (i, bad.mean())
+
+
+def test_long_run_stays_finite():
+    """40 optimizer steps at a mid size: no NaN/Inf in losses, weights or Adam state."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 128, 32, 2
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+    inp = st.make_inputs(B, S)
+    first = None
+    for step in range(40):
+        m.train_step(*inp, draws=st.make_draws(step, B, S, F))
+        if step in (0, 39):
+            torch.cuda.synchronize()
+            L = m.losses()
+            assert all(np.isfinite(v) for k, v in L.items() if k != "ssim"), L
+            first = first or L
+    for P in (m.G.P, m.D.P):
+        for t in (P.flat, P.m, P.v):
+            assert bool(torch.isfinite(t).all())
+    # the same batch 40 times: the L1 reconstruction term must have gone down
+    assert L["L1_loss_Gen"] < first["L1_loss_Gen"]
