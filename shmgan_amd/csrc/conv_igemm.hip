@@ -525,6 +525,213 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride-1 tap GEMM with an LDS halo for the A operand (forward conv and its dgrad).
+//
+// Block = 16 x 16 output pixels of one image (M = 256) x 128 output channels, 8 waves of 64x64.
+// Per 16-channel chunk the 18 x 18 input halo is DMA'd into LDS ONCE (double buffered, fetched
+// while the previous chunk's nine taps are computed); the nine taps read it through nine shifted
+// fragment addresses.  Only the weight slice (128 rows x 64 B) is streamed per tap (3 stages, DMA
+// two taps ahead).  Per tap a wave issues 1 DMA instruction instead of 4, and the A operand moves
+// 6.4x fewer bytes.  Same LDS row format as tapgemm_dma_kernel: 64-byte rows, chunk ^= (row>>2)&3
+// applied on the DMA source side; halo pixels outside the image use offset 0xffffffff (zeros).
+__global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) {
+    constexpr int BN = 128, WGN = 2;                  // 8 waves: 4 (M) x 2 (N)
+    constexpr int HC = 18, NHR = 384;                 // halo 18 x 18 = 324 rows, padded to 24 DMA items
+    constexpr int ASTG = NHR * 16, BSTG = BN * 16;    // floats per stage
+    constexpr int NA = 3, NB = 1;                     // DMA instructions per wave: A per chunk, B per tap
+    __shared__ __attribute__((aligned(1024))) float smem[2 * ASTG + 3 * BSTG];
+    float* const sA = smem;
+    float* const sB = smem + 2 * ASTG;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const TapPhase& P = a.ph[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    // block -> (image, patch)
+    const int ppr = a.wi >> 4, ppi = (a.hi >> 4) * ppr;
+    const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
+    const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+8, w+16
+    const int drow = lane >> 2, dq = lane & 3;
+    unsigned arow1[NA], arow2[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int hrow = 16 * (wave + 8 * j) + drow;
+        const int hr = hrow / HC, hc = hrow - hr * HC;
+        const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const int pix = (img * a.hi + iy) * a.wi + ix;
+        const int coff = (dq ^ ((hrow >> 2) & 3)) * 4;
+        arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * 4u : 0xffffffffu;
+        arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * 4u : 0xffffffffu;
+    }
+    unsigned wrow;
+    {
+        const int row = wave * 16 + drow;                  // B rows [16 wave, 16 wave + 16)
+        const int nn = n0 + row;
+        wrow = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * 4) * 4u : 0xffffffffu;
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+
+    const int nch = a.K >> 4;
+    const int ksteps = 9 * nch;
+    // tap table in VGPR lanes: halo row shift (dh*18 + dw) and weight slice of tap `lane`
+    const int tl = lane < 9 ? lane : 0;
+    const int tapsh_v = P.dh[tl] * HC + P.dw[tl];
+    const int tapw_v = P.widx[tl];
+
+    auto dma_a = [&](int chunk) {                  // halo of 16-channel chunk `chunk` into A stage chunk & 1
+        const int c0 = chunk << 4;
+        const bool second = c0 >= a.c1;
+        const unsigned cb = (unsigned)(second ? c0 - a.c1 : c0) * 4u;
+        float* dst = sA + (chunk & 1) * ASTG + wave * 256;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const unsigned r = second ? arow2[j] : arow1[j];
+            const unsigned off = r == 0xffffffffu ? r : r + cb;
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + j * 8 * 256), 16, (int)off, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + j * 8 * 256), 16, (int)off, 0, 0, 0);
+        }
+    };
+    int ld_tap = 0, ld_chunk = 0, ld_stage = 0;    // position of the next weight DMA
+    auto dma_b = [&]() {
+        const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (ld_chunk << 4)) * 4u;
+        const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sB + ld_stage * BSTG + wave * 256), 16, (int)off, 0, 0, 0);
+        if (++ld_tap == 9) {
+            ld_tap = 0;
+            ++ld_chunk;
+        }
+        ld_stage = ld_stage == 2 ? 0 : ld_stage + 1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing.  A: lane -> patch pixel (4 wm + 2 i + (l31 >> 4), l31 & 15), halo row of the
+    // centre tap; B: as in tapgemm_dma_kernel
+    int hb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hb[i] = (4 * wm + 2 * i + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
+    const int swb = (l31 >> 2) & 3;
+    const int fb0 = l31 * 16 + ((0 + h) ^ swb) * 4, fb1 = l31 * 16 + ((2 + h) ^ swb) * 4;
+
+    auto compute = [&](int chunk, int tap, int bstage) {
+        const float* Ab = sA + (chunk & 1) * ASTG;
+        const float* Bb = sB + bstage * BSTG + wn * 64 * 16;
+        const int sh = __builtin_amdgcn_readlane(tapsh_v, tap);
+        int fa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hrow = hb[i] + sh;
+            const int sw = (hrow >> 2) & 3;
+            fa[i][0] = hrow * 16 + ((0 + h) ^ sw) * 4;
+            fa[i][1] = hrow * 16 + ((2 + h) ^ sw) * 4;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(Ab + fa[i][kk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline.  DMA issue order per wave: A(0); B(0); B(1); then at step s: [A(chunk+1) if tap == 0]; B(s+2).
+    dma_a(0);
+    dma_b();
+    if (ksteps > 1) dma_b();
+    int tap = 0, chunk = 0, bst = 0;
+    for (int s = 0; s < ksteps; ++s) {
+        // B(s) (and, in order before it, the halo of this chunk) must have landed.  Issued after B(s):
+        // B(s+1), preceded by the A items of step s-1 if that step opened a chunk.
+        if (s + 1 < ksteps) {
+            if (tap == 1 && chunk + 1 < nch)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
+        if (s + 2 < ksteps) dma_b();
+        compute(chunk, tap, bst);
+        asm volatile("" ::: "memory");
+        bst = bst == 2 ? 0 : bst + 1;
+        if (++tap == 9) {
+            tap = 0;
+            ++chunk;
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU + store (+ InstanceNorm statistics)
+    float s1[2], s2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
+            const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (n < a.nout) {
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    v = shm_lrelu(v, a.slope);
+                    s1[j] += v;
+                    s2[j] += v * v;
+                    if (n < a.n1)
+                        a.y[opix * a.ldy + n] = v;
+                    else
+                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
+                }
+            }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+            float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (h == 0 && n < a.nout) {
+                double* dst = a.stats + ((size_t)img * a.nout + n) * 2;
+                atomicAdd(dst, (double)t1);
+                atomicAdd(dst + 1, (double)t2);
+            }
+        }
+    }
+}
+
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0;
 
@@ -554,6 +761,22 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
     static const int use_dma = getenv("SHM_TAPGEMM_REG") ? 0 : 1;
     static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
     static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
+    static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
+    if (use_dma && use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && a.nout > 64 &&
+        a.hi % 16 == 0 && a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi) {
+        bool unit = true;                      // every tap within the 1-pixel halo
+        for (int t = 0; t < 9; ++t) unit = unit && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
+        // 2 blocks of 8 waves per CU = 512 slots: below ~4 rounds the coarser (256-row) tiles lose more to
+        // grid quantization than the halo reuse gains (measured: 32x32 maps 113 vs 133 TFLOP/s)
+        static const int halo_min = getenv("SHM_TAPGEMM_HALO_MIN") ? atoi(getenv("SHM_TAPGEMM_HALO_MIN")) : 1024;
+        const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
+        if (unit && nblk >= halo_min) {
+            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
+            hipLaunchKernelGGL(tapgemm_halo_kernel, grid, dim3(512), 0, st, a);
+            SHM_LAUNCH_CHECK(who);
+            return SHM_OK;
+        }
+    }
     if (use_dma) {
         auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
         static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
