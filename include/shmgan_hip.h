@@ -187,6 +187,33 @@ int shm_image_losses(const float* gen_rgb, const float* cyc_rgb, const float* cy
                      int flags_mask, float style_factor, double* loss, float* dgen_y, float* dcyc_y,
                      void* ws, size_t ws_bytes, int batch, int s, void* stream);
 
+/* ---- SpecSeg mask network, inference only (SpecSeg.py:27-98; SpecSeg.predict at SHM.py:492) --
+ * Its Conv2D(3x3, relu) layers are shm_conv2d_fwd with slope 0.  The rest: */
+/* dst[p, 0:nc] = src[p, c0:c0+nc], dst[p, nc:lddst] = 0 (the Y plane into a 16-float pitch). */
+int shm_pack_channels(const float* src, int ldsrc, int c0, int nc, float* dst, int lddst, size_t npix,
+                      void* stream);
+/* Keras BatchNormalization(axis=-1) in inference mode (SpecSeg.py:37,43,49,55,60):
+ * out = (a - moving_mean) * gamma / sqrt(moving_var + eps) + beta. */
+int shm_bn_apply(const float* a, int lda, const float* gamma, const float* beta, const float* mean,
+                 const float* var, float eps, float* out, int ldo, size_t npix, int c, void* stream);
+/* MaxPooling2D((2,2)) on even sizes (SpecSeg.py:38,44,50,56). */
+int shm_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int h, int w, int c,
+                     void* stream);
+/* Conv2DTranspose(k=2, strides=2, 'same') + bias (SpecSeg.py:63,69,75,81).  w = Keras layout
+ * [2][2][cout][cin] as stored; y [batch,2hi,2wi,cout]; slope 1.0f = linear. */
+int shm_conv2d_transpose2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                                int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
+                                void* stream);
+/* Conv2D(1, (1,1), activation='sigmoid') (SpecSeg.py:88). */
+int shm_head_sigmoid_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                         size_t npix, int c, void* stream);
+/* Spec_loss terms (SHM.py:792-796, logged only): loss[k] (f64 [5], zeroed by the call) = sum over
+ * samples, pixels and the 3 yuv channels of (mask * cyc_k_yuv - mask * ds_k)^2, where
+ * cyc_k_yuv = concat(cyc_y[k*batch + b], cbcr[b]); mask [batch,S,S,1].  ds = host array of 5
+ * device pointers.  reduce_mean = loss / (batch*npix*3). */
+int shm_spec_loss(const float* cyc_y, const float* cbcr, const float* const* ds, const float* mask,
+                  double* loss, int batch, size_t npix, void* stream);
+
 /* ---- optimizer (SHM.py:169-175, 859-872) ------------------------------------------
  * tf.clip_by_value(g,-1,1) + Keras adam_v2.Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
  * w -= alpha * m / (sqrt(v) + eps); alpha = lr_t*sqrt(1-b2^t)/(1-b1^t) computed by the caller.

@@ -352,13 +352,15 @@ def _mslice(masks, lo, hi):
 
 
 def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_factor,
-               filter_size=64, dtype=torch.float64, need_grads=True, masks=None):
+               filter_size=64, dtype=torch.float64, need_grads=True, masks=None, specseg=None):
     """One SHM.py:467-875 forward + both tape.gradient calls (no optimizer apply).
 
     gvars/dvars/gbetas/dbetas: lists of numpy arrays or tensors (TF layouts).
     inputs: 5 x [B,S,S,3] in [0,1].  Returns dict(losses=..., gG=[...], gD=[...], outs=...).
     masks: optional {"g1": [23 x [B,...]], "cyc": [23 x [5B,...]], "d": [6 x [12B,...]]} LeakyReLU
     sign patterns taken from the device run (see _act); D batch order [D1][D3 x5][D2][D4 x5].
+    specseg: optional SpecSeg weights (oracle.specseg_torch layout): adds the mask of SHM.py:492 to
+    outs["specular_candidate"] and the logged-only losses["Spec_loss"] (SHM.py:792-806).
     """
     mk = masks or {}
     T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype)
@@ -453,11 +455,17 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
         "L1_loss_Gen": L1_loss, "ssim_cyc_loss": ssim_loss, "content_loss": content,
         "style_loss": style, "total_NST_loss": nst,
     }
+    spec_mask = None
+    if specseg is not None:
+        from .specseg_torch import spec_loss, specseg_forward
+        spec_mask = specseg_forward(specseg, Ych[2], dtype)                      # predict(I90_Ych)  SHM.py:492
+        losses["Spec_loss"] = spec_loss([c.detach() for c in cyc_yuv], ds, spec_mask)[0]
     out = {"losses": {k: float(v.mean().detach()) for k, v in losses.items()},
            "outs": {"gen_Y": gen_Y.detach(), "gen_rgb": gen_rgb.detach(),
                     "cyc_rgb": [c.detach() for c in cyc_rgb],
                     "rf_D1": rf_D1.detach(), "cls_D1": cls_D1.detach(),
-                    "ssim": [s_.detach() for s_ in ssims], "scales": [s_.detach() for s_ in scales]}}
+                    "ssim": [s_.detach() for s_ in ssims], "scales": [s_.detach() for s_ in scales],
+                    "specular_candidate": spec_mask}}
     if need_grads:
         gD = torch.autograd.grad((total_D + total_C).mean(), dv, retain_graph=True)
         # intermediate generator-loss gradients (test diagnostics): wrt the 5 cyclic outputs and

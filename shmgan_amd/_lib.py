@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function"]
 
@@ -56,6 +56,12 @@ SIGNATURES = {
     "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, P]),
     "shm_image_losses_workspace": (Z, [I, I]),
     "shm_image_losses": (I, [P, P, P, P, P, P, I, F, P, P, P, P, Z, I, I, P]),
+    "shm_pack_channels": (I, [P, I, I, I, P, I, Z, P]),
+    "shm_bn_apply": (I, [P, I, P, P, P, P, F, P, I, Z, I, P]),
+    "shm_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, P]),
+    "shm_conv2d_transpose2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, P]),
+    "shm_head_sigmoid_fwd": (I, [P, I, P, P, P, Z, I, P]),
+    "shm_spec_loss": (I, [P, P, P, P, P, I, Z, P]),
     "shm_adam_clip": (I, [P, P, P, P, Z, F, F, F, F, F, P]),
 }
 

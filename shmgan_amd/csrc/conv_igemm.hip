@@ -1016,3 +1016,42 @@ extern "C" int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w,
     fill_s2_phases(a, pt, pl);
     return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_transpose_fwd");
 }
+
+// Keras Conv2DTranspose(k=2, strides=2) (SpecSeg.py:63,69,75,81): non-overlapping, every output
+// phase (ph, pw) is a 1x1 product with its own tap: y[2a+ph, 2b+pw] = bias + x[a, b] . w[ph][pw].
+extern "C" int shm_conv2d_transpose2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                                           int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
+                                           void* stream) {
+    SHM_REQUIRE(x && w && y, SHM_E_SHAPE, "shm_conv2d_transpose2x2_fwd: null pointer");
+    TapGemmArgs a{};
+    a.x = x;
+    a.x2 = nullptr;
+    a.c1 = cin;
+    a.ldx = ldx;
+    a.w = w;            // Keras [2][2][cout][cin] == [t][N=cout][K=cin]
+    a.bias = bias;
+    a.y = y;
+    a.y2 = nullptr;
+    a.n1 = cout;
+    a.ldy = ldy;
+    a.hi = hi;
+    a.wi = wi;
+    a.K = cin;
+    a.hg = hi;
+    a.wg = wi;
+    a.ho = 2 * hi;
+    a.wo = 2 * wi;
+    a.nout = cout;
+    a.is = 1;
+    a.os = 2;
+    a.slope = slope;
+    for (int p = 0; p < 4; ++p) {
+        TapPhase& P = a.ph[p];
+        P.oph = p >> 1;
+        P.opw = p & 1;
+        P.ntaps = 1;
+        P.dh[0] = P.dw[0] = 0;
+        P.widx[0] = p;
+    }
+    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_transpose2x2_fwd");
+}

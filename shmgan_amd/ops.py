@@ -240,3 +240,34 @@ def image_losses(gen_rgb, cyc_rgb, cyc_y, cbcr, orig_ptrs, ds_ptrs, flags_mask, 
 def adam_clip(w, m, v, g, n, alpha, beta1, beta2, eps, gscale):
     check(lib().shm_adam_clip(_p(w), _p(m), _p(v), _p(g), n, alpha, beta1, beta2, eps, gscale, _stream()),
           "shm_adam_clip")
+
+
+# ---- SpecSeg (inference only) ----------------------------------------------------------------
+def pack_channels(src, ldsrc, c0, nc, dst, lddst, npix):
+    check(lib().shm_pack_channels(_p(src), ldsrc, c0, nc, _p(dst), lddst, npix, _stream()), "shm_pack_channels")
+
+
+def bn_apply(a, lda, gamma, beta, mean, var, eps, out, ldo, npix, c):
+    check(lib().shm_bn_apply(_p(a), lda, _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(out), ldo, npix, c,
+                             _stream()), "shm_bn_apply")
+
+
+def maxpool2_fwd(x, ldx, y, ldy, batch, h, w, c):
+    check(lib().shm_maxpool2_fwd(_p(x), ldx, _p(y), ldy, batch, h, w, c, _stream()), "shm_maxpool2_fwd")
+
+
+def conv2d_transpose2x2_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope=1.0):
+    flops = 2.0 * batch * hi * wi * 4 * cin * cout
+    _timed(_tile(cout), flops, lambda: check(
+        lib().shm_conv2d_transpose2x2_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
+                                          slope, _stream()), "shm_conv2d_transpose2x2_fwd"),
+           f"convT2 n{batch} h{hi} {cin}->{cout}")
+
+
+def head_sigmoid_fwd(x, ldx, w, bias, y, npix, c):
+    check(lib().shm_head_sigmoid_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, _stream()), "shm_head_sigmoid_fwd")
+
+
+def spec_loss(cyc_y, cbcr, ds_ptrs, mask, loss, batch, npix):
+    check(lib().shm_spec_loss(_p(cyc_y), _p(cbcr), ds_ptrs, _p(mask), _p(loss), batch, npix, _stream()),
+          "shm_spec_loss")

@@ -27,6 +27,7 @@ import torch
 from . import ops
 from .dist import GradReducer, world_size
 from .model import PAD_C, Arena, Discriminator, Generator, WgradLane
+from .specseg import SpecSeg
 
 
 class _Optimizer:
@@ -55,7 +56,7 @@ _DEFAULTS = dict(image_size=128, batch_size=1, filter_size=64, g_lr=0.00002, d_l
 LOSS_NAMES = ["total_Generator_loss", "total_Discriminator_loss", "total_Classification_loss", "G_gan_loss",
               "G_clsf_loss", "D1_RealFake_loss", "D3_RealFake_cyc", "D2_RealFake_target", "D4_RealFake_cyc",
               "D1_classification_loss", "D3_classification_loss", "D4_classification_loss", "L1_loss_Gen",
-              "ssim_cyc_loss", "content_loss", "style_loss", "total_NST_loss"]
+              "ssim_cyc_loss", "content_loss", "style_loss", "total_NST_loss", "Spec_loss"]
 
 
 class ShmGANwithSSpecSeg:
@@ -86,8 +87,10 @@ class ShmGANwithSSpecSeg:
         self.arena = Arena(self.device)
         self._ws = None
         self._lane = None
-        self.G = self.D = None
-        self.specular_candidate = None          # constant zero in the executed graph (finding 3)
+        self.G = self.D = self.SpecSeg = None
+        # zeros at graph-build time (SHM.py:206; the attention convs only ever see this constant, finding 3);
+        # train_step overwrites it with SpecSeg.predict(I90_Ych) (SHM.py:492), which feeds Spec_loss only
+        self.specular_candidate = None
         self._rng = np.random.default_rng(self.seed)
         self._reducer = GradReducer(self.device)
         self._loss_cache = None
@@ -122,11 +125,19 @@ class ShmGANwithSSpecSeg:
         return Discriminator(self.image_size, self.filter_size, self.device, self.arena, self._workspace,
                              self.dropout_amnt, self._get_lane())
 
+    def build_specseg(self):
+        """SHM.py:930-931: SpecSeg(image_size, image_size, 1) then load_model('specsegv3_chkpt.h5').  The
+        checkpoint is not available, so the network starts from the initialisers of SpecSeg.py; load trained
+        Keras weights with `self.SpecSeg.set_weights(keras_model.get_weights())`."""
+        return SpecSeg(self.image_size, self.device, self.arena).init_random()
+
     def build(self, seed=42, beta_seed=43):
-        """Build G and D and give them the synthetic init of SURVEY 8(d): weights N(0,0.02) from
+        """Build G, D and SpecSeg and give G/D the synthetic init of SURVEY 8(d): weights N(0,0.02) from
         default_rng(seed) (RandomNormal(0,0.02), SHM.py:200), biases 0, IN beta N(0,0.02)."""
         self.G = self.build_generator()
         self.D = self.build_discriminator()
+        if self.SpecSeg is None:
+            self.SpecSeg = self.build_specseg()
         rng = np.random.default_rng(seed)
         gw = [np.zeros(s, np.float32) if len(s) == 1 else rng.normal(0.0, 0.02, s).astype(np.float32)
               for s in self.G.P.shapes]
@@ -220,6 +231,15 @@ class ShmGANwithSSpecSeg:
         cbcr = A.get("pre/cbcr", (B, S, S, 2))
         ops.avg_cbcr(ds, cbcr, B * npix)
 
+        # ---- specular mask: SpecSeg.predict(I90_Ych), outside the tape (SHM.py:492).  Nothing on the
+        # gradient path reads it, so it runs on the second stream beside the generator forward.
+        lane = self._get_lane()
+        if self.SpecSeg is None:
+            self.SpecSeg = self.build_specseg()
+        box = {}
+        lane.submit(lambda: box.__setitem__("mask", self.SpecSeg.forward_plane(ds[2], 3, 0, B, tag="specseg/step")))
+        self.specular_candidate = box["mask"]
+
         # ---- G(1)  SHM.py:517-538
         gen_in = A.get("g1/in", (B, S, S, PAD_C))
         ops.build_gen_input(ds, None, fmask, 0, gen_in, B, npix)
@@ -257,6 +277,8 @@ class ShmGANwithSSpecSeg:
         optr = (C.c_void_p * 5)(*[t.data_ptr() for t in orig])
         dptr = (C.c_void_p * 5)(*[t.data_ptr() for t in ds])
         ops.image_losses(gen_rgb, cyc_rgb, cyc_Y, cbcr, optr, dptr, fmask, sf, il, dgen_y, dcyc_y, ws, B, S)
+        sl = A.get("loss/spec", (5,), torch.float64)                      # Spec_loss, logged only  SHM.py:792-806
+        lane.submit(lambda: ops.spec_loss(cyc_Y, cbcr, dptr, self.specular_candidate, sl, B, npix))
 
         # ---- D backward (weights) then its all-reduce overlapped with everything below
         D.backward_params(drf_d, dcls_d)
@@ -300,7 +322,7 @@ class ShmGANwithSSpecSeg:
         self.RealFake_target_D2, self.label_target_D2 = rf[6 * B:7 * B], cls[6 * B:7 * B]
         self.gradmapD, self.gradmapG = D.P.grads, G.P.grads
         self.stddev_arr = scales          # reference appends forever (a leak); we keep the last step's
-        self._last = SimpleNamespace(dl=dl, il=il, B=B, flags=flags, T=T, scales=scales, ds=ds, cbcr=cbcr)
+        self._last = SimpleNamespace(dl=dl, il=il, sl=sl, npix=npix, B=B, flags=flags, T=T, scales=scales, ds=ds, cbcr=cbcr)
         self._loss_cache = None
         return None
 
@@ -319,6 +341,9 @@ class ShmGANwithSSpecSeg:
         npix = S * S
         G.prepare_weights()
         yuv, scale = self.preprocess(x, "inf")
+        if self.SpecSeg is None:
+            self.SpecSeg = self.build_specseg()
+        self.specular_candidate = self.SpecSeg.forward_plane(yuv, 3, 0, B, tag="specseg/inf")   # test.py:221
         cbcr = yuv[..., 1:].contiguous()                       # averageCbCr = the input's own CbCr (test.py:224)
         ys = [yuv] * 5
         gen_in = A.get("inf/in", (B, S, S, PAD_C))
@@ -384,6 +409,7 @@ class ShmGANwithSSpecSeg:
         ssim_loss = (i[11] + i[12] + i[13] + i[14] + i[15] * 10.0) / 5.0
         content, style = i[16], i[17]
         nst = 100.0 * style + content
+        sp = (L.sl.cpu().numpy() / (L.B * L.npix * 3.0)).tolist()       # reduce_mean over [B,S,S,3]
         out = {
             "total_Generator_loss": (D1_RF + D3_RF) / 6.0 + 10.0 * L1 + 10.0 * ssim_loss + 10.0 * nst,
             "total_Discriminator_loss": (D1_cls + D3_cls) / 6.0 + (D2_RF + D4_RF) / 6.0 + 0.5 * D4_cls + 10.0 * nst,
@@ -393,6 +419,7 @@ class ShmGANwithSSpecSeg:
             "D4_RealFake_cyc": D4_RF, "D1_classification_loss": D1_cls, "D3_classification_loss": D3_cls,
             "D4_classification_loss": D4_cls, "L1_loss_Gen": L1, "ssim_cyc_loss": ssim_loss,
             "content_loss": content, "style_loss": style, "total_NST_loss": nst,
+            "Spec_loss": (sp[0] + sp[1] + sp[2] + sp[3]) / 5.0 + sp[4] * 5.0,
             "ssim": [i[6 + k] for k in range(5)],
         }
         self._loss_cache = out

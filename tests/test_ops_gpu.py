@@ -377,3 +377,59 @@ def test_error_reporting():
         ops.conv2d_fwd(x, None, 0, 24, 0, x, None, x, 24, 1, 4, 4, 24, 16, 3, 1, 1.0)   # cin % 16 != 0
     with pytest.raises(ShmError):
         ops.conv2d_fwd(x, None, 0, 32, 0, x, None, x, 32, 1, 4, 4, 32, 16, 5, 1, 1.0)   # ksize 5
+
+
+# ------------------------------------------------------------------ SpecSeg building blocks
+@pytest.mark.parametrize("n,h,cin,cout", [(2, 8, 32, 16), (1, 16, 256, 128), (3, 4, 64, 32)])
+def test_conv2d_transpose2x2_fwd(n, h, cin, cout):
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((n, h, h, cin))
+    w = rng.standard_normal((2, 2, cout, cin)) * 0.1
+    b = rng.standard_normal(cout)
+    ref = F.conv_transpose2d(nchw(x), t64(w).permute(3, 2, 0, 1).contiguous(), stride=2)
+    ref = nhwc(ref) + b
+    y = torch.empty((n, 2 * h, 2 * h, cout), device="cuda")
+    ops.conv2d_transpose2x2_fwd(dev(x), cin, dev(w), dev(b), y, cout, n, h, h, cin, cout, 1.0)
+    assert rel_l2(host(y), ref) < TOL
+
+
+@pytest.mark.parametrize("n,h,cin,cout", [(2, 16, 16, 16), (1, 8, 48, 32)])
+def test_conv2d_relu_narrow(n, h, cin, cout):
+    """slope 0 == ReLU on 16/32-wide layers (SpecSeg.py:34-36)."""
+    ops = _ops()
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((n, h, h, cin))
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    ref = np.maximum(conv_ref(x, w, 1) + b, 0.0)
+    y = torch.empty((n, h, h, cout), device="cuda")
+    ops.conv2d_fwd(dev(x), None, 0, cin, 0, _wk(w, cin), dev(b), y, cout, n, h, h, cin, cout, 3, 1, 0.0)
+    assert rel_l2(host(y), ref) < TOL
+    assert (host(y) >= 0).all()
+
+
+def test_bn_apply_maxpool_pack_sigmoid():
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    n, h, c = 2, 8, 32
+    a = rng.standard_normal((n, h, h, c))
+    g, be, mu = rng.standard_normal(c), rng.standard_normal(c), rng.standard_normal(c)
+    var = rng.random(c) + 0.1
+    out = torch.empty((n, h, h, c), device="cuda")
+    ops.bn_apply(dev(a), c, dev(g), dev(be), dev(mu), dev(var), 1e-3, out, c, n * h * h, c)
+    ref = (a - mu) * g / np.sqrt(var + 1e-3) + be
+    assert rel_l2(host(out), ref) < TOL
+    p = torch.empty((n, h // 2, h // 2, c), device="cuda")
+    ops.maxpool2_fwd(out, c, p, c, n, h, h, c)
+    refp = host(out).reshape(n, h // 2, 2, h // 2, 2, c).max(axis=(2, 4))
+    assert np.array_equal(host(p), refp)
+    src = rng.standard_normal((n, h, h, 3))
+    d16 = torch.full((n, h, h, 16), 7.0, device="cuda")
+    ops.pack_channels(dev(src), 3, 1, 2, d16, 16, n * h * h)
+    assert np.array_equal(host(d16)[..., :2], dev(src).cpu().numpy()[..., 1:3]) and (host(d16)[..., 2:] == 0).all()
+    w, b = rng.standard_normal(c) * 0.3, rng.standard_normal(1)
+    y = torch.empty((n, h, h, 1), device="cuda")
+    ops.head_sigmoid_fwd(out, c, dev(w), dev(b), y, n * h * h, c)
+    refy = 1.0 / (1.0 + np.exp(-(host(out) @ w + b)))
+    assert np.abs(host(y)[..., 0] - refy).max() < 1e-6

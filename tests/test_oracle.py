@@ -205,10 +205,53 @@ def test_golden_step_fixture(name):
     gold = np.load(GOLD / name)
     S, F, B, step = [int(v) for v in gold["meta"]]
     g, d, gb, db = st.init_params(F, S)
-    r = st.train_step(g, d, gb, db, st.make_inputs(B, S), st.make_draws(step, B, S, F), st.style_factor_intended(S), F)
+    from oracle import specseg_torch as sp
+    r = st.train_step(g, d, gb, db, st.make_inputs(B, S), st.make_draws(step, B, S, F), st.style_factor_intended(S), F,
+                      specseg=sp.init_specseg(seed=44 + step))
+    assert "Spec_loss" in r["losses"]
+    assert np.abs(r["outs"]["specular_candidate"].numpy() - gold["specular_candidate"]).max() < 1e-6
     for k, v in r["losses"].items():
         assert abs(v - float(gold[f"loss/{k}"])) <= 1e-9 * max(1.0, abs(v)), k
     assert np.abs(r["outs"]["gen_Y"].numpy() - gold["gen_Y"]).max() < 1e-6
     for nm, gr in (("gG", r["gG"]), ("gD", r["gD"])):
         n = np.array([float(t.norm()) for t in gr])
         assert np.abs(n - gold[f"{nm}/norm"]).max() <= 1e-8 * max(1.0, n.max())
+
+
+# ------------------------------------------------------------------ SpecSeg restatement (S1, L5)
+def test_specseg_param_count_known_answer():
+    """/root/reference/SpecSeg_summary.txt:118-120: 1,942,801 params, 992 non-trainable; per-layer
+    counts from the same file."""
+    from oracle import specseg_torch as sp
+    spec = sp.specseg_spec()
+    n = sum(int(np.prod(s)) for _, s in spec)
+    nt = sum(int(np.prod(s)) for k, s in spec if k in ("bn_mean", "bn_var"))
+    assert (n, nt) == (1942801, 992)
+    # conv2d 160, conv2d_1 2320, conv2d_9 590080, conv2d_transpose 131200, conv2d_10 295040, conv2d_18 17
+    pair = lambda i: int(np.prod(spec[i][1])) + int(np.prod(spec[i + 1][1]))
+    assert pair(0) == 160 and pair(2) == 2320 and pair(34) == 590080
+    assert pair(40) == 131200 and pair(42) == 295040 and pair(64) == 17
+    from shmgan_amd.specseg import specseg_variables
+    assert [tuple(s) for _, _, s in specseg_variables()] == [tuple(s) for _, s in spec]
+
+
+def test_specseg_oracle_forward_properties():
+    from oracle import specseg_torch as sp
+    import torch
+    w = sp.init_specseg(seed=1)
+    x = np.random.default_rng(0).standard_normal((2, 32, 32, 1))
+    m = sp.specseg_forward(w, x)
+    assert m.shape == (2, 32, 32, 1) and float(m.min()) > 0 and float(m.max()) < 1
+    # samples are independent in inference mode
+    m0 = sp.specseg_forward(w, x[:1])
+    assert np.allclose(m[:1].numpy(), m0.numpy(), atol=1e-12)
+    # float32 evaluation of the same restatement agrees
+    m32 = sp.specseg_forward(w, x, dtype=torch.float32)
+    assert np.abs(m32.numpy() - m.numpy()).max() < 1e-5
+
+
+def test_specseg_golden_fixture():
+    from oracle import specseg_torch as sp
+    gold = np.load(GOLD / "specseg_S32.npz")
+    m = sp.specseg_forward(sp.init_specseg(seed=3), gold["x"])
+    assert np.abs(m.numpy() - gold["mask"]).max() < 1e-12

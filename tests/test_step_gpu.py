@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import specseg_torch as sp
 from oracle import step_torch as st
 from util import cosine, dev, host, rel_l2, t64
 
@@ -165,6 +166,8 @@ def test_train_step_parity(S, F, B, step):
     inp = st.make_inputs(B, S)
     dr = st.make_draws(step, B, S, F)
     sf = st.style_factor_intended(S)
+    sw = sp.init_specseg(seed=44 + step)
+    m.SpecSeg.set_weights(sw)
     m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
     torch.cuda.synchronize()
     # The oracle evaluates every LeakyReLU on the side of the kink the device took (see
@@ -173,7 +176,8 @@ def test_train_step_parity(S, F, B, step):
     # rel-L2 (DESIGN.md "parity").  Values are unaffected (<= 1e-6).
     masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
     ref = st.train_step(g, d, gb, db, inp, dr, sf, F, masks=masks)
-    free = st.train_step(g, d, gb, db, inp, dr, sf, F, need_grads=False)      # un-pinned oracle: values
+    free = st.train_step(g, d, gb, db, inp, dr, sf, F, need_grads=False, specseg=sw)   # un-pinned oracle: values
+    assert np.abs(host(m.specular_candidate) - free["outs"]["specular_candidate"].numpy()).max() < 1e-5
     got = m.losses()
     for k, v in free["losses"].items():
         assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
@@ -241,9 +245,11 @@ def test_golden_fixture_on_device(name):
     gold = np.load(Path(__file__).resolve().parent / "golden" / name)
     S, F, B, step = [int(v) for v in gold["meta"]]
     m, _ = _mk(S, F, B)
+    m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
     m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
     torch.cuda.synchronize()
     got = m.losses()
+    assert np.abs(host(m.specular_candidate) - gold["specular_candidate"]).max() < 1e-5
     for k in got:
         if k != "ssim":
             v = float(gold[f"loss/{k}"])
@@ -342,3 +348,62 @@ def test_long_run_stays_finite():
             assert bool(torch.isfinite(t).all())
     # the same batch 40 times: the L1 reconstruction term must have gone down
     assert L["L1_loss_Gen"] < first["L1_loss_Gen"]
+
+
+# ------------------------------------------------------------------ SpecSeg (S1) + Spec_loss (L5)
+@pytest.mark.parametrize("S,B", [(32, 2), (64, 1), (256, 1)])
+def test_specseg_forward_matches_oracle(S, B):
+    """SpecSeg.predict (SHM.py:492) against the float64 restatement; 1,942,801 parameters
+    (SpecSeg_summary.txt:118)."""
+    from shmgan_amd.model import Arena
+    from shmgan_amd.specseg import SpecSeg
+    net = SpecSeg(S, torch.device("cuda"), Arena(torch.device("cuda")))
+    assert net.count_params() == 1942801
+    w = sp.init_specseg(seed=3)
+    net.set_weights(w)
+    x = np.random.default_rng(S).standard_normal((B, S, S, 1)) * 2.0
+    got = host(net.predict(x))
+    ref = sp.specseg_forward(w, x).numpy()
+    assert got.shape == ref.shape == (B, S, S, 1)
+    assert np.abs(got - ref).max() < 1e-5 and rel_l2(got, ref) < 1e-5
+    back = net.get_weights()
+    assert all(np.array_equal(a, b) for a, b in zip(back, w))
+
+
+def test_specseg_golden_fixture():
+    from pathlib import Path
+    from shmgan_amd.model import Arena
+    from shmgan_amd.specseg import SpecSeg
+    gold = np.load(Path(__file__).resolve().parent / "golden" / "specseg_S32.npz")
+    net = SpecSeg(32, torch.device("cuda"), Arena(torch.device("cuda")))
+    net.set_weights(sp.init_specseg(seed=3))
+    assert np.abs(host(net.predict(gold["x"])) - gold["mask"]).max() < 1e-5
+
+
+def test_specseg_default_init_and_summary():
+    from shmgan_amd.model import Arena
+    from shmgan_amd.specseg import SpecSeg
+    net = SpecSeg(32, torch.device("cuda"), Arena(torch.device("cuda"))).init_random()
+    lines = []
+    net.summary(print_fn=lines.append)
+    assert "Total params: 1,942,801" in lines and "Non-trainable params: 992" in lines
+    m = host(net.predict(np.zeros((1, 32, 32, 1), np.float32)))
+    assert np.allclose(m, 0.5)          # zero input, zero biases, BN mean 0 -> logit 0
+
+
+def test_spec_loss_kernel():
+    from shmgan_amd import ops
+    rng = np.random.default_rng(8)
+    B, S = 2, 16
+    cyc_y = rng.standard_normal((5 * B, S, S, 1))
+    cbcr = rng.standard_normal((B, S, S, 2))
+    ds = [rng.standard_normal((B, S, S, 3)) for _ in range(5)]
+    mask = rng.random((B, S, S, 1))
+    dsd = [dev(a) for a in ds]
+    ptr = (C.c_void_p * 5)(*[t.data_ptr() for t in dsd])
+    loss = torch.zeros(5, dtype=torch.float64, device="cuda")
+    ops.spec_loss(dev(cyc_y), dev(cbcr), ptr, dev(mask), loss, B, S * S)
+    cyc = [t64(np.concatenate([cyc_y[k * B:(k + 1) * B], cbcr], axis=3)) for k in range(5)]
+    total, terms = sp.spec_loss(cyc, [t64(a) for a in ds], t64(mask))
+    got = loss.cpu().numpy() / (B * S * S * 3)
+    assert np.allclose(got, [float(t) for t in terms], rtol=1e-5)
