@@ -31,6 +31,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 
 
 def main():
@@ -48,6 +49,10 @@ def main():
     ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: all ranks share GPU 0")
+    ap.add_argument("--grad-dtype", type=str, default=None, choices=["float32", "bfloat16"],
+                    help="bf16 mode only: element type of the gradient-signal tensors (float32 = SHM_BF16_GF32)")
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE configs[1] (default, the headline line); bf16 = configs[3]/[4] (bf16 MFMA path)")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,7 +80,10 @@ def main():
     from shmgan_amd import ShmGANwithSSpecSeg, ops
 
     S, F, B = args.image_size, args.filter_size, args.batch
-    model = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, device=dev).build()
+    model = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, device=dev,
+                               compute_dtype="bfloat16" if args.dtype == "bf16" else "float32",
+                               grad_dtype=args.grad_dtype).build()
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
 
     # synthetic inputs, resident in HBM before the timed region
     rng = np.random.default_rng(1234 + rank)
@@ -151,10 +159,13 @@ def main():
         out = {
             "metric": "images/sec (gen+disc train_step)", "value": round(value, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, fp32"
-                                   + (" (BASELINE configs[1])" if (S, B, F) == (256, 8, 64) else ""),
+            "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, "
+                                   + ("fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate")
+                                   + (" (BASELINE configs[1])" if (S, B, F, args.dtype) == (256, 8, 64, "f32") else "")
+                                   + (" (BASELINE configs[3])" if (S, B, F, args.dtype) == (512, 4, 64, "bf16") else "")
+                                   + (" (BASELINE configs[4], per GPU)" if (S, B, F, args.dtype) == (256, 32, 64, "bf16") else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "losses_finite": bool(finite)},
         }
@@ -171,8 +182,8 @@ def main():
                     if name.replace("void ", "").replace(" ", "") == dom.replace(" ", ""):
                         traffic = rec["hbm_bytes_per_launch"]
             out["roofline"] = {
-                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "region": "serialized replay of the timed steps (single stream), same process",
                 "replay_ms_per_step": round(dt_serial / args.steps * 1e3, 3),
                 "whole_step_conv_tflops": round(sum(v["flops"] for v in summ.values()) / args.steps / (ms * 1e-3) / 1e12, 2),

@@ -8,10 +8,17 @@
  * the ctypes binding a maintainer of the reference would add.
  *
  * Conventions
- *  - all tensors are float32, NHWC, device pointers (the caller owns every buffer, the
- *    library never allocates device memory and keeps no pointer after return);
- *  - "ld*" arguments are channel pitches in floats (>= the channel count; 16-float
- *    aligned pitches let 3- and 10-channel images go through the MFMA path);
+ *  - tensors are NHWC device pointers (the caller owns every buffer, the library never
+ *    allocates device memory and keeps no pointer after return);
+ *  - `void*` tensors are ACTIVATION-typed: float32 when the call's `dtype` is SHM_F32, bfloat16
+ *    when it is SHM_BF16 (BASELINE configs 4-5: bf16 operands on v_mfma_f32_32x32x16_bf16, fp32
+ *    accumulation and fp32 arithmetic inside every kernel).  `float*` / `double*` arguments keep
+ *    their type in both modes: master weights, biases, IN beta, statistics, weight gradients,
+ *    image-space tensors and losses are always fp32 / f64;
+ *  - "ld*" arguments are channel pitches in ELEMENTS (>= the channel count).  MFMA operands are
+ *    staged as 64-byte rows, so contraction channel counts and concat splits are multiples of
+ *    16 (fp32) or 32 (bf16), pitches multiples of 4 (fp32) or 8 (bf16); the 3- and 10-channel
+ *    images are stored in a 16-float / 32-bf16 pitch (zero padded);
  *  - "f64 scratch" arguments are small double accumulators the call zeroes itself;
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *  - return value: SHM_OK or a negative error; shm_last_error() gives the text.
@@ -31,47 +38,59 @@ extern "C" {
 #define SHM_E_WORKSPACE (-3)
 #define SHM_E_HIP (-4)
 
+#define SHM_F32 0
+#define SHM_BF16 1
+/* bf16 activations and MFMA operands, but fp32 for the tensors marked [G] below: the gradient
+ * signal on its way from an input-gradient product into the next InstanceNorm/LeakyReLU backward.
+ * An option for callers that want that signal unrounded; measured on the whole step it changes no
+ * per-tensor gradient cosine beyond the 4th digit and costs 1.7 % (DESIGN.md, bf16 path), so the
+ * host side defaults to plain SHM_BF16.  Accepted by the functions that have a [G] argument. */
+#define SHM_BF16_GF32 2
+
 int shm_version(void);
 const char* shm_last_error(void);
 
 /* ---- weight layout ---------------------------------------------------------------
  * [ntaps][rows][cols] -> [ntaps][cols][rows_pad] (zero padded): HWIO -> K-contiguous
  * [tap][Cout][Cin] for the implicit-GEMM B operand. */
-int shm_transpose_taps(const float* w, float* wt, int ntaps, int rows, int cols, int rows_pad,
-                       void* stream);
+int shm_transpose_taps(const float* w, void* wt, int ntaps, int rows, int cols, int rows_pad,
+                       int dtype, void* stream);
+/* dst[i] = (dtype) src[i]: operand copies of weights that are already K-contiguous as stored. */
+int shm_cast_f32(const float* src, void* dst, size_t n, int dtype, void* stream);
 
 /* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) -----------------------
  * Keras Conv2D(k in {1,3}, strides in {1,2}, padding='same') + bias + LeakyReLU(slope)
- * (SHM.py:244-245, 254-326, 365-369, 387).  Input = channel concat of x (c1 channels,
+ * (SHM.py:244-245, 254-326, 365-369, 387).  y is [G]-typed under SHM_BF16_GF32 (the call is then the
+ * input-gradient of a Conv2DTranspose).  Input = channel concat of x (c1 channels,
  * pitch ldx) and optional x2 (cin-c1 channels, pitch ldx2): Concatenate() SHM.py:299,306,
  * 313,320 is never materialised.  wk = [k*k][cout][cin] (shm_transpose_taps of HWIO),
  * cin % 16 == 0.  bias may be NULL; slope 1.0f = no activation. */
-int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
-                   const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
-                   int cout, int ksize, int stride, float slope, void* stream);
+int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
+                   const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
+                   int cout, int ksize, int stride, float slope, int dtype, void* stream);
 
 /* The same convolution fused with the InstanceNormalization statistics of its output
  * (Conv2D -> LeakyReLU -> InstanceNormalization, SHM.py:244-245): the epilogue accumulates
  * sum / sum of squares per (sample, channel); on return (stream order) stats holds
  * (mean, rsqrt(var + eps)) exactly as shm_in_stats would leave it.  stats = f64 [batch*cout*2]. */
-int shm_conv2d_in_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
-                      const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
+                      const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                       int cout, int ksize, int stride, float slope, double* stats, float eps,
-                      void* stream);
+                      int dtype, void* stream);
 
 /* Input-gradient of the same conv.  dy [batch,ho,wo,cout] (pitch lddy), w = HWIO
  * [k*k][cin][cout] as stored (it is already K-contiguous for this product), cout % 16 == 0.
  * dx channels [0,n1) go to dx (pitch lddx), [n1,cin) to dx2 (pitch lddx2): the split of a
- * concat gradient.  Pass dx2=NULL, n1=cin for a single destination. */
-int shm_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, float* dx2, int n1,
+ * concat gradient.  Pass dx2=NULL, n1=cin for a single destination.  dx, dx2 are [G] tensors. */
+int shm_conv2d_dgrad(const void* dy, int lddy, const void* w, void* dx, void* dx2, int n1,
                      int lddx, int lddx2, int batch, int hi, int wi, int cin, int cout,
-                     int ksize, int stride, void* stream);
+                     int ksize, int stride, int dtype, void* stream);
 
 /* Keras Conv2DTranspose(k=3, strides=2, 'same') + bias + LeakyReLU (SHM.py:298,305,312,319).
  * x [batch,hi,wi,cin]; w = Keras layout [3][3][cout][cin] as stored; y [batch,2hi,2wi,cout]. */
-int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+int shm_conv2d_transpose_fwd(const void* x, int ldx, const void* w, const float* bias, void* y,
                              int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
-                             void* stream);
+                             int dtype, void* stream);
 
 /* Weight gradient: dw[t][ci][co] (+)= sum_pixels x[pix*stride + tap][ci] * dy[pix][co]
  * (HWIO).  For Conv2DTranspose pass x = dz of the transposed conv (2H res), dy = its input
@@ -79,35 +98,36 @@ int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const floa
  * input channels to read (multiple of 4, pad channels must be zero), cin = rows stored.
  * workspace: split-K partial slabs, at least shm_conv2d_wgrad_workspace() bytes. */
 size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize);
-int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* dy,
+int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
                      int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
                      int cout, int ksize, int stride, int accumulate, void* workspace,
-                     size_t ws_bytes, void* stream);
+                     size_t ws_bytes, int dtype, void* stream);
 
 /* ---- InstanceNormalization (tfa, axis=-1, eps, gamma==1, constant beta) -----------
  * SHM.py:245...:388; op chain Generator_summary.txt:9-36.
  * stats = f64 [batch*c*2]; on return (stream order) stats[(n*c+ch)*2] = mean over H*W,
  * stats[(n*c+ch)*2+1] = rsqrt(biased variance + eps). */
-int shm_in_stats(const float* a, int lda, double* stats, int batch, int hw, int c, float eps,
-                 void* stream);
+int shm_in_stats(const void* a, int lda, double* stats, int batch, int hw, int c, float eps,
+                 int dtype, void* stream);
 /* out = (a - mean) * inv + beta[c]  (out may alias a). */
-int shm_in_apply(const float* a, int lda, const double* stats, const float* beta, float* out,
-                 int ldo, int batch, int hw, int c, void* stream);
+int shm_in_apply(const void* a, int lda, const double* stats, const float* beta, void* out,
+                 int ldo, int batch, int hw, int c, int dtype, void* stream);
 /* Backward of LeakyReLU -> IN given the gradient at the IN output:
  *   d_out = g1 + 0.25 * g2[h/2][w/2]   (g2 = gradient of AveragePooling2D(2,2), may be NULL)
  *   dz = lrelu'(a) * inv * (d_out - mean(d_out) - xhat * mean(d_out * xhat))
- * red = f64 scratch [batch*c*2]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL). */
-int shm_in_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* a, int lda,
-               const double* stats, double* red, float* dz, int lddz, double* dbias, int batch,
-               int h, int w, int c, float slope, void* stream);
+ * red = f64 scratch [batch*c*2]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL).
+ * g1, g2 are [G] tensors; a and dz are activation-typed. */
+int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
+               const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
+               int h, int w, int c, float slope, int dtype, void* stream);
 
-/* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y). */
-int shm_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz,
-                  double* dbias, size_t npix, int c, float slope, void* stream);
+/* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y); dy is [G]. */
+int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dz, int lddz,
+                  double* dbias, size_t npix, int c, float slope, int dtype, void* stream);
 
 /* AveragePooling2D(2,2,'same') on even sizes (SHM.py:249,258,267,276). */
-int shm_avgpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int h, int w, int c,
-                     void* stream);
+int shm_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int batch, int h, int w, int c,
+                     int dtype, void* stream);
 
 /* f64 accumulator -> f32 (dst = or += src). */
 int shm_cvt_f64_f32(const double* src, float* dst, size_t n, int accumulate, void* stream);
@@ -115,28 +135,30 @@ int shm_zero(void* p, size_t bytes, void* stream);
 
 /* ---- 1-output-channel layers ------------------------------------------------------
  * Generator head Conv2D(1, k=1) + LeakyReLU (SHM.py:326). */
-int shm_head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, size_t npix,
-                 int c, float slope, void* stream);
-/* dz = dy*lrelu'(y); dx = dz (x) w; dw_acc[c] += sum x*dz; db_acc[0] += sum dz (f64, not zeroed). */
-int shm_head_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dx,
+int shm_head_fwd(const void* x, int ldx, const float* w, const float* bias, float* y, size_t npix,
+                 int c, float slope, int dtype, void* stream);
+/* dz = dy*lrelu'(y); dx [G] = dz (x) w; dw_acc[c] += sum x*dz; db_acc[0] += sum dz (f64, not zeroed). */
+int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, void* dx,
                  int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope,
-                 void* stream);
+                 int dtype, void* stream);
 /* PatchGAN logits Conv2D(1, k=3, no bias) + LeakyReLU (SHM.py:365-369). x [batch,h,w,c]. */
-int shm_patch_fwd(const float* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,
-                  float slope, void* stream);
-/* dz = dy*lrelu'(y) (written to dz [batch,h,w]); dx = transposed conv of dz (overwritten);
+int shm_patch_fwd(const void* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,
+                  float slope, int dtype, void* stream);
+/* dz = dy*lrelu'(y) (written to dz [batch,h,w]); dx [G] = transposed conv of dz (overwritten);
  * dw[9*c] = sum x*dz (overwritten; may be NULL). */
-int shm_patch_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
-                  float* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope,
-                  void* stream);
+int shm_patch_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
+                  void* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope,
+                  int dtype, void* stream);
 /* Flatten + Dense(5, no bias) (SHM.py:371-375): logits[n][j] = sum_k x[n][k] * w[k][j]. */
-int shm_dense_fwd(const float* x, const float* w, float* y, int batch, int k, int nout, void* stream);
-/* dx[n][k] += sum_j dy[n][j]*w[k][j] (accumulates onto dx); dw[k][j] = sum_n x[n][k]*dy[n][j]
+int shm_dense_fwd(const void* x, const float* w, float* y, int batch, int k, int nout, int dtype,
+                  void* stream);
+/* dx[n][k] += sum_j dy[n][j]*w[k][j] (accumulates onto dx, a [G] tensor); dw[k][j] = sum_n x[n][k]*dy[n][j]
  * (dw may be NULL). */
-int shm_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int batch,
-                  int k, int nout, void* stream);
+int shm_dense_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, int batch,
+                  int k, int nout, int dtype, void* stream);
 /* Dropout(0.2) as keep-mask multiply (SHM.py:363): y = x * mask * scale. */
-int shm_mul_mask(const float* x, const float* mask, float* y, size_t n, float scale, void* stream);
+int shm_mul_mask(const void* x, const float* mask, void* y, size_t n, float scale, int dtype,
+                 void* stream);
 
 /* ---- colour / standardisation / input assembly (SHM.py:480-531, 544-553, 576-624) -- */
 /* tf.image.rgb_to_yuv + custom_per_image_standardization (SHM.py:1271-1309), per sample.
@@ -146,26 +168,28 @@ int shm_rgb2yuv_std(const float* rgb, float* yuv, double* acc, float* scale_out,
 /* averageCbCr (SHM.py:505): out[b,p,0:2] = mean_k yuv_k[b,p,1:3]. */
 int shm_avg_cbcr(const float* y0, const float* y1, const float* y2, const float* y3,
                  const float* y4, float* out, size_t n_pix_total, void* stream);
-/* 10-channel generator inputs in a 16-float pitch (SHM.py:517-531, 576-594).
+/* 10-channel generator inputs in a pitch of ldo elements, zero padded (SHM.py:517-531, 576-594).
  * mode 0: G(1) input  -> out [batch,...]: view k = flags[k] ? 0 : Y_k ; one-hot tail = ED.
  * mode 1: cyclic inputs -> out [5*batch,...] (k-major): view j = (j==k) ? 0 : (flags[j] ? genY : Y_j);
  * one-hot k.  yuv_k are the standardised [batch,S,S,3] tensors, genY [batch,S,S,1]. */
 int shm_build_gen_input(const float* y0, const float* y1, const float* y2, const float* y3,
-                        const float* y4, const float* gen_y, int flags_mask, int mode, float* out,
-                        int batch, size_t npix, void* stream);
+                        const float* y4, const float* gen_y, int flags_mask, int mode, void* out,
+                        int ldo, int batch, size_t npix, int dtype, void* stream);
 /* Gradient of the cyclic inputs back into genY (G o G chain): dgenY[b,p] += sum over k, j!=k with
  * flags[j] of dcyc[k*batch+b, p, j]. */
-int shm_cyc_input_bwd(const float* dcyc, int flags_mask, float* dgen_y, int batch, size_t npix,
-                      void* stream);
+int shm_cyc_input_bwd(const void* dcyc, int ld, int flags_mask, float* dgen_y, int batch,
+                      size_t npix, int dtype, void* stream);
 /* tf.image.yuv_to_rgb of concat([Y, avgCbCr]) (SHM.py:544-553, 613-624) for nimg = reps*batch
- * images (image i uses cbcr[i % batch]); writes rgb [nimg,S,S,3] and, if dpad != NULL, the
- * 16-pitch discriminator input (rgb + optional GaussianNoise `noise` [nimg,S,S,3], SHM.py:352). */
-int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, float* dpad,
-                int nimg, int batch, size_t npix, void* stream);
-/* Pack raw rgb [nimg,S,S,3] (+ noise) into the 16-pitch discriminator input. */
-int shm_pack_rgb16(const float* rgb, const float* noise, float* dpad, size_t npix_total, void* stream);
-/* dY[i,p] (+)= sum_c d_rgb16[i,p,c], c<3 (yuv_to_rgb backward: every channel has dRGB/dY = 1). */
-int shm_rgb16_to_dy(const float* d16, float* dy, size_t npix_total, int accumulate, void* stream);
+ * images (image i uses cbcr[i % batch]); writes rgb [nimg,S,S,3] and, if dpad != NULL, the padded
+ * discriminator input of pitch ldp (rgb + optional GaussianNoise `noise` [nimg,S,S,3], SHM.py:352). */
+int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, void* dpad,
+                int ldp, int nimg, int batch, size_t npix, int dtype, void* stream);
+/* Pack raw rgb [nimg,S,S,3] (+ noise) into the padded discriminator input of pitch ldp. */
+int shm_pack_rgb16(const float* rgb, const float* noise, void* dpad, int ldp, size_t npix_total,
+                   int dtype, void* stream);
+/* dY[i,p] (+)= sum_c d_pad[i,p,c], c<3 (yuv_to_rgb backward: every channel has dRGB/dY = 1). */
+int shm_rgb16_to_dy(const void* d16, int ld, float* dy, size_t npix_total, int accumulate, int dtype,
+                    void* stream);
 
 /* ---- losses (SHM.py:669-844) ------------------------------------------------------
  * Discriminator-head losses and their gradients.  Sample order in the D batch:
@@ -201,9 +225,9 @@ int shm_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int 
                      void* stream);
 /* Conv2DTranspose(k=2, strides=2, 'same') + bias (SpecSeg.py:63,69,75,81).  w = Keras layout
  * [2][2][cout][cin] as stored; y [batch,2hi,2wi,cout]; slope 1.0f = linear. */
-int shm_conv2d_transpose2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+int shm_conv2d_transpose2x2_fwd(const void* x, int ldx, const void* w, const float* bias, void* y,
                                 int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
-                                void* stream);
+                                int dtype, void* stream);
 /* Conv2D(1, (1,1), activation='sigmoid') (SpecSeg.py:88). */
 int shm_head_sigmoid_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
                          size_t npix, int c, void* stream);

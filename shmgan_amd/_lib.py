@@ -16,8 +16,9 @@ LIB_PATH = _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
 SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip"]
+F32, BF16 = 0, 1                 # SHM_F32 / SHM_BF16 of include/shmgan_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-Wno-unused-local-typedef"]
 
 P, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 
@@ -25,46 +26,46 @@ P, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 SIGNATURES = {
     "shm_version": (I, []),
     "shm_last_error": (C.c_char_p, []),
-    "shm_transpose_taps": (I, [P, P, I, I, I, I, P]),
-    "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P]),
-    "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, F, P]),
-    "shm_conv2d_dgrad": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "shm_conv2d_transpose_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, P]),
+    "shm_transpose_taps": (I, [P, P, I, I, I, I, I, P]),
+    "shm_cast_f32": (I, [P, P, Z, I, P]),
+    "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, F, I, P]),
+    "shm_conv2d_dgrad": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "shm_conv2d_transpose_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, I, P]),
     "shm_conv2d_wgrad_workspace": (Z, [I, I, I, I, I, I]),
-    "shm_conv2d_wgrad": (I, [P, P, I, I, I, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, P]),
-    "shm_in_stats": (I, [P, I, P, I, I, I, F, P]),
-    "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, P]),
-    "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, P]),
-    "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, Z, I, F, P]),
-    "shm_avgpool2_fwd": (I, [P, I, P, I, I, I, I, I, P]),
+    "shm_conv2d_wgrad": (I, [P, P, I, I, I, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
+    "shm_in_stats": (I, [P, I, P, I, I, I, F, I, P]),
+    "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
+    "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
+    "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, Z, I, F, I, P]),
+    "shm_avgpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "shm_cvt_f64_f32": (I, [P, P, Z, I, P]),
     "shm_zero": (I, [P, Z, P]),
-    "shm_head_fwd": (I, [P, I, P, P, P, Z, I, F, P]),
-    "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, Z, I, F, P]),
-    "shm_patch_fwd": (I, [P, I, P, P, I, I, I, I, F, P]),
-    "shm_patch_bwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, F, P]),
-    "shm_dense_fwd": (I, [P, P, P, I, I, I, P]),
-    "shm_dense_bwd": (I, [P, P, P, P, P, I, I, I, P]),
-    "shm_mul_mask": (I, [P, P, P, Z, F, P]),
+    "shm_head_fwd": (I, [P, I, P, P, P, Z, I, F, I, P]),
+    "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, Z, I, F, I, P]),
+    "shm_patch_fwd": (I, [P, I, P, P, I, I, I, I, F, I, P]),
+    "shm_patch_bwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, F, I, P]),
+    "shm_dense_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "shm_dense_bwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "shm_mul_mask": (I, [P, P, P, Z, F, I, P]),
     "shm_rgb2yuv_std": (I, [P, P, P, P, I, Z, P]),
     "shm_avg_cbcr": (I, [P, P, P, P, P, P, Z, P]),
-    "shm_build_gen_input": (I, [P, P, P, P, P, P, I, I, P, I, Z, P]),
-    "shm_cyc_input_bwd": (I, [P, I, P, I, Z, P]),
-    "shm_yuv2rgb": (I, [P, P, P, P, P, I, I, Z, P]),
-    "shm_pack_rgb16": (I, [P, P, P, Z, P]),
-    "shm_rgb16_to_dy": (I, [P, P, Z, I, P]),
+    "shm_build_gen_input": (I, [P, P, P, P, P, P, I, I, P, I, I, Z, I, P]),
+    "shm_cyc_input_bwd": (I, [P, I, I, P, I, Z, I, P]),
+    "shm_yuv2rgb": (I, [P, P, P, P, P, I, I, I, Z, I, P]),
+    "shm_pack_rgb16": (I, [P, P, P, I, Z, I, P]),
+    "shm_rgb16_to_dy": (I, [P, I, P, Z, I, I, P]),
     "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, P]),
     "shm_image_losses_workspace": (Z, [I, I]),
     "shm_image_losses": (I, [P, P, P, P, P, P, I, F, P, P, P, P, Z, I, I, P]),
     "shm_pack_channels": (I, [P, I, I, I, P, I, Z, P]),
     "shm_bn_apply": (I, [P, I, P, P, P, P, F, P, I, Z, I, P]),
     "shm_maxpool2_fwd": (I, [P, I, P, I, I, I, I, I, P]),
-    "shm_conv2d_transpose2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, P]),
+    "shm_conv2d_transpose2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, I, P]),
     "shm_head_sigmoid_fwd": (I, [P, I, P, P, P, Z, I, P]),
     "shm_spec_loss": (I, [P, P, P, P, P, I, Z, P]),
     "shm_adam_clip": (I, [P, P, P, P, Z, F, F, F, F, F, P]),
 }
-
 
 def header_functions():
     """Names declared in include/shmgan_hip.h (used by the ABI test)."""

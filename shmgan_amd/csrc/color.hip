@@ -111,7 +111,9 @@ struct Five {
     const float* p[5];
 };
 
-__global__ void build_gen_input_kernel(Five ys, const float* __restrict__ gen_y, int flags, int mode, float* __restrict__ out, int batch, size_t npix) {
+// writes the 10 real channels + zero padding up to the pitch ldo (16 floats or 32 bf16: one 64-byte LDS row)
+template <typename T>
+__global__ void build_gen_input_kernel(Five ys, const float* __restrict__ gen_y, int flags, int mode, T* __restrict__ out, int ldo, int batch, size_t npix) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // (img, p)
     const int nimg = mode ? 5 * batch : batch;
     if (idx >= (size_t)nimg * npix) return;
@@ -132,45 +134,59 @@ __global__ void build_gen_input_kernel(Five ys, const float* __restrict__ gen_y,
             v[j] = (j == k) ? 0.f : (fl ? gen_y[src] : ys.p[j][src * 3]);
     }
     v[5 + k] = 1.f;
-    f32x4* o = (f32x4*)(out + idx * 16);
+    T* o = out + idx * ldo;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    for (int q = 0; q < 4; ++q) st4(o + 4 * q, (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+    for (int q = 4; q < (ldo >> 2); ++q) st4(o + 4 * q, (f32x4){0.f, 0.f, 0.f, 0.f});
 }
 
 extern "C" int shm_build_gen_input(const float* y0, const float* y1, const float* y2, const float* y3, const float* y4, const float* gen_y,
-                                   int flags_mask, int mode, float* out, int batch, size_t npix, void* stream) {
+                                   int flags_mask, int mode, void* out, int ldo, int batch, size_t npix, int dtype, void* stream) {
     SHM_REQUIRE(mode == 0 || (mode == 1 && gen_y), SHM_E_SHAPE, "shm_build_gen_input: bad mode/gen_y");
+    SHM_REQUIRE(ldo >= 16 && ldo % 4 == 0, SHM_E_SHAPE, "shm_build_gen_input: pitch %d must be >= 16 and a multiple of 4", ldo);
     size_t total = (size_t)(mode ? 5 * batch : batch) * npix;
     if (total == 0) return SHM_OK;
     Five f{{y0, y1, y2, y3, y4}};
-    hipLaunchKernelGGL(build_gen_input_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, f, gen_y, flags_mask, mode, out, batch, npix);
+    SHM_DISPATCH(dtype, "shm_build_gen_input",
+                 hipLaunchKernelGGL(build_gen_input_kernel<T>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, f, gen_y, flags_mask, mode,
+                                    (T*)out, ldo, batch, npix));
     SHM_LAUNCH_CHECK("shm_build_gen_input");
     return SHM_OK;
 }
 
-__global__ void cyc_input_bwd_kernel(const float* __restrict__ dcyc, int flags, float* __restrict__ dgen_y, int batch, size_t npix) {
+template <typename T>
+__global__ void cyc_input_bwd_kernel(const T* __restrict__ dcyc, int ld, int flags, float* __restrict__ dgen_y, int batch, size_t npix) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // (b, p)
     if (idx >= (size_t)batch * npix) return;
     float s = 0.f;
     for (int k = 0; k < 5; ++k) {
-        const float* row = dcyc + ((size_t)k * batch * npix + idx) * 16;
+        const T* row = dcyc + ((size_t)k * batch * npix + idx) * ld;
         for (int j = 0; j < 5; ++j)
-            if (j != k && ((flags >> j) & 1)) s += row[j];
+            if (j != k && ((flags >> j) & 1)) s += (float)row[j];
     }
     dgen_y[idx] += s;
 }
 
-extern "C" int shm_cyc_input_bwd(const float* dcyc, int flags_mask, float* dgen_y, int batch, size_t npix, void* stream) {
+extern "C" int shm_cyc_input_bwd(const void* dcyc, int ld, int flags_mask, float* dgen_y, int batch, size_t npix, int dtype, void* stream) {
     size_t total = (size_t)batch * npix;
     if (total == 0) return SHM_OK;
-    hipLaunchKernelGGL(cyc_input_bwd_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, dcyc, flags_mask, dgen_y, batch, npix);
+    SHM_DISPATCH(dtype, "shm_cyc_input_bwd",
+                 hipLaunchKernelGGL(cyc_input_bwd_kernel<T>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dcyc, ld, flags_mask,
+                                    dgen_y, batch, npix));
     SHM_LAUNCH_CHECK("shm_cyc_input_bwd");
     return SHM_OK;
 }
 
 // -------------------------------------------------------------------------- yuv -> rgb
+template <typename T>
+__device__ __forceinline__ void store_rgb_pad(T* o, int ld, float r, float g, float b) {
+    st4(o, (f32x4){r, g, b, 0.f});
+    for (int q = 1; q < (ld >> 2); ++q) st4(o + 4 * q, (f32x4){0.f, 0.f, 0.f, 0.f});
+}
+
+template <typename T>
 __global__ void yuv2rgb_kernel(const float* __restrict__ ych, const float* __restrict__ cbcr, const float* __restrict__ noise, float* __restrict__ rgb,
-                               float* __restrict__ dpad, int nimg, int batch, size_t npix) {
+                               T* __restrict__ dpad, int ldp, int nimg, int batch, size_t npix) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)nimg * npix) return;
     size_t p = idx % npix;
@@ -189,22 +205,25 @@ __global__ void yuv2rgb_kernel(const float* __restrict__ ych, const float* __res
             g += noise[idx * 3 + 1];
             bl += noise[idx * 3 + 2];
         }
-        f32x4* o = (f32x4*)(dpad + idx * 16);
-        o[0] = (f32x4){r, g, bl, 0.f};
-        o[1] = o[2] = o[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        store_rgb_pad(dpad + idx * ldp, ldp, r, g, bl);
     }
 }
 
-extern "C" int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, float* dpad, int nimg, int batch, size_t npix, void* stream) {
+extern "C" int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, void* dpad, int ldp, int nimg, int batch, size_t npix,
+                           int dtype, void* stream) {
+    SHM_REQUIRE(!dpad || (ldp >= 4 && ldp % 4 == 0), SHM_E_SHAPE, "shm_yuv2rgb: pitch %d must be a multiple of 4", ldp);
     SHM_REQUIRE(batch > 0 && nimg % batch == 0, SHM_E_SHAPE, "shm_yuv2rgb: nimg %d not a multiple of batch %d", nimg, batch);
     size_t total = (size_t)nimg * npix;
     if (total == 0) return SHM_OK;
-    hipLaunchKernelGGL(yuv2rgb_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, ych, cbcr, noise, rgb, dpad, nimg, batch, npix);
+    SHM_DISPATCH(dtype, "shm_yuv2rgb",
+                 hipLaunchKernelGGL(yuv2rgb_kernel<T>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, ych, cbcr, noise, rgb, (T*)dpad, ldp,
+                                    nimg, batch, npix));
     SHM_LAUNCH_CHECK("shm_yuv2rgb");
     return SHM_OK;
 }
 
-__global__ void pack_rgb16_kernel(const float* __restrict__ rgb, const float* __restrict__ noise, float* __restrict__ dpad, size_t n) {
+template <typename T>
+__global__ void pack_rgb16_kernel(const float* __restrict__ rgb, const float* __restrict__ noise, T* __restrict__ dpad, int ldp, size_t n) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     float r = rgb[idx * 3], g = rgb[idx * 3 + 1], b = rgb[idx * 3 + 2];
@@ -213,29 +232,32 @@ __global__ void pack_rgb16_kernel(const float* __restrict__ rgb, const float* __
         g += noise[idx * 3 + 1];
         b += noise[idx * 3 + 2];
     }
-    f32x4* o = (f32x4*)(dpad + idx * 16);
-    o[0] = (f32x4){r, g, b, 0.f};
-    o[1] = o[2] = o[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    store_rgb_pad(dpad + idx * ldp, ldp, r, g, b);
 }
 
-extern "C" int shm_pack_rgb16(const float* rgb, const float* noise, float* dpad, size_t n, void* stream) {
+extern "C" int shm_pack_rgb16(const float* rgb, const float* noise, void* dpad, int ldp, size_t n, int dtype, void* stream) {
+    SHM_REQUIRE(ldp >= 4 && ldp % 4 == 0, SHM_E_SHAPE, "shm_pack_rgb16: pitch %d must be a multiple of 4", ldp);
     if (n == 0) return SHM_OK;
-    hipLaunchKernelGGL(pack_rgb16_kernel, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, rgb, noise, dpad, n);
+    SHM_DISPATCH(dtype, "shm_pack_rgb16",
+                 hipLaunchKernelGGL(pack_rgb16_kernel<T>, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, rgb, noise, (T*)dpad, ldp, n));
     SHM_LAUNCH_CHECK("shm_pack_rgb16");
     return SHM_OK;
 }
 
-__global__ void rgb16_to_dy_kernel(const float* __restrict__ d16, float* __restrict__ dy, size_t n, int acc) {
+template <typename T>
+__global__ void rgb16_to_dy_kernel(const T* __restrict__ d16, int ld, float* __restrict__ dy, size_t n, int acc) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    f32x4 v = *(const f32x4*)(d16 + idx * 16);
+    f32x4 v = ld4(d16 + idx * ld);
     float s = v[0] + v[1] + v[2];
     dy[idx] = acc ? dy[idx] + s : s;
 }
 
-extern "C" int shm_rgb16_to_dy(const float* d16, float* dy, size_t n, int accumulate, void* stream) {
+extern "C" int shm_rgb16_to_dy(const void* d16, int ld, float* dy, size_t n, int accumulate, int dtype, void* stream) {
+    SHM_REQUIRE(ld >= 4 && ld % 4 == 0, SHM_E_SHAPE, "shm_rgb16_to_dy: pitch %d must be a multiple of 4", ld);
     if (n == 0) return SHM_OK;
-    hipLaunchKernelGGL(rgb16_to_dy_kernel, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, d16, dy, n, accumulate);
+    SHM_DISPATCH(dtype, "shm_rgb16_to_dy",
+                 hipLaunchKernelGGL(rgb16_to_dy_kernel<T>, dim3(shm_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)d16, ld, dy, n, accumulate));
     SHM_LAUNCH_CHECK("shm_rgb16_to_dy");
     return SHM_OK;
 }

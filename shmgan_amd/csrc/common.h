@@ -10,7 +10,69 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16_t;            // activation element type of the bf16 path (SHM_BF16)
+
 void shm_set_error(const char* fmt, ...);
+
+// 4-channel vector access in either element type; arithmetic is always fp32.
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+    const uint2 u = *(const uint2*)p;
+    f32x4 r;
+    r[0] = __uint_as_float(u.x << 16);
+    r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16);
+    r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t o;
+    o[0] = (bf16_t)v[0];
+    o[1] = (bf16_t)v[1];
+    o[2] = (bf16_t)v[2];
+    o[3] = (bf16_t)v[3];
+    *(bf16x4_t*)p = o;
+}
+// value as it will read back from a tensor of type T
+__device__ __forceinline__ float rnd_as(const float*, float v) { return v; }
+__device__ __forceinline__ float rnd_as(const bf16_t*, float v) { return (float)(bf16_t)v; }
+
+// run `...` with T = float or bf16_t according to an SHM_F32 / SHM_BF16 dtype argument
+#define SHM_DISPATCH(dtype, who, ...)                                          \
+    do {                                                                       \
+        if ((dtype) == SHM_BF16) {                                             \
+            using T = bf16_t;                                                  \
+            __VA_ARGS__;                                                       \
+        } else if ((dtype) == SHM_F32) {                                       \
+            using T = float;                                                   \
+            __VA_ARGS__;                                                       \
+        } else {                                                               \
+            shm_set_error("%s: dtype %d not in {SHM_F32, SHM_BF16}", who, (int)(dtype)); \
+            return SHM_E_DTYPE;                                                \
+        }                                                                      \
+    } while (0)
+// same with a second type TG for gradient-signal tensors: fp32 under SHM_BF16_GF32
+#define SHM_DISPATCH_G(dtype, who, ...)                                        \
+    do {                                                                       \
+        if ((dtype) == SHM_BF16) {                                             \
+            using T = bf16_t;                                                  \
+            using TG = bf16_t;                                                 \
+            __VA_ARGS__;                                                       \
+        } else if ((dtype) == SHM_BF16_GF32) {                                 \
+            using T = bf16_t;                                                  \
+            using TG = float;                                                  \
+            __VA_ARGS__;                                                       \
+        } else if ((dtype) == SHM_F32) {                                       \
+            using T = float;                                                   \
+            using TG = float;                                                  \
+            __VA_ARGS__;                                                       \
+        } else {                                                               \
+            shm_set_error("%s: dtype %d not in {SHM_F32, SHM_BF16, SHM_BF16_GF32}", who, (int)(dtype)); \
+            return SHM_E_DTYPE;                                                \
+        }                                                                      \
+    } while (0)
 
 #define SHM_REQUIRE(cond, code, ...)  \
     do {                              \

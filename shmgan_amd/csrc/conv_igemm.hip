@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution family on v_mfma_f32_32x32x2_f32 (gfx950, exact fp32).
+// Implicit-GEMM convolution family on v_mfma_f32_32x32x2_f32 (exact fp32) and, for the bf16 path,
+// v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate) -- gfx950.
 //
 // One kernel ("tap GEMM") serves Conv2D forward (k=1/3, stride 1/2), its input-gradient
 // (stride 1: flipped taps; stride 2: four output phases) and Conv2DTranspose forward
@@ -7,16 +8,15 @@
 //     out[pix(m), n] = act( bias[n] + sum_{tap} sum_{k<K} A[src(m, tap), k] * B[tap][n][k] )
 //
 //   M = batch * grid_h * grid_w output positions of one phase, N = output channels,
-//   K = channels of the A tensor (multiple of 16).  A is NHWC (optionally the channel
-//   concat of two tensors), B is [tap][N][K] (K contiguous), so both operands are staged
-//   as rows of 16 consecutive floats: 16-byte global loads, ds_write_b128 into LDS rows
-//   padded to 20 floats (conflict-free ds_read_b128 per 16-lane group), and each lane
-//   feeds four consecutive MFMAs from one 16-byte LDS read (the k order inside an 8-wide
-//   group is permuted identically for A and B, which a dot product does not see).
+//   K = channels of the A tensor (multiple of 16 fp32 / 32 bf16).  A is NHWC (optionally the
+//   channel concat of two tensors), B is [tap][N][K] (K contiguous), so both operands are staged
+//   as 64-byte rows (16 floats or 32 bf16) and each lane feeds four consecutive f32 MFMAs (or one
+//   bf16 MFMA) from one 16-byte LDS read (the k order inside a group is permuted identically for
+//   A and B, which a dot product does not see).
 //
-// Block = 256 threads = 4 waves of 64x64 outputs each (2x2 MFMA tiles), block tile 128x128
-// (2x2 waves) or 256x64 (4x1 waves, for Cout <= 64), BK = 16, two LDS stages and two register
-// sets: global loads run two K-steps ahead of the MFMAs that consume them.
+// Block = 4 waves of 64x64 outputs each (2x2 MFMA tiles), block tile 128x128 (Cout > 64) or
+// 128x64; operands go HBM/L2 -> LDS by DMA three stages deep (tapgemm_dma_kernel), or through an
+// 18x18 LDS halo for unit-stride 3x3 layers (tapgemm_halo_kernel).
 #include "common.h"
 
 #include <stdlib.h>
@@ -28,14 +28,16 @@ struct TapPhase {
     int dh[9], dw[9], widx[9];
 };
 
-struct TapGemmArgs {
-    const float* x;   // A source 1 [batch, hi, wi, c1]   pitch ldx
-    const float* x2;  // A source 2 [batch, hi, wi, K-c1] pitch ldx2 (or unused, c1 == K)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (kernel template parameter T)
+    const void* x;    // A source 1 [batch, hi, wi, c1]   pitch ldx (elements)
+    const void* x2;   // A source 2 [batch, hi, wi, K-c1] pitch ldx2 (or unused, c1 == K)
     int c1, ldx, ldx2;
-    const float* w;     // [taps][nout][K]
+    const void* w;      // [taps][nout][K]
     const float* bias;  // [nout] or null
-    float* y;           // channels [0,n1)
-    float* y2;          // channels [n1,nout)
+    void* y;            // channels [0,n1)
+    void* y2;           // channels [n1,nout)
     int n1, ldy, ldy2;
     int hi, wi, K;      // A tensor dims
     int hg, wg;         // output grid of one phase
@@ -49,225 +51,24 @@ struct TapGemmArgs {
     TapPhase ph[4];
 };
 
-// BM x BN block tile, WGM x WGN waves (4 waves), every wave owns a 64x64 sub-tile (2x2 MFMA tiles).
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
-    static_assert(WGM * WGN == 4 && BM / WGM == 64 && BN / WGN == 64, "wave tile must be 64x64");
-    constexpr int LDK = 20;          // 16 + 4 pad floats per LDS row
-    constexpr int AR = BM / 64;      // A rows staged per thread
-    constexpr int BR = BN / 64;      // B rows staged per thread
-    constexpr int TM = 2, TN = 2;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
-
-    const TapPhase& P = a.ph[blockIdx.z];
-    const int tid = threadIdx.x, quad = tid & 3, lrow = tid >> 2;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    int pixbase[AR], ih0[AR], iw0[AR];
-    bool mval[AR];
+// One 16-byte fragment per operand tile: four f32 MFMAs (K = 2 each) or one bf16 MFMA (K = 16).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void tap_mfma(const f32x4 (&av)[TM], const f32x4 (&bv)[TN], f32x16 (&acc)[TM][TN]) {
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int j = 0; j < AR; ++j) {
-        int m = m0 + lrow + 64 * j;
-        mval[j] = m < a.M;
-        int mm = mval[j] ? m : 0;
-        int ow = mm % a.wg, t = mm / a.wg;
-        int oh = t % a.hg, n = t / a.hg;
-        ih0[j] = oh * a.is;
-        iw0[j] = ow * a.is;
-        pixbase[j] = (n * a.hi + ih0[j]) * a.wi + iw0[j];
-    }
-    const int ntaps = P.ntaps;
-    const int ksteps = ntaps * (a.K >> 4);
-
-    // K-step order: (32-channel group, tap, 16-channel half).  The two halves of a 128-byte line
-    // are read in consecutive steps (second one hits L1), and the 9 shifted reads of a group reuse
-    // the same input rows.  Everything advances incrementally; the tap-table entries of the NEXT
-    // load are fetched one step ahead so their scalar-load latency sits behind an MFMA block.
-    const int nch = a.K >> 4;
-    int ld_g = 0, ld_tap = 0, ld_sub = 0, ld_c0 = 0;    // position of the next gload
-    int t_dh = P.dh[0], t_dw = P.dw[0], t_wi = P.widx[0];
-    auto advance = [&]() {
-        const int nsub = (nch - ld_g) >= 2 ? 2 : 1;
-        if (++ld_sub == nsub) {
-            ld_sub = 0;
-            if (++ld_tap == ntaps) {
-                ld_tap = 0;
-                ld_g += 2;
-            }
-            t_dh = P.dh[ld_tap];
-            t_dw = P.dw[ld_tap];
-            t_wi = P.widx[ld_tap];
-        }
-        ld_c0 = (ld_g + ld_sub) << 4;
-    };
-    // Operands are fetched with raw buffer loads: a lane whose tap falls outside the image (SAME
-    // padding), whose row is past M or whose weight row is past N gets byte offset 0xffffffff,
-    // which the hardware range check turns into zeros.  No divergent branch around a load, so
-    // hipcc can wait with counted s_waitcnt vmcnt(N) and the loads really stay two steps ahead.
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
-    unsigned wrow[BR];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        int nn = n0 + lrow + 64 * j;
-        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + quad * 4) * 4u : 0xffffffffu;
-    }
-    auto gload = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
-        const int c0 = ld_c0;
-        const bool second = c0 >= a.c1;
-        const int ld = second ? a.ldx2 : a.ldx;
-        const int cc = (second ? c0 - a.c1 : c0) + quad * 4;
-        const int dh = t_dh, dw = t_dw;
-        const int doff = dh * a.wi + dw;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            int ih = ih0[j] + dh, iw = iw0[j] + dw;
-            bool ok = mval[j] && (unsigned)ih < (unsigned)a.hi && (unsigned)iw < (unsigned)a.wi;
-            unsigned off = ok ? (unsigned)((pixbase[j] + doff) * ld + cc) * 4u : 0xffffffffu;
-#ifdef SHM_ABL_SAMELINE
-            off = ok ? (unsigned)(quad * 16 + (off & 0x40u)) : 0xffffffffu;      // timing only: every lane hits one line
-#endif
-#ifdef SHM_ABL_NOADDR
-            off = (unsigned)(pixbase[j] * ld + quad * 4) * 4u;                  // timing only: no per-step address work
-#endif
-            u32x4 v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsx2, (int)off, 0, 0)
-                             : __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
-            ra[j] = __builtin_bit_cast(f32x4, v);
-        }
-        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * 4u;
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)off, 0, 0));
-        }
-        advance();
-    };
-    auto sstore = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < AR; ++j) *(f32x4*)(&As[buf][(lrow + 64 * j) * LDK + quad * 4]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < BR; ++j) *(f32x4*)(&Bs[buf][(lrow + 64 * j) * LDK + quad * 4]) = rb[j];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto compute = [&](int buf) {
-        const float* Ab = &As[buf][(wm * 64 + l31) * LDK + h * 4];
-        const float* Bb = &Bs[buf][(wn * 64 + l31) * LDK + h * 4];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f32x4 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // Two LDS stages, two register sets: the global loads of step s+2 are issued while step s is
-    // computed and are written to LDS at the end of step s+1 (two MFMA phases of flight time).
-    f32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
-    gload(ra0, rb0);
-    if (ksteps > 1) gload(ra1, rb1);
-    sstore(0, ra0, rb0);
-    __syncthreads();
-    int s = 0;
-#ifdef SHM_ABL_NOBAR
-#define SHM_BAR()
-#else
-#define SHM_BAR() __syncthreads()
-#endif
-#ifdef SHM_ABL_NOLOAD
-#define SHM_GLOAD(a_, b_)
-#else
-#define SHM_GLOAD(a_, b_) gload(a_, b_)
-#endif
-#ifdef SHM_ABL_NOSTORE
-#define SHM_SSTORE(i_, a_, b_)
-#else
-#define SHM_SSTORE(i_, a_, b_) sstore(i_, a_, b_)
-#endif
-#ifdef SHM_SCHED_PIN
-#define SHM_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SHM_PIN()
-#endif
-    for (; s + 3 < ksteps; s += 2) {      // steady state: steps s, s+1 computed, s+2, s+3 fetched
-        SHM_GLOAD(ra0, rb0);
-        compute(0);
-        SHM_PIN();
-        SHM_SSTORE(1, ra1, rb1);
-        SHM_BAR();
-        SHM_GLOAD(ra1, rb1);
-        compute(1);
-        SHM_PIN();
-        SHM_SSTORE(0, ra0, rb0);
-        SHM_BAR();
-    }
-    // tail: 1..3 steps left; buf0 holds step s, (ra1, rb1) hold step s+1 if it exists
-    const int left = ksteps - s;
-    if (left >= 3) gload(ra0, rb0);
-    compute(0);
-    if (left >= 2) {
-        sstore(1, ra1, rb1);
-        __syncthreads();
-        compute(1);
-        if (left >= 3) {
-            sstore(0, ra0, rb0);
-            __syncthreads();
-            compute(0);
-        }
-    }
-
-    // epilogue: bias + LeakyReLU + store.  C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-    const bool direct = (a.os == 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + wm * 64 + i * 32 + row;
-            if (m >= a.M) continue;
-            size_t opix;
-            if (direct) {
-                opix = (size_t)m;
-            } else {
-                int ow = m % a.wg, t = m / a.wg;
-                int oh = t % a.hg, n = t / a.hg;
-                opix = ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
-                if (n < a.nout) {
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[n];
-                    v = shm_lrelu(v, a.slope);
-                    if (n < a.n1)
-                        a.y[opix * a.ldy + n] = v;
-                    else
-                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
-                }
-            }
-        }
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[j]),
+                                                                   acc[i][j], 0, 0, 0);
     }
 }
 
@@ -280,9 +81,14 @@ __global__ __launch_bounds__(256, 3) void tapgemm_kernel(const TapGemmArgs a) {
 // the descriptor's range check makes the DMA write zeros (tools/ldsdma_probe.hip).
 // Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
 // counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
-template <int BM, int BN, int WGM, int WGN, int NST, int BK>
+// T = float or bf16_t.  BK counts 4-byte words per LDS row (16 -> 64-byte rows); a K step covers
+// BKE = BK*4/sizeof(T) channels.
+template <typename T, typename TO, int BM, int BN, int WGM, int WGN, int NST, int BK>
 __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGemmArgs a) {
-    static_assert(BK == 16 || BK == 32, "K step of 16 (64-byte LDS rows) or 32 (128-byte rows)");
+    static_assert(BK == 16 || BK == 32, "K step of 16 words (64-byte LDS rows) or 32 (128-byte rows)");
+    constexpr int ESZ = sizeof(T);
+    constexpr int BKE = BK * 4 / ESZ;                // channels per K step
+    constexpr int CHE = 16 / ESZ;                    // channels per 16-byte chunk
     constexpr int NW = WGM * WGN;                    // waves per block (4 or 8)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -321,9 +127,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const int oh = t % a.hg, n = t / a.hg;
         const int ih0 = oh * a.is, iw0 = ow * a.is;
         const int pixbase = (n * a.hi + ih0) * a.wi + iw0;
-        const int acoff = (dq ^ ((row >> SWS) & SWM)) * 4;   // swizzled channel offset inside the K step
-        rowb1[j] = (unsigned)(pixbase * a.ldx + acoff) * 4u;
-        rowb2[j] = (unsigned)(pixbase * a.ldx2 + acoff) * 4u;
+        const int acoff = (dq ^ ((row >> SWS) & SWM)) * CHE;   // swizzled channel offset inside the K step
+        rowb1[j] = (unsigned)(pixbase * a.ldx + acoff) * (unsigned)ESZ;
+        rowb2[j] = (unsigned)(pixbase * a.ldx2 + acoff) * (unsigned)ESZ;
         unsigned mk = 0;
         for (int tp = 0; tp < P.ntaps; ++tp) {
             const int ih = ih0 + P.dh[tp], iw = iw0 + P.dw[tp];
@@ -336,14 +142,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     for (int j = 0; j < NB; ++j) {
         const int row = wave * (BN / NW) + RPI * j + drow;
         const int nn = n0 + row;
-        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> SWS) & SWM)) * 4) * 4u : 0xffffffffu;
+        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> SWS) & SWM)) * CHE) * (unsigned)ESZ : 0xffffffffu;
     }
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
 
     const int ntaps = P.ntaps;
-    const int nch = a.K / BK;
+    const int nch = a.K / BKE;
     const int ksteps = ntaps * nch;
     // The tap table lives in two VGPRs (lane t holds tap t) and is read with v_readlane: a scalar
     // memory load inside the K loop would share lgkmcnt with the ds_reads and force every fragment
@@ -356,7 +162,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         if (BK == 32) {                          // (chunk, tap): a step already covers a whole 128-B line
             if (++ld_tap == ntaps) {
                 ld_tap = 0;
-                ld_c0 += 32;
+                ld_c0 += BKE;
             }
             return;
         }
@@ -368,7 +174,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 ld_g += 2;
             }
         }
-        ld_c0 = (ld_g + ld_sub) << 4;
+        ld_c0 = (ld_g + ld_sub) * BKE;
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto dma = [&](int stage) {
@@ -380,7 +186,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const int cc = second ? c0 - a.c1 : c0;
         const int t_off = __builtin_amdgcn_readlane(tapoff_v, ld_tap);
         const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
-        const unsigned stepb = (unsigned)(t_off * ld + cc) * 4u;                     // wave-uniform
+        const unsigned stepb = (unsigned)(t_off * ld + cc) * (unsigned)ESZ;          // wave-uniform
         const unsigned tbit = 1u << ld_tap;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -396,7 +202,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sa + j * 256), 16, (int)off, 0, 0, 0);
         }
-        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * 4u;
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + c0) * (unsigned)ESZ;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
@@ -433,13 +239,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(Ab + i * 32 * BK + fo[kk]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(Bb + j * 32 * BK + fo[kk]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+            tap_mfma<T, TM, TN>(av, bv, acc);
         }
     };
 
@@ -493,13 +293,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 if (n < a.nout) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[n];
-                    v = shm_lrelu(v, a.slope);
+                    const TO vo = (TO)shm_lrelu(v, a.slope);
+                    v = (float)vo;                       // statistics of the value as stored
                     s1[j] += v;
                     s2[j] += v * v;
                     if (n < a.n1)
-                        a.y[opix * a.ldy + n] = v;
+                        ((TO*)a.y)[opix * a.ldy + n] = vo;
                     else
-                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
+                        ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
                 }
             }
         }
@@ -535,7 +336,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // two taps ahead).  Per tap a wave issues 1 DMA instruction instead of 4, and the A operand moves
 // 6.4x fewer bytes.  Same LDS row format as tapgemm_dma_kernel: 64-byte rows, chunk ^= (row>>2)&3
 // applied on the DMA source side; halo pixels outside the image use offset 0xffffffff (zeros).
+template <typename T, typename TO>
 __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) {
+    constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
     constexpr int BN = 128, WGN = 2;                  // 8 waves: 4 (M) x 2 (N)
     constexpr int HC = 18, NHR = 384;                 // halo 18 x 18 = 324 rows, padded to 24 DMA items
     constexpr int ASTG = NHR * 16, BSTG = BN * 16;    // floats per stage
@@ -566,31 +369,31 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
         const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
         const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
         const int pix = (img * a.hi + iy) * a.wi + ix;
-        const int coff = (dq ^ ((hrow >> 2) & 3)) * 4;
-        arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * 4u : 0xffffffffu;
-        arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * 4u : 0xffffffffu;
+        const int coff = (dq ^ ((hrow >> 2) & 3)) * CHE;
+        arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * (unsigned)ESZ : 0xffffffffu;
+        arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * (unsigned)ESZ : 0xffffffffu;
     }
     unsigned wrow;
     {
         const int row = wave * 16 + drow;                  // B rows [16 wave, 16 wave + 16)
         const int nn = n0 + row;
-        wrow = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * 4) * 4u : 0xffffffffu;
+        wrow = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * CHE) * (unsigned)ESZ : 0xffffffffu;
     }
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
 
-    const int nch = a.K >> 4;
+    const int nch = a.K / BKE;
     const int ksteps = 9 * nch;
     // tap table in VGPR lanes: halo row shift (dh*18 + dw) and weight slice of tap `lane`
     const int tl = lane < 9 ? lane : 0;
     const int tapsh_v = P.dh[tl] * HC + P.dw[tl];
     const int tapw_v = P.widx[tl];
 
-    auto dma_a = [&](int chunk) {                  // halo of 16-channel chunk `chunk` into A stage chunk & 1
-        const int c0 = chunk << 4;
+    auto dma_a = [&](int chunk) {                  // halo of 64-byte channel chunk `chunk` into A stage chunk & 1
+        const int c0 = chunk * BKE;
         const bool second = c0 >= a.c1;
-        const unsigned cb = (unsigned)(second ? c0 - a.c1 : c0) * 4u;
+        const unsigned cb = (unsigned)(second ? c0 - a.c1 : c0) * (unsigned)ESZ;
         float* dst = sA + (chunk & 1) * ASTG + wave * 256;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -605,7 +408,7 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
     int ld_tap = 0, ld_chunk = 0, ld_stage = 0;    // position of the next weight DMA
     auto dma_b = [&]() {
         const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
-        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (ld_chunk << 4)) * 4u;
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + ld_chunk * BKE) * (unsigned)ESZ;
         const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sB + ld_stage * BSTG + wave * 256), 16, (int)off, 0, 0, 0);
         if (++ld_tap == 9) {
@@ -650,13 +453,7 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
             for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(Ab + fa[i][kk]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+            tap_mfma<T, 2, 2>(av, bv, acc);
         }
     };
 
@@ -706,13 +503,14 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
                 if (n < a.nout) {
                     float v = acc[i][j][r];
                     if (a.bias) v += a.bias[n];
-                    v = shm_lrelu(v, a.slope);
+                    const TO vo = (TO)shm_lrelu(v, a.slope);
+                    v = (float)vo;
                     s1[j] += v;
                     s2[j] += v * v;
                     if (n < a.n1)
-                        a.y[opix * a.ldy + n] = v;
+                        ((TO*)a.y)[opix * a.ldy + n] = vo;
                     else
-                        a.y2[opix * a.ldy2 + (n - a.n1)] = v;
+                        ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
                 }
             }
         }
@@ -735,22 +533,65 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0;
 
-static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
+template <typename T, typename TO>
+static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStream_t st) {
+    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
+    static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
+    static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
+    constexpr int BKE = 64 / (int)sizeof(T);
+    if (use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && a.nout > 64 && a.hi % 16 == 0 && a.wi % 16 == 0 &&
+        a.hg == a.hi && a.wg == a.wi) {
+        bool unit = true;                      // every tap within the 1-pixel halo
+        for (int t = 0; t < 9; ++t) unit = unit && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
+        // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
+        // grid quantization than the halo reuse gains in fp32 (measured: 32x32 maps 113 vs 133 TFLOP/s).
+        // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
+        static const int halo_min = getenv("SHM_TAPGEMM_HALO_MIN") ? atoi(getenv("SHM_TAPGEMM_HALO_MIN")) : 1024;
+        const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
+        if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
+            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO>), grid, dim3(512), 0, st, a);
+            return;
+        }
+    }
+    auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
+    static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
+    if (a.nout > 64 && bk32 && a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0)) {
+        if (bk32 == 2)
+            hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
+    } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
+    } else if (a.nout > 64) {
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
+    } else if (dma_small == 0) {
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 2, 16>), grid1d(256, 64), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
+    }
+}
+
+static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipStream_t st, const char* who) {
+    SHM_REQUIRE(dtype == SHM_F32 || dtype == SHM_BF16 || dtype == SHM_BF16_GF32, SHM_E_DTYPE,
+                "%s: dtype %d not in {SHM_F32, SHM_BF16, SHM_BF16_GF32}", who, dtype);
     a.stats = g_conv_stats;
     a.hw = g_conv_hw;
-    SHM_REQUIRE(a.K % 16 == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of 16", who, a.K);
-    SHM_REQUIRE(a.c1 % 16 == 0, SHM_E_SHAPE, "%s: concat split %d must be a multiple of 16", who, a.c1);
-    SHM_REQUIRE(a.ldx % 4 == 0 && (a.x2 == nullptr || a.ldx2 % 4 == 0), SHM_E_SHAPE, "%s: input pitch must be a multiple of 4", who);
+    SHM_REQUIRE(dtype != SHM_BF16_GF32 || a.stats == nullptr, SHM_E_DTYPE, "%s: SHM_BF16_GF32 has no fused statistics", who);
+    const int esz = dtype == SHM_F32 ? 4 : 2, bke = 64 / esz, che = 16 / esz;
+    SHM_REQUIRE(a.K % bke == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of %d", who, a.K, bke);
+    SHM_REQUIRE(a.c1 % bke == 0, SHM_E_SHAPE, "%s: concat split %d must be a multiple of %d", who, a.c1, bke);
+    SHM_REQUIRE(a.ldx % che == 0 && (a.x2 == nullptr || a.ldx2 % che == 0), SHM_E_SHAPE, "%s: input pitch must be a multiple of 16 bytes", who);
     SHM_REQUIRE((size_t)batch * a.hi * a.wi < (1u << 31) && (size_t)batch * a.ho * a.wo < (1u << 31), SHM_E_SHAPE, "%s: pixel count overflows int32", who);
     a.M = batch * a.hg * a.wg;
     if (a.M == 0 || a.nout == 0) return SHM_OK;
     {
         const size_t lim = 0xfffffff0ull;
-        size_t xb = (size_t)batch * a.hi * a.wi * a.ldx * 4, x2b = a.x2 ? (size_t)batch * a.hi * a.wi * a.ldx2 * 4 : 0;
+        size_t xb = (size_t)batch * a.hi * a.wi * a.ldx * esz, x2b = a.x2 ? (size_t)batch * a.hi * a.wi * a.ldx2 * esz : 0;
         size_t wb = 0;
         for (int p = 0; p < nphase; ++p)
             for (int t = 0; t < a.ph[p].ntaps; ++t) {
-                size_t e = (size_t)(a.ph[p].widx[t] + 1) * a.nout * a.K * 4;
+                size_t e = (size_t)(a.ph[p].widx[t] + 1) * a.nout * a.K * esz;
                 if (e > wb) wb = e;
             }
         SHM_REQUIRE(xb < lim && x2b < lim && wb < lim, SHM_E_SHAPE, "%s: operand larger than 4 GiB (32-bit buffer offsets)", who);
@@ -758,64 +599,25 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, hipStream_t st,
         a.x2bytes = (unsigned)x2b;
         a.wbytes = (unsigned)wb;
     }
-    static const int use_dma = getenv("SHM_TAPGEMM_REG") ? 0 : 1;
-    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
-    static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
-    static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
-    if (use_dma && use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && a.nout > 64 &&
-        a.hi % 16 == 0 && a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi) {
-        bool unit = true;                      // every tap within the 1-pixel halo
-        for (int t = 0; t < 9; ++t) unit = unit && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
-        // 2 blocks of 8 waves per CU = 512 slots: below ~4 rounds the coarser (256-row) tiles lose more to
-        // grid quantization than the halo reuse gains (measured: 32x32 maps 113 vs 133 TFLOP/s)
-        static const int halo_min = getenv("SHM_TAPGEMM_HALO_MIN") ? atoi(getenv("SHM_TAPGEMM_HALO_MIN")) : 1024;
-        const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
-        if (unit && nblk >= halo_min) {
-            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
-            hipLaunchKernelGGL(tapgemm_halo_kernel, grid, dim3(512), 0, st, a);
-            SHM_LAUNCH_CHECK(who);
-            return SHM_OK;
-        }
-    }
-    if (use_dma) {
-        auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
-        static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
-        if (a.nout > 64 && bk32 && a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0)) {
-            if (bk32 == 2)
-                hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
-        } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
-        } else if (a.nout > 64) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
-        } else if (dma_small == 0) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<256, 64, 4, 1, 2, 16>), grid1d(256, 64), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
-        }
-        SHM_LAUNCH_CHECK(who);
-        return SHM_OK;
-    }
-    if (a.nout > 64) {
-        dim3 grid(shm_cdiv(a.M, 128), shm_cdiv(a.nout, 128), nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
-    } else {
-        dim3 grid(shm_cdiv(a.M, 256), 1, nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, a);
-    }
+    if (dtype == SHM_BF16)
+        launch_tapgemm_t<bf16_t, bf16_t>(a, batch, nphase, st);
+    else if (dtype == SHM_BF16_GF32)
+        launch_tapgemm_t<bf16_t, float>(a, batch, nphase, st);
+    else
+        launch_tapgemm_t<float, float>(a, batch, nphase, st);
     SHM_LAUNCH_CHECK(who);
     return SHM_OK;
 }
 
 // ------------------------------------------------------------------------------------
 // [ntaps][rows][cols] -> [ntaps][cols][rows_pad]
-__global__ void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols, int rows_pad) {
+template <typename T>
+__global__ void transpose_taps_kernel(const float* __restrict__ w, T* __restrict__ wt, int rows, int cols, int rows_pad) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const float* src = w + (size_t)t * rows * cols;
-    float* dst = wt + (size_t)t * cols * rows_pad;
+    T* dst = wt + (size_t)t * cols * rows_pad;
     for (int i = threadIdx.y; i < 32; i += blockDim.y) {
         int r = r0 + i, c = c0 + threadIdx.x;
         tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
@@ -823,22 +625,26 @@ __global__ void transpose_taps_kernel(const float* __restrict__ w, float* __rest
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += blockDim.y) {
         int c = c0 + i, r = r0 + threadIdx.x;
-        if (c < cols && r < rows_pad) dst[(size_t)c * rows_pad + r] = tile[threadIdx.x][i];
+        if (c < cols && r < rows_pad) dst[(size_t)c * rows_pad + r] = (T)tile[threadIdx.x][i];
     }
 }
 
-extern "C" int shm_transpose_taps(const float* w, float* wt, int ntaps, int rows, int cols, int rows_pad, void* stream) {
+extern "C" int shm_transpose_taps(const float* w, void* wt, int ntaps, int rows, int cols, int rows_pad, int dtype, void* stream) {
     SHM_REQUIRE(rows_pad >= rows && ntaps > 0 && rows > 0 && cols > 0, SHM_E_SHAPE, "shm_transpose_taps: bad shape");
+    SHM_REQUIRE(dtype == SHM_F32 || dtype == SHM_BF16, SHM_E_DTYPE, "shm_transpose_taps: bad dtype %d", dtype);
     dim3 grid(shm_cdiv(cols, 32), shm_cdiv(rows_pad, 32), ntaps);
-    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, w, wt, rows, cols, rows_pad);
+    if (dtype == SHM_BF16)
+        hipLaunchKernelGGL(transpose_taps_kernel<bf16_t>, grid, dim3(32, 8), 0, (hipStream_t)stream, w, (bf16_t*)wt, rows, cols, rows_pad);
+    else
+        hipLaunchKernelGGL(transpose_taps_kernel<float>, grid, dim3(32, 8), 0, (hipStream_t)stream, w, (float*)wt, rows, cols, rows_pad);
     SHM_LAUNCH_CHECK("shm_transpose_taps");
     return SHM_OK;
 }
 
 // ------------------------------------------------------------------------------------
-extern "C" int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
-                              const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
-                              int cout, int ksize, int stride, float slope, void* stream) {
+extern "C" int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
+                              const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
+                              int cout, int ksize, int stride, float slope, int dtype, void* stream) {
     SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_fwd: ksize %d not in {1,3}", ksize);
     SHM_REQUIRE(stride == 1 || stride == 2, SHM_E_SHAPE, "shm_conv2d_fwd: stride %d not in {1,2}", stride);
     SHM_REQUIRE(x && wk && y, SHM_E_SHAPE, "shm_conv2d_fwd: null pointer");
@@ -877,31 +683,31 @@ extern "C" int shm_conv2d_fwd(const float* x, const float* x2, int c1, int ldx, 
             P.dw[t] = kw - pl;
             P.widx[t] = t;
         }
-    return launch_tapgemm(a, batch, 1, (hipStream_t)stream, "shm_conv2d_fwd");
+    return launch_tapgemm(a, batch, 1, dtype, (hipStream_t)stream, "shm_conv2d_fwd");
 }
 
 int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipStream_t st);
 
-extern "C" int shm_conv2d_in_fwd(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* wk,
-                                 const float* bias, float* y, int ldy, int batch, int hi, int wi, int cin,
+extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
+                                 const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                                  int cout, int ksize, int stride, float slope, double* stats, float eps,
-                                 void* stream) {
+                                 int dtype, void* stream) {
     SHM_REQUIRE(stats, SHM_E_SHAPE, "shm_conv2d_in_fwd: null stats");
     int ho, wo, pt;
     shm_same_pad(hi, ksize, stride, &ho, &pt);
     shm_same_pad(wi, ksize, stride, &wo, &pt);
     const int hw = ho * wo;
     static const int fuse = getenv("SHM_NO_STATS_FUSION") ? 0 : 1;
-    if (!fuse || hw % 64 != 0 || getenv("SHM_TAPGEMM_REG")) {       // tiny maps: separate statistics pass
-        int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stream);
+    if (!fuse || hw % 64 != 0) {       // tiny maps: separate statistics pass
+        int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
         if (r) return r;
-        return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, stream);
+        return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, dtype, stream);
     }
     int r = shm_zero(stats, (size_t)batch * cout * 2 * sizeof(double), stream);
     if (r) return r;
     g_conv_stats = stats;
     g_conv_hw = hw;
-    r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stream);
+    r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
     g_conv_stats = nullptr;
     if (r) return r;
     return shm_in_finalize_internal(stats, batch * cout, hw, (double)eps, (hipStream_t)stream);
@@ -930,9 +736,9 @@ static void fill_s2_phases(TapGemmArgs& a, int pt, int pl) {
         }
 }
 
-extern "C" int shm_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, float* dx2, int n1,
+extern "C" int shm_conv2d_dgrad(const void* dy, int lddy, const void* w, void* dx, void* dx2, int n1,
                                 int lddx, int lddx2, int batch, int hi, int wi, int cin, int cout,
-                                int ksize, int stride, void* stream) {
+                                int ksize, int stride, int dtype, void* stream) {
     SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_dgrad: ksize %d not in {1,3}", ksize);
     SHM_REQUIRE(stride == 1 || (stride == 2 && ksize == 3), SHM_E_SHAPE, "shm_conv2d_dgrad: stride %d unsupported", stride);
     SHM_REQUIRE(dy && w && dx, SHM_E_SHAPE, "shm_conv2d_dgrad: null pointer");
@@ -973,19 +779,19 @@ extern "C" int shm_conv2d_dgrad(const float* dy, int lddy, const float* w, float
                 P.dw[t] = pl - kw;
                 P.widx[t] = t;
             }
-        return launch_tapgemm(a, batch, 1, (hipStream_t)stream, "shm_conv2d_dgrad");
+        return launch_tapgemm(a, batch, 1, dtype, (hipStream_t)stream, "shm_conv2d_dgrad");
     }
     SHM_REQUIRE(hi % 2 == 0 && wi % 2 == 0, SHM_E_SHAPE, "shm_conv2d_dgrad: stride 2 needs even input size");
     a.hg = hi / 2;
     a.wg = wi / 2;
     a.os = 2;
     fill_s2_phases(a, pt, pl);
-    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_dgrad");
+    return launch_tapgemm(a, batch, 4, dtype, (hipStream_t)stream, "shm_conv2d_dgrad");
 }
 
-extern "C" int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+extern "C" int shm_conv2d_transpose_fwd(const void* x, int ldx, const void* w, const float* bias, void* y,
                                         int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
-                                        void* stream) {
+                                        int dtype, void* stream) {
     SHM_REQUIRE(x && w && y, SHM_E_SHAPE, "shm_conv2d_transpose_fwd: null pointer");
     // the stride-2 SAME conv that maps [2hi,2wi] back to [hi,wi] has pad_before = 0
     int ho2, wo2, pt, pl;
@@ -1014,14 +820,14 @@ extern "C" int shm_conv2d_transpose_fwd(const float* x, int ldx, const float* w,
     a.os = 2;
     a.slope = slope;
     fill_s2_phases(a, pt, pl);
-    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_transpose_fwd");
+    return launch_tapgemm(a, batch, 4, dtype, (hipStream_t)stream, "shm_conv2d_transpose_fwd");
 }
 
 // Keras Conv2DTranspose(k=2, strides=2) (SpecSeg.py:63,69,75,81): non-overlapping, every output
 // phase (ph, pw) is a 1x1 product with its own tap: y[2a+ph, 2b+pw] = bias + x[a, b] . w[ph][pw].
-extern "C" int shm_conv2d_transpose2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+extern "C" int shm_conv2d_transpose2x2_fwd(const void* x, int ldx, const void* w, const float* bias, void* y,
                                            int ldy, int batch, int hi, int wi, int cin, int cout, float slope,
-                                           void* stream) {
+                                           int dtype, void* stream) {
     SHM_REQUIRE(x && w && y, SHM_E_SHAPE, "shm_conv2d_transpose2x2_fwd: null pointer");
     TapGemmArgs a{};
     a.x = x;
@@ -1053,5 +859,5 @@ extern "C" int shm_conv2d_transpose2x2_fwd(const float* x, int ldx, const float*
         P.dh[0] = P.dw[0] = 0;
         P.widx[0] = p;
     }
-    return launch_tapgemm(a, batch, 4, (hipStream_t)stream, "shm_conv2d_transpose2x2_fwd");
+    return launch_tapgemm(a, batch, 4, dtype, (hipStream_t)stream, "shm_conv2d_transpose2x2_fwd");
 }

@@ -1,4 +1,5 @@
-// Convolution weight gradient on v_mfma_f32_32x32x2_f32 (gfx950, exact fp32).
+// Convolution weight gradient on v_mfma_f32_32x32x2_f32 (exact fp32) and, for the bf16 path, on
+// v_mfma_f32_32x32x16_bf16 with transposed LDS reads (wgrad_bf16_kernel) -- gfx950.
 //
 //   dW[tap][ci][co] = sum_{pixels p} X[src(p, tap)][ci] * dY[p][co]
 //
@@ -18,11 +19,11 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct WgradArgs {
-    const float* x;
-    const float* x2;
+struct WgradArgs {            // x, x2, dy: float (wgrad_kernel) or bf16 (wgrad_bf16_kernel) tensors
+    const void* x;
+    const void* x2;
     int c1, ldx, ldx2;
-    const float* dy;
+    const void* dy;
     int lddy;
     float* part;
     int hi, wi, ho, wo;
@@ -230,6 +231,198 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 operands, fp32 accumulation: v_mfma_f32_32x32x16_bf16 contracts 16 pixels per instruction.
+// Both operands are pixel-major ([pixel][channel], channels contiguous) but the MFMA wants, per lane,
+// 8 consecutive PIXELS of one channel: the LDS image keeps the HBM layout (128-byte rows of 64
+// channels) and the fragments are fetched with ds_read_b64_tr_b16 (hardware transpose: a 16-lane group
+// reads a 4-pixel x 16-channel block column-major).  Rows whose index has bit 1 set hold their two
+// 64-byte halves swapped, which makes the four rows x two channel blocks a 32-lane half reads hit 32
+// distinct 8-byte bank pairs.  Stage = 16 pixels; same work split, split-K slabs and (register
+// staged, two-stages-ahead) pipeline as wgrad_kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* base) {
+    // pixels [0,4) and [4,8) of this lane's k group: two transposed reads 4 rows (512 B) apart
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 4 * 64));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NT, bool STRADDLE>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
+    constexpr int BKP = 16;
+    constexpr int NTL = (NT + 1) / 2;          // tap loads per thread
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2][NT][BKP][64];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2][BKP][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int mi = wave >> 1, ni = wave & 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int p_begin = blockIdx.z * a.pix_per_split;
+    const int p_end = min(a.M, p_begin + a.pix_per_split);
+    const int nstages = (p_end - p_begin + BKP - 1) / BKP;
+
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);      // wave-uniform: waves 0,1 / 2,3
+    const int k = (tid >> 3) & 15, c8 = tid & 7;                    // pixel slot, 8-channel (16-byte) lane
+    const int c = ci0 + c8 * 8;
+    const bool second = STRADDLE ? (c >= a.c1) : (ci0 >= a.c1);
+    const bool xvalid = c < a.cin_ld;
+    const int ld = second ? a.ldx2 : a.ldx;
+    const int cc = second ? c - a.c1 : c;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    constexpr int KS = NT == 9 ? 3 : 1;
+    int tofb[NTL];
+    unsigned tbit[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int t = half + 2 * j;
+        const bool tv = t < NT;
+        const int tt = tv ? t : 0;
+        tofb[j] = (a.dh[tt] * a.wi + a.dw[tt]) * ld * 2;
+        tbit[j] = tv ? (1u << tt) : 0u;
+    }
+    int rdh[KS], cdw[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        rdh[i] = a.dh[i * KS];
+        cdw[i] = a.dw[i];
+    }
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    const int co = co0 + c8 * 8;
+    const bool dvalid = (co < a.cout) && half == 0;
+
+    int p = p_begin + k;
+    int ow, oh, n;
+    {
+        const int pp = p < a.M ? p : 0;
+        ow = pp % a.wo;
+        const int t2 = pp / a.wo;
+        oh = t2 % a.ho;
+        n = t2 / a.ho;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto gload = [&](u32x4 (&rx)[NTL], u32x4& rd) {
+        const bool ok = p < p_end;
+        const int ihb = oh * a.is, iwb = ow * a.is;
+        const unsigned base = (unsigned)(((n * a.hi + ihb) * a.wi + iwb) * ld + cc) * 2u;
+        unsigned rm = 0, cm = 0;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            rm |= ((unsigned)(ihb + rdh[i]) < (unsigned)a.hi ? 1u : 0u) << i;
+            cm |= ((unsigned)(iwb + cdw[i]) < (unsigned)a.wi ? 1u : 0u) << i;
+        }
+        unsigned m9 = 0;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) m9 |= (rm & (1u << i)) ? (cm << (i * KS)) : 0u;
+        if (!(ok && xvalid)) m9 = 0;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const unsigned off = (m9 & tbit[j]) ? base + (unsigned)tofb[j] : 0xffffffffu;
+            if (STRADDLE) {
+                u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(second ? 0xffffffffu : off), 0, 0);
+                u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(second ? off : 0xffffffffu), 0, 0);
+                rx[j] = v1 | v2;
+            } else {
+                rx[j] = second ? __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)off, 0, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)off, 0, 0);
+            }
+        }
+        const unsigned offd = (ok && dvalid) ? (unsigned)(p * a.lddy + co) * 2u : 0xffffffffu;
+        rd = __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)offd, 0, 0);
+        p += BKP;
+        ow += BKP;
+        if (ow >= a.wo) {
+            do {
+                ow -= a.wo;
+                if (++oh == a.ho) {
+                    oh = 0;
+                    ++n;
+                }
+            } while (ow >= a.wo);
+        }
+    };
+    const int scol = (c8 ^ (((k >> 1) & 1) << 2)) * 8;              // swizzled 16-byte chunk of this thread's row
+    auto sstore = [&](int buf, const u32x4 (&rx)[NTL], const u32x4& rd) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int t = half + 2 * j;
+            if (t < NT) *(u32x4*)(&Xs[buf][t][k][scol]) = rx[j];
+        }
+        if (half == 0) *(u32x4*)(&Ds[buf][k][scol]) = rd;
+    };
+    // transposed-read addressing: lane (group g = lane>>4, i = lane&15) supplies row 8h + (i>>2) (+4 for the
+    // second read) and the 4 channels [32*tile + 16*(g&1) + 4*(i&3), +4)
+    const int frow = 8 * h + ((lane & 15) >> 2);
+    const int fsw = ((frow >> 1) & 1) << 5;
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int fa = frow * 64 + ((mi * 32 + fcol) ^ fsw);
+    const int fb = frow * 64 + ((ni * 32 + fcol) ^ fsw);
+    auto compute = [&](int buf) {
+        const bf16x8 bv = tr_frag(&Ds[buf][0][0] + fb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 av = tr_frag(&Xs[buf][t][0][0] + fa);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+        }
+    };
+
+    if (nstages > 0) {
+        u32x4 rx0[NTL], rx1[NTL], rd0, rd1;
+        gload(rx0, rd0);
+        if (nstages > 1) gload(rx1, rd1);
+        sstore(0, rx0, rd0);
+        __syncthreads();
+        int s = 0;
+        for (; s + 3 < nstages; s += 2) {
+            gload(rx0, rd0);
+            compute(0);
+            sstore(1, rx1, rd1);
+            __syncthreads();
+            gload(rx1, rd1);
+            compute(1);
+            sstore(0, rx0, rd0);
+            __syncthreads();
+        }
+        const int left = nstages - s;
+        if (left >= 3) gload(rx0, rd0);
+        compute(0);
+        if (left >= 2) {
+            sstore(1, rx1, rd1);
+            __syncthreads();
+            compute(1);
+            if (left >= 3) {
+                sstore(0, rx0, rd0);
+                __syncthreads();
+                compute(0);
+            }
+        }
+    }
+
+    float* out = a.part + (size_t)blockIdx.z * NT * a.cin * a.cout;
+    const int con = co0 + ni * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 / stride-1 weight gradient with an LDS halo patch.
 //
 // A stage is a patch of 2 x 16 output pixels of one image.  Its 4 x 18 input halo (64 channels)
@@ -241,10 +434,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // s_waitcnt vmcnt, raw s_barrier.  Work split: block = (64 ci, 64 co, slice of patches); wave w
 // owns the 32x32 sub-tile (w>>1, w&1) of all nine taps; partial slabs as in wgrad_kernel.
 struct WgradHaloArgs {
-    const float* x;
-    const float* x2;
+    const void* x;
+    const void* x2;
     int c1, ldx, ldx2;
-    const float* dy;
+    const void* dy;
     int lddy;
     float* part;
     int h, w, cin_ld, cin, cout;
@@ -423,17 +616,19 @@ extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin,
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
 
-extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx, int ldx2, const float* dy,
+extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
                                 int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
                                 int cout, int ksize, int stride, int accumulate, void* workspace,
-                                size_t ws_bytes, void* stream) {
+                                size_t ws_bytes, int dtype, void* stream) {
+    SHM_REQUIRE(dtype == SHM_F32 || dtype == SHM_BF16, SHM_E_DTYPE, "shm_conv2d_wgrad: dtype %d not in {SHM_F32, SHM_BF16}", dtype);
+    const int esz = dtype == SHM_BF16 ? 2 : 4, vec = 16 / esz;      // 16-byte loads: 4 floats / 8 bf16
     SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_wgrad: ksize %d not in {1,3}", ksize);
     SHM_REQUIRE(stride == 1 || stride == 2, SHM_E_SHAPE, "shm_conv2d_wgrad: stride %d not in {1,2}", stride);
     SHM_REQUIRE(x && dy && dw && workspace, SHM_E_SHAPE, "shm_conv2d_wgrad: null pointer");
-    SHM_REQUIRE(cin_ld % 4 == 0 && cin_ld >= cin && cout % 4 == 0, SHM_E_SHAPE,
-                "shm_conv2d_wgrad: cin_ld %d / cout %d must be multiples of 4", cin_ld, cout);
-    SHM_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && (!x2 || (ldx2 % 4 == 0 && c1 % 4 == 0)), SHM_E_SHAPE,
-                "shm_conv2d_wgrad: pitches must be multiples of 4");
+    SHM_REQUIRE(cin_ld % vec == 0 && cin_ld >= cin && cout % vec == 0, SHM_E_SHAPE,
+                "shm_conv2d_wgrad: cin_ld %d / cout %d must be multiples of %d", cin_ld, cout, vec);
+    SHM_REQUIRE(ldx % vec == 0 && lddy % vec == 0 && (!x2 || (ldx2 % vec == 0 && c1 % vec == 0)), SHM_E_SHAPE,
+                "shm_conv2d_wgrad: pitches must be multiples of %d", vec);
     int ho, wo, pt, pl;
     shm_same_pad(hi, ksize, stride, &ho, &pt);
     shm_same_pad(wi, ksize, stride, &wo, &pl);
@@ -467,8 +662,8 @@ extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx
     SHM_REQUIRE(ws_bytes >= need, SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     {
         const size_t lim = 0xfffffff0ull;
-        size_t xb = (size_t)batch * hi * wi * ldx * 4, x2b = x2 ? (size_t)batch * hi * wi * ldx2 * 4 : 0;
-        size_t db = (size_t)batch * ho * wo * lddy * 4;
+        size_t xb = (size_t)batch * hi * wi * ldx * esz, x2b = x2 ? (size_t)batch * hi * wi * ldx2 * esz : 0;
+        size_t db = (size_t)batch * ho * wo * lddy * esz;
         SHM_REQUIRE(xb < lim && x2b < lim && db < lim, SHM_E_SHAPE, "shm_conv2d_wgrad: operand larger than 4 GiB (32-bit buffer offsets)");
         a.xbytes = (unsigned)xb;
         a.x2bytes = (unsigned)x2b;
@@ -481,7 +676,20 @@ extern "C" int shm_conv2d_wgrad(const float* x, const float* x2, int c1, int ldx
     hipStream_t st = (hipStream_t)stream;
     const bool straddle = x2 && (c1 % 64 != 0);
     static const int no_halo = getenv("SHM_WGRAD_NOHALO") ? 1 : 0;
-    if (ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo) {
+    if (dtype == SHM_BF16) {
+        dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
+        if (ksize == 3) {
+            if (straddle)
+                hipLaunchKernelGGL((wgrad_bf16_kernel<9, true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_bf16_kernel<9, false>), grid, dim3(256), 0, st, a);
+        } else {
+            if (straddle)
+                hipLaunchKernelGGL((wgrad_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
+        }
+    } else if (ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo) {
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;

@@ -42,6 +42,21 @@ extern "C" int shm_cvt_f64_f32(const double* src, float* dst, size_t n, int accu
     return SHM_OK;
 }
 
+// f32 -> activation dtype copy (bf16 operand copies of the fp32 master weights)
+template <typename T>
+__global__ void cast_f32_kernel(const float* __restrict__ s, T* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (T)s[i];
+}
+
+extern "C" int shm_cast_f32(const float* src, void* dst, size_t n, int dtype, void* stream) {
+    if (n == 0) return SHM_OK;
+    long blocks = (long)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    SHM_DISPATCH(dtype, "shm_cast_f32", hipLaunchKernelGGL(cast_f32_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, n));
+    SHM_LAUNCH_CHECK("shm_cast_f32");
+    return SHM_OK;
+}
+
 // ------------------------------------------------------------------ pixel-chunk skeleton
 // thread -> (pp, cl): pixel slot and 4-channel lane.  PP pixel slots per block iteration.
 struct PixMap {
@@ -95,15 +110,16 @@ __device__ __forceinline__ void block_reduce_atomic(double (&v)[NV][4], const Pi
 }
 
 // ------------------------------------------------------------------------- IN statistics
-__global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__ a, int lda, double* __restrict__ stats, int hw, int c, int chunk) {
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ a, int lda, double* __restrict__ stats, int hw, int c, int chunk) {
     PixMap pm(c);
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
     double v[2][4] = {};
     if (pm.active) {
-        const float* base = a + (size_t)n * hw * lda + pm.cl * 4;
+        const T* base = a + (size_t)n * hw * lda + pm.cl * 4;
         for (int p = p0 + pm.pp; p < p1; p += pm.PP) {
-            f32x4 x = *(const f32x4*)(base + (size_t)p * lda);
+            f32x4 x = ld4(base + (size_t)p * lda);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[0][e] += (double)x[e];
@@ -131,7 +147,7 @@ int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipSt
     return SHM_OK;
 }
 
-extern "C" int shm_in_stats(const float* a, int lda, double* stats, int batch, int hw, int c, float eps, void* stream) {
+extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, int hw, int c, float eps, int dtype, void* stream) {
     SHM_CHECK_C(c, "shm_in_stats");
     SHM_REQUIRE(lda % 4 == 0 && lda >= c, SHM_E_SHAPE, "shm_in_stats: bad pitch %d", lda);
     hipStream_t st = (hipStream_t)stream;
@@ -140,15 +156,17 @@ extern "C" int shm_in_stats(const float* a, int lda, double* stats, int batch, i
     if (r) return r;
     int nch = pix_chunks(hw, batch, c);
     int chunk = shm_cdiv(hw, nch);
-    hipLaunchKernelGGL(in_stats_kernel, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, a, lda, stats, hw, c, chunk);
+    SHM_DISPATCH(dtype, "shm_in_stats",
+                 hipLaunchKernelGGL(in_stats_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, (const T*)a, lda, stats, hw, c, chunk));
     SHM_LAUNCH_CHECK("shm_in_stats");
     hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, batch * c, hw, (double)eps);
     SHM_LAUNCH_CHECK("shm_in_stats(finalize)");
     return SHM_OK;
 }
 
-__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
-                                                       float* __restrict__ out, int ldo, int hw, int c, int chunk) {
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
+                                                       T* __restrict__ out, int ldo, int hw, int c, int chunk) {
     PixMap pm(c);
     if (!pm.active) return;
     const int n = blockIdx.y;
@@ -161,67 +179,72 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
         inv[e] = (float)stats[((size_t)n * c + ch) * 2 + 1];
         bt[e] = beta[ch];
     }
-    const float* base = a + (size_t)n * hw * lda + pm.cl * 4;
-    float* ob = out + (size_t)n * hw * ldo + pm.cl * 4;
+    const T* base = a + (size_t)n * hw * lda + pm.cl * 4;
+    T* ob = out + (size_t)n * hw * ldo + pm.cl * 4;
     int p = p0 + pm.pp;
     for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
         f32x4 x[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(base + (size_t)(p + u * pm.PP) * lda);
+        for (int u = 0; u < 4; ++u) x[u] = ld4(base + (size_t)(p + u * pm.PP) * lda);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (x[u][e] - mean[e]) * inv[e] + bt[e];
-            *(f32x4*)(ob + (size_t)(p + u * pm.PP) * ldo) = y;
+            st4(ob + (size_t)(p + u * pm.PP) * ldo, y);
         }
     }
     for (; p < p1; p += pm.PP) {
-        f32x4 x = *(const f32x4*)(base + (size_t)p * lda);
+        f32x4 x = ld4(base + (size_t)p * lda);
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (x[e] - mean[e]) * inv[e] + bt[e];
-        *(f32x4*)(ob + (size_t)p * ldo) = y;
+        st4(ob + (size_t)p * ldo, y);
     }
 }
 
-extern "C" int shm_in_apply(const float* a, int lda, const double* stats, const float* beta, float* out, int ldo, int batch, int hw, int c, void* stream) {
+extern "C" int shm_in_apply(const void* a, int lda, const double* stats, const float* beta, void* out, int ldo, int batch, int hw, int c, int dtype,
+                            void* stream) {
     SHM_CHECK_C(c, "shm_in_apply");
     SHM_REQUIRE(lda % 4 == 0 && ldo % 4 == 0, SHM_E_SHAPE, "shm_in_apply: bad pitch");
     if (batch == 0 || hw == 0) return SHM_OK;
     int nch = pix_chunks(hw, batch, c);
     int chunk = shm_cdiv(hw, nch);
-    hipLaunchKernelGGL(in_apply_kernel, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, (hipStream_t)stream, a, lda, stats, beta, out, ldo, hw, c, chunk);
+    SHM_DISPATCH(dtype, "shm_in_apply",
+                 hipLaunchKernelGGL(in_apply_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats, beta,
+                                    (T*)out, ldo, hw, c, chunk));
     SHM_LAUNCH_CHECK("shm_in_apply");
     return SHM_OK;
 }
 
 // --------------------------------------------------------------------------- IN backward
-struct InBwdArgs {
-    const float* g1;
-    const float* g2;
-    const float* a;
+struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' element type T
+    const void* g1;
+    const void* g2;
+    const void* a;
     const double* stats;
     double* red;
-    float* dz;
+    void* dz;
     double* dbias;
     int ldg1, ldg2, lda, lddz;
     int h, w, c, chunk;
     float slope;
 };
 
+template <typename TG>
 __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, int cl) {
-    f32x4 g = *(const f32x4*)(k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
+    f32x4 g = ld4((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
     if (k.g2) {
         int y = p / k.w, x = p - y * k.w;
         size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
-        f32x4 u = *(const f32x4*)(k.g2 + q * k.ldg2 + cl * 4);
+        f32x4 u = ld4((const TG*)k.g2 + q * k.ldg2 + cl * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] += 0.25f * u[e];
     }
     return g;
 }
 
+template <typename T, typename TG>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
     const int n = blockIdx.y, hw = k.h * k.w;
@@ -241,8 +264,8 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             f32x4 g[4], x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                g[u] = in_bwd_dout(k, n, p + u * pm.PP, pm.cl);
-                x[u] = *(const f32x4*)(k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
+                g[u] = in_bwd_dout<TG>(k, n, p + u * pm.PP, pm.cl);
+                x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -258,8 +281,8 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             }
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout(k, n, p, pm.cl);
-            f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
+            f32x4 g = in_bwd_dout<TG>(k, n, p, pm.cl);
+            f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float xh = (x[e] - mean[e]) * inv[e];
@@ -271,6 +294,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     block_reduce_atomic<2>(v, pm, k.red + (size_t)n * k.c * 2, k.c, true);
 }
 
+template <typename T, typename TG>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
     const int n = blockIdx.y, hw = k.h * k.w;
@@ -291,8 +315,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             f32x4 g[4], x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                g[u] = in_bwd_dout(k, n, p + u * pm.PP, pm.cl);
-                x[u] = *(const f32x4*)(k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
+                g[u] = in_bwd_dout<TG>(k, n, p + u * pm.PP, pm.cl);
+                x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
             float sd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -305,14 +329,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                     d[e] = x[u][e] > 0.f ? da : da * k.slope;
                     sd[e] += d[e];
                 }
-                *(f32x4*)(k.dz + ((size_t)n * hw + p + u * pm.PP) * k.lddz + pm.cl * 4) = d;
+                st4((T*)k.dz + ((size_t)n * hw + p + u * pm.PP) * k.lddz + pm.cl * 4, d);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout(k, n, p, pm.cl);
-            f32x4 x = *(const f32x4*)(k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
+            f32x4 g = in_bwd_dout<TG>(k, n, p, pm.cl);
+            f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
             f32x4 d;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -321,15 +345,15 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                 d[e] = x[e] > 0.f ? da : da * k.slope;
                 v[0][e] += (double)d[e];
             }
-            *(f32x4*)(k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4) = d;
+            st4((T*)k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4, d);
         }
     }
     if (k.dbias) block_reduce_atomic<1>(v, pm, k.dbias, k.c, true);
 }
 
-extern "C" int shm_in_bwd(const float* g1, int ldg1, const float* g2, int ldg2, const float* a, int lda,
-                          const double* stats, double* red, float* dz, int lddz, double* dbias, int batch,
-                          int h, int w, int c, float slope, void* stream) {
+extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
+                          const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
+                          int h, int w, int c, float slope, int dtype, void* stream) {
     SHM_CHECK_C(c, "shm_in_bwd");
     SHM_REQUIRE(ldg1 % 4 == 0 && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "shm_in_bwd: bad pitch");
     SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "shm_in_bwd: pooled gradient needs even h,w");
@@ -342,15 +366,16 @@ extern "C" int shm_in_bwd(const float* g1, int ldg1, const float* g2, int ldg2, 
     int nch = pix_chunks(hw, batch, c);
     k.chunk = shm_cdiv(hw, nch);
     dim3 grid(shm_cdiv(hw, k.chunk), batch);
-    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, k);
+    SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG>), grid, dim3(256), 0, st, k));
     SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, k);
+    SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG>), grid, dim3(256), 0, st, k));
     SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
     return SHM_OK;
 }
 
 // ---------------------------------------------------------------------- LeakyReLU backward
-__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dz, int lddz,
+template <typename T, typename TG>
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const TG* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy, T* __restrict__ dz, int lddz,
                                                         double* dbias, size_t npix, int c, size_t chunk, float slope) {
     PixMap pm(c);
     const size_t p0 = (size_t)blockIdx.x * chunk;
@@ -358,34 +383,37 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
     double v[1][4] = {};
     if (pm.active) {
         for (size_t p = p0 + pm.pp; p < p1; p += pm.PP) {
-            f32x4 g = *(const f32x4*)(dy + p * lddy + pm.cl * 4);
-            f32x4 x = *(const f32x4*)(y + p * ldy + pm.cl * 4);
+            f32x4 g = ld4(dy + p * lddy + pm.cl * 4);
+            f32x4 x = ld4(y + p * ldy + pm.cl * 4);
             f32x4 d;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 d[e] = x[e] > 0.f ? g[e] : g[e] * slope;
                 v[0][e] += (double)d[e];
             }
-            *(f32x4*)(dz + p * lddz + pm.cl * 4) = d;
+            st4(dz + p * lddz + pm.cl * 4, d);
         }
     }
     if (dbias) block_reduce_atomic<1>(v, pm, dbias, c, true);
 }
 
-extern "C" int shm_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz,
-                             double* dbias, size_t npix, int c, float slope, void* stream) {
+extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dz, int lddz,
+                             double* dbias, size_t npix, int c, float slope, int dtype, void* stream) {
     SHM_CHECK_C(c, "shm_lrelu_bwd");
     SHM_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0, SHM_E_SHAPE, "shm_lrelu_bwd: bad pitch");
     if (npix == 0) return SHM_OK;
     int nch = pix_chunks((long)npix, 1, c);
     size_t chunk = (npix + nch - 1) / nch;
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(shm_cdiv((long)npix, (long)chunk)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, dz, lddz, dbias, npix, c, chunk, slope);
+    SHM_DISPATCH_G(dtype, "shm_lrelu_bwd",
+                 hipLaunchKernelGGL((lrelu_bwd_kernel<T, TG>), dim3(shm_cdiv((long)npix, (long)chunk)), dim3(256), 0, (hipStream_t)stream, (const TG*)dy, lddy,
+                                    (const T*)y, ldy, (T*)dz, lddz, dbias, npix, c, chunk, slope));
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
     return SHM_OK;
 }
 
 // -------------------------------------------------------------------------------- pooling
-__global__ void avgpool2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int h, int w, int c4, size_t total) {
+template <typename T>
+__global__ void avgpool2_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int h, int w, int c4, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int cl = (int)(i % c4);
@@ -395,31 +423,34 @@ __global__ void avgpool2_kernel(const float* __restrict__ x, int ldx, float* __r
     size_t t = q / wo;
     int oy = (int)(t % ho);
     size_t n = t / ho;
-    const float* b = x + ((n * h + 2 * oy) * w + 2 * ox) * ldx + cl * 4;
-    f32x4 s = *(const f32x4*)b + *(const f32x4*)(b + ldx) + *(const f32x4*)(b + (size_t)w * ldx) + *(const f32x4*)(b + (size_t)(w + 1) * ldx);
-    *(f32x4*)(y + q * ldy + cl * 4) = s * 0.25f;
+    const T* b = x + ((n * h + 2 * oy) * w + 2 * ox) * ldx + cl * 4;
+    f32x4 s = ld4(b) + ld4(b + ldx) + ld4(b + (size_t)w * ldx) + ld4(b + (size_t)(w + 1) * ldx);
+    st4(y + q * ldy + cl * 4, s * 0.25f);
 }
 
-extern "C" int shm_avgpool2_fwd(const float* x, int ldx, float* y, int ldy, int batch, int h, int w, int c, void* stream) {
+extern "C" int shm_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int batch, int h, int w, int c, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, SHM_E_SHAPE, "shm_avgpool2_fwd: channels/pitch must be multiples of 4");
     SHM_REQUIRE(h % 2 == 0 && w % 2 == 0, SHM_E_SHAPE, "shm_avgpool2_fwd: odd size %dx%d", h, w);
     size_t total = (size_t)batch * (h / 2) * (w / 2) * (c / 4);
     if (total == 0) return SHM_OK;
-    hipLaunchKernelGGL(avgpool2_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, h, w, c / 4, total);
+    SHM_DISPATCH(dtype, "shm_avgpool2_fwd",
+                 hipLaunchKernelGGL(avgpool2_kernel<T>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, h, w,
+                                    c / 4, total));
     SHM_LAUNCH_CHECK("shm_avgpool2_fwd");
     return SHM_OK;
 }
 
 // -------------------------------------------------------------------------- generator head
 // y[p] = lrelu(sum_c x[p][c] w[c] + b); C/4 lanes per pixel (power of two <= 64).
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ y, size_t npix, int c, float slope) {
     const int lanes_c = c >> 2, PP = 256 / lanes_c;
     const int pp = threadIdx.x / lanes_c, cl = threadIdx.x % lanes_c;
     f32x4 wv = *(const f32x4*)(w + cl * 4);
     const float b = bias ? bias[0] : 0.f;
     for (size_t p = (size_t)blockIdx.x * PP + pp; p < npix; p += (size_t)gridDim.x * PP) {
-        f32x4 xv = *(const f32x4*)(x + p * ldx + cl * 4);
+        f32x4 xv = ld4(x + p * ldx + cl * 4);
         float s = xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
         for (int o = lanes_c >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (cl == 0) y[p] = shm_lrelu(s + b, slope);
@@ -428,19 +459,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 static bool pow2_le64(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
 
-extern "C" int shm_head_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, size_t npix, int c, float slope, void* stream) {
+extern "C" int shm_head_fwd(const void* x, int ldx, const float* w, const float* bias, float* y, size_t npix, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && ldx % 4 == 0, SHM_E_SHAPE, "shm_head_fwd: channels %d unsupported", c);
     if (npix == 0) return SHM_OK;
     int PP = 256 / (c / 4);
     long blocks = ((long)npix + PP - 1) / PP;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, npix, c, slope);
+    SHM_DISPATCH(dtype, "shm_head_fwd",
+                 hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, bias, y, npix, c, slope));
     SHM_LAUNCH_CHECK("shm_head_fwd");
     return SHM_OK;
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
-                                                       float* __restrict__ dx, int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope) {
+template <typename T, typename TG>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
+                                                       TG* __restrict__ dx, int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope) {
     PixMap pm(c);
     f32x4 wv = *(const f32x4*)(w + pm.cl * 4);
     double v[1][4] = {};
@@ -448,8 +481,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (size_t p = (size_t)blockIdx.x * pm.PP + pm.pp; p < npix; p += (size_t)gridDim.x * pm.PP) {
         float g = dy[p];
         float dz = y[p] > 0.f ? g : g * slope;
-        f32x4 xv = *(const f32x4*)(x + p * ldx + pm.cl * 4);
-        *(f32x4*)(dx + p * lddx + pm.cl * 4) = wv * dz;
+        f32x4 xv = ld4(x + p * ldx + pm.cl * 4);
+        st4(dx + p * lddx + pm.cl * 4, wv * dz);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[0][e] += (double)xv[e] * (double)dz;
         if (pm.cl == 0) dbs += (double)dz;
@@ -460,15 +493,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(db_acc, dbs);
 }
 
-extern "C" int shm_head_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dx,
-                            int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope, void* stream) {
+extern "C" int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, void* dx,
+                            int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && ldx % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_head_bwd: channels %d unsupported", c);
     if (npix == 0) return SHM_OK;
     int PP = 256 / (c / 4);
     long blocks = ((long)npix + (long)PP * 8 - 1) / ((long)PP * 8);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope);
+    SHM_DISPATCH_G(dtype, "shm_head_bwd",
+                 hipLaunchKernelGGL((head_bwd_kernel<T, TG>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, dw_acc,
+                                    db_acc, npix, c, slope));
     SHM_LAUNCH_CHECK("shm_head_bwd");
     return SHM_OK;
 }
@@ -484,7 +519,8 @@ __device__ __forceinline__ float block_sum_256(float v) {
 }
 
 // one block per output pixel
-__global__ __launch_bounds__(256) void patch_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, float* __restrict__ y, int h, int wd, int c, float slope) {
+template <typename T>
+__global__ __launch_bounds__(256) void patch_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, float* __restrict__ y, int h, int wd, int c, float slope) {
     const int q = blockIdx.x;              // (n, i, j)
     const int j = q % wd, t = q / wd;
     const int i = t % h, n = t / h;
@@ -494,7 +530,7 @@ __global__ __launch_bounds__(256) void patch_fwd_kernel(const float* __restrict_
         int tap = it / c4, cl = it - tap * c4;
         int ii = i + tap / 3 - 1, jj = j + tap % 3 - 1;
         if ((unsigned)ii < (unsigned)h && (unsigned)jj < (unsigned)wd) {
-            f32x4 xv = *(const f32x4*)(x + ((size_t)(n * h + ii) * wd + jj) * ldx + cl * 4);
+            f32x4 xv = ld4(x + ((size_t)(n * h + ii) * wd + jj) * ldx + cl * 4);
             f32x4 wv = *(const f32x4*)(w + (size_t)tap * c + cl * 4);
             s += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
         }
@@ -503,11 +539,11 @@ __global__ __launch_bounds__(256) void patch_fwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) y[q] = shm_lrelu(s, slope);
 }
 
-extern "C" int shm_patch_fwd(const float* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c, float slope, void* stream) {
+extern "C" int shm_patch_fwd(const void* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0, SHM_E_SHAPE, "shm_patch_fwd: channels must be a multiple of 4");
     int total = batch * h * wd;
     if (total == 0) return SHM_OK;
-    hipLaunchKernelGGL(patch_fwd_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, x, ldx, w, y, h, wd, c, slope);
+    SHM_DISPATCH(dtype, "shm_patch_fwd", hipLaunchKernelGGL(patch_fwd_kernel<T>, dim3(total), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, h, wd, c, slope));
     SHM_LAUNCH_CHECK("shm_patch_fwd");
     return SHM_OK;
 }
@@ -518,7 +554,8 @@ __global__ void patch_dz_kernel(const float* __restrict__ y, const float* __rest
 }
 
 // dx[n,i,j,c] = sum_tap dz[n, i-(kh-1), j-(kw-1)] * w[tap][c]
-__global__ void patch_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx, int lddx, int h, int wd, int c4, size_t total) {
+template <typename T>
+__global__ void patch_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w, T* __restrict__ dx, int lddx, int h, int wd, int c4, size_t total) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int cl = (int)(idx % c4);
@@ -535,11 +572,12 @@ __global__ void patch_dx_kernel(const float* __restrict__ dz, const float* __res
             s += *(const f32x4*)(w + (size_t)tap * c4 * 4 + cl * 4) * g;
         }
     }
-    *(f32x4*)(dx + q * lddx + cl * 4) = s;
+    st4(dx + q * lddx + cl * 4, s);
 }
 
 // dw[tap][c] = sum_{n,i,j} x[n,i+kh-1,j+kw-1,c] * dz[n,i,j]; block = (tap, 64 channels), 16 pixel groups
-__global__ __launch_bounds__(1024) void patch_dw_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, float* __restrict__ dw, int batch, int h, int wd, int c) {
+template <typename T>
+__global__ __launch_bounds__(1024) void patch_dw_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dz, float* __restrict__ dw, int batch, int h, int wd, int c) {
     __shared__ double red[16][64];
     const int tap = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     const int dh = tap / 3 - 1, dwv = tap % 3 - 1;
@@ -551,7 +589,7 @@ __global__ __launch_bounds__(1024) void patch_dw_kernel(const float* __restrict_
             const int i = t % h, n = t / h;
             const int ii = i + dh, jj = j + dwv;
             if ((unsigned)ii < (unsigned)h && (unsigned)jj < (unsigned)wd)
-                s += (double)x[((size_t)(n * h + ii) * wd + jj) * ldx + ch] * (double)dz[q];
+                s += (double)(float)x[((size_t)(n * h + ii) * wd + jj) * ldx + ch] * (double)dz[q];
         }
     red[g][threadIdx.x & 63] = s;
     __syncthreads();
@@ -562,8 +600,8 @@ __global__ __launch_bounds__(1024) void patch_dw_kernel(const float* __restrict_
     }
 }
 
-extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
-                             float* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope, void* stream) {
+extern "C" int shm_patch_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, float* dz,
+                             void* dx, int lddx, float* dw, int batch, int h, int wd, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_patch_bwd: channels must be a multiple of 4");
     int npx = batch * h * wd;
     if (npx == 0) return SHM_OK;
@@ -571,10 +609,12 @@ extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const floa
     hipLaunchKernelGGL(patch_dz_kernel, dim3(shm_cdiv(npx, 256)), dim3(256), 0, st, y, dy, dz, npx, slope);
     SHM_LAUNCH_CHECK("shm_patch_bwd(dz)");
     size_t total = (size_t)npx * (c / 4);
-    hipLaunchKernelGGL(patch_dx_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, (const float*)dz, w, dx, lddx, h, wd, c / 4, total);
+    SHM_DISPATCH_G(dtype, "shm_patch_bwd",
+                 hipLaunchKernelGGL(patch_dx_kernel<TG>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, (const float*)dz, w, (TG*)dx, lddx, h, wd, c / 4, total));
     SHM_LAUNCH_CHECK("shm_patch_bwd(dx)");
     if (dw) {
-        hipLaunchKernelGGL(patch_dw_kernel, dim3(9, shm_cdiv(c, 64)), dim3(1024), 0, st, x, ldx, (const float*)dz, dw, batch, h, wd, c);
+        SHM_DISPATCH_G(dtype, "shm_patch_bwd",
+                     hipLaunchKernelGGL(patch_dw_kernel<T>, dim3(9, shm_cdiv(c, 64)), dim3(1024), 0, st, (const T*)x, ldx, (const float*)dz, dw, batch, h, wd, c));
         SHM_LAUNCH_CHECK("shm_patch_bwd(dw)");
     }
     return SHM_OK;
@@ -583,12 +623,13 @@ extern "C" int shm_patch_bwd(const float* x, int ldx, const float* w, const floa
 // --------------------------------------------------------------------------------- Dense(5)
 constexpr int DENSE_MAX_OUT = 8;
 
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int k, int nout) {
+template <typename T>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int k, int nout) {
     const int n = blockIdx.x;
     float acc[DENSE_MAX_OUT] = {};
-    const float* xr = x + (size_t)n * k;
+    const T* xr = x + (size_t)n * k;
     for (int i = threadIdx.x; i < k; i += 256) {
-        float xv = xr[i];
+        float xv = (float)xr[i];
         for (int j = 0; j < nout; ++j) acc[j] += xv * w[(size_t)i * nout + j];
     }
     for (int j = 0; j < nout; ++j) {
@@ -597,16 +638,17 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
     }
 }
 
-extern "C" int shm_dense_fwd(const float* x, const float* w, float* y, int batch, int k, int nout, void* stream) {
+extern "C" int shm_dense_fwd(const void* x, const float* w, float* y, int batch, int k, int nout, int dtype, void* stream) {
     SHM_REQUIRE(nout >= 1 && nout <= DENSE_MAX_OUT, SHM_E_SHAPE, "shm_dense_fwd: nout %d > %d", nout, DENSE_MAX_OUT);
     if (batch == 0) return SHM_OK;
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, x, w, y, k, nout);
+    SHM_DISPATCH(dtype, "shm_dense_fwd", hipLaunchKernelGGL(dense_fwd_kernel<T>, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const T*)x, w, y, k, nout));
     SHM_LAUNCH_CHECK("shm_dense_fwd");
     return SHM_OK;
 }
 
 // thread per k: dx[n][k] += sum_j dy[n][j] w[k][j];  dw[k][j] = sum_n x[n][k] dy[n][j]
-__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T, typename TG>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, TG* __restrict__ dx,
                                                         float* __restrict__ dw, int batch, int k, int nout) {
     extern __shared__ float sdy[];          // [batch][nout]
     for (int i = threadIdx.x; i < batch * nout; i += 256) sdy[i] = dy[i];
@@ -616,40 +658,44 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict_
     float wv[DENSE_MAX_OUT], acc[DENSE_MAX_OUT] = {};
     for (int j = 0; j < nout; ++j) wv[j] = w[(size_t)i * nout + j];
     for (int n = 0; n < batch; ++n) {
-        float xv = x[(size_t)n * k + i];
+        float xv = (float)x[(size_t)n * k + i];
         float s = 0.f;
         for (int j = 0; j < nout; ++j) {
             float g = sdy[n * nout + j];
             s += g * wv[j];
             acc[j] += xv * g;
         }
-        dx[(size_t)n * k + i] += s;
+        dx[(size_t)n * k + i] = (TG)((float)dx[(size_t)n * k + i] + s);
     }
     if (dw)
         for (int j = 0; j < nout; ++j) dw[(size_t)i * nout + j] = acc[j];
 }
 
-extern "C" int shm_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int batch, int k, int nout, void* stream) {
+extern "C" int shm_dense_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, int batch, int k, int nout, int dtype, void* stream) {
     SHM_REQUIRE(nout >= 1 && nout <= DENSE_MAX_OUT, SHM_E_SHAPE, "shm_dense_bwd: nout %d > %d", nout, DENSE_MAX_OUT);
     SHM_REQUIRE((size_t)batch * nout * 4 <= 48 * 1024, SHM_E_SHAPE, "shm_dense_bwd: batch %d too large", batch);
     if (batch == 0 || k == 0) return SHM_OK;
-    hipLaunchKernelGGL(dense_bwd_kernel, dim3(shm_cdiv(k, 256)), dim3(256), (size_t)batch * nout * 4, (hipStream_t)stream, x, w, dy, dx, dw, batch, k, nout);
+    SHM_DISPATCH_G(dtype, "shm_dense_bwd",
+                 hipLaunchKernelGGL((dense_bwd_kernel<T, TG>), dim3(shm_cdiv(k, 256)), dim3(256), (size_t)batch * nout * 4, (hipStream_t)stream, (const T*)x, w,
+                                    dy, (TG*)dx, dw, batch, k, nout));
     SHM_LAUNCH_CHECK("shm_dense_bwd");
     return SHM_OK;
 }
 
 // --------------------------------------------------------------------------- dropout mask
-__global__ void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, size_t n4, float scale) {
+template <typename T>
+__global__ void mul_mask_kernel(const T* __restrict__ x, const float* __restrict__ m, T* __restrict__ y, size_t n4, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    f32x4 a = ((const f32x4*)x)[i], b = ((const f32x4*)m)[i];
-    ((f32x4*)y)[i] = a * b * scale;
+    f32x4 a = ld4(x + i * 4), b = ((const f32x4*)m)[i];
+    st4(y + i * 4, a * b * scale);
 }
 
-extern "C" int shm_mul_mask(const float* x, const float* mask, float* y, size_t n, float scale, void* stream) {
+extern "C" int shm_mul_mask(const void* x, const float* mask, void* y, size_t n, float scale, int dtype, void* stream) {
     SHM_REQUIRE(n % 4 == 0, SHM_E_SHAPE, "shm_mul_mask: n must be a multiple of 4");
     if (n == 0) return SHM_OK;
-    hipLaunchKernelGGL(mul_mask_kernel, dim3(shm_cdiv((long)(n / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n / 4, scale);
+    SHM_DISPATCH(dtype, "shm_mul_mask",
+                 hipLaunchKernelGGL(mul_mask_kernel<T>, dim3(shm_cdiv((long)(n / 4), 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, mask, (T*)y, n / 4, scale));
     SHM_LAUNCH_CHECK("shm_mul_mask");
     return SHM_OK;
 }

@@ -21,11 +21,17 @@ from . import ops
 
 LRELU = 0.2
 IN_EPS = 1e-6
-PAD_C = 16          # channel pitch of 3- and 10-channel images
+PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
 
 
-def _pad16(c):
-    return (c + 15) // 16 * 16
+def pad_channels(dtype):
+    """Channel pitch of the 3- and 10-channel images = contraction granule of the tap GEMM:
+    one 64-byte LDS row, i.e. 16 float32 or 32 bfloat16 channels."""
+    return 64 // torch.empty((), dtype=dtype).element_size()
+
+
+def _padk(c, g):
+    return (c + g - 1) // g * g
 
 
 class Arena:
@@ -122,6 +128,19 @@ class _Vars:
         self.vars = [self.flat[o:o + z].view(s) for o, z, s in zip(self.offsets, sizes, self.shapes)]
         self.grads = [self.grad[o:o + z].view(s) for o, z, s in zip(self.offsets, sizes, self.shapes)]
         self.iterations = 0
+        self._sizes = sizes
+        self.op_flat, self.op_vars = self.flat, self.vars       # MFMA operand copy (== master in float32)
+
+    def operand_copy(self, dtype):
+        """bf16 path: the products that read weights 'as stored' (dgrad, Conv2DTranspose) take a bf16
+        copy of the whole flat buffer, refreshed once per step by one cast kernel."""
+        if dtype != torch.float32:
+            self.op_flat = torch.zeros(self.n, dtype=dtype, device=self.flat.device)
+            self.op_vars = [self.op_flat[o:o + z].view(s) for o, z, s in zip(self.offsets, self._sizes, self.shapes)]
+
+    def refresh_operands(self):
+        if self.op_flat is not self.flat:
+            ops.cast_f32(self.flat, self.op_flat, self.n)
 
     def load(self, arrays):
         assert len(arrays) == len(self.vars)
@@ -160,11 +179,16 @@ class _ModelBase:
 class Generator(_ModelBase):
     name = "SHM_Generator"
 
-    def __init__(self, image_size, filter_size, device, arena, ws_provider, lane=None):
+    def __init__(self, image_size, filter_size, device, arena, ws_provider, lane=None, dtype=torch.float32,
+                 grad_dtype=None):
         self.S, self.F, self.dev = image_size, filter_size, device
         self.arena, self.ws_provider = arena, ws_provider
         self.lane = lane or WgradLane(device, enabled=False)
-        assert image_size % 16 == 0 and filter_size % 16 == 0, "image_size and filter_size must be multiples of 16"
+        self.adt = dtype                                   # activation / MFMA operand dtype
+        self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32   # gradient-signal tensors ([G] in the header)
+        self.pad = pad_channels(dtype)
+        assert image_size % 16 == 0 and filter_size % self.pad == 0, \
+            f"image_size must be a multiple of 16 and filter_size of {self.pad}"
         self.layers = generator_layers(filter_size)
         shapes = []
         for _, kind, k, cin, cout in self.layers:
@@ -174,6 +198,7 @@ class Generator(_ModelBase):
         # storage order: all MFMA-wgrad kernels, then [head kernel, every bias] (f64-accumulated grads)
         order = [2 * i for i in range(nl - 1)] + [2 * (nl - 1)] + [2 * i + 1 for i in range(nl)]
         self.P = _Vars(shapes, order, device)
+        self.P.operand_copy(dtype)
         self.acc_off = self.P.offsets[2 * (nl - 1)]            # start of the f64-accumulated region
         self.acc_n = self.P.n - self.acc_off
         self.acc = torch.zeros(self.acc_n, dtype=torch.float64, device=device)
@@ -183,9 +208,9 @@ class Generator(_ModelBase):
         self.wk = {}
         for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
             if kind == "c":
-                self.wk[i] = torch.zeros(k * k * cout * _pad16(cin), dtype=torch.float32, device=device)
+                self.wk[i] = torch.zeros(k * k * cout * _padk(cin, self.pad), dtype=dtype, device=device)
             else:
-                self.wk[i] = torch.zeros(9 * cin * cout, dtype=torch.float32, device=device)
+                self.wk[i] = torch.zeros(9 * cin * cout, dtype=dtype, device=device)
         self.weights_dirty = True
         self.ctx = {}
         self.debug = None
@@ -203,10 +228,11 @@ class Generator(_ModelBase):
         """Refresh the K-contiguous weight copies after an optimizer step."""
         if not self.weights_dirty:
             return
+        self.P.refresh_operands()
         for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
             w = self.P.vars[2 * i]
             if kind == "c":      # HWIO [t][cin][cout] -> [t][cout][cin_pad]
-                ops.transpose_taps(w, self.wk[i], k * k, cin, cout, _pad16(cin))
+                ops.transpose_taps(w, self.wk[i], k * k, cin, cout, _padk(cin, self.pad))
             else:                # Keras convT [t][cout][cin] -> [t][cin][cout] (for its dgrad)
                 ops.transpose_taps(w, self.wk[i], 9, cout, cin, cout)
         self.weights_dirty = False
@@ -223,10 +249,10 @@ class Generator(_ModelBase):
     def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w):
         """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record)."""
         _, _, k, cin, cout = self.layers[li]
-        cin_p = _pad16(cin)
+        cin_p = _padk(cin, self.pad)
         A = self.arena
-        a = A.get(f"{tag}/a{li}", (n, h, w, cout))
-        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout))
+        a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
+        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt)
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
         ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
                           k, 1, LRELU, stats, IN_EPS, cin_real=cin)
@@ -235,13 +261,13 @@ class Generator(_ModelBase):
         return ahat, rec
 
     def forward(self, x16, tag):
-        """x16: [N,S,S,16] (10 real channels, 6 zero).  Returns gen_Y [N,S,S,1]."""
+        """x16: [N,S,S,pad] (10 real channels, zero padded to the 64-byte pitch).  Returns gen_Y [N,S,S,1]."""
         n, S, F = x16.shape[0], self.S, self.F
-        assert tuple(x16.shape) == (n, S, S, PAD_C)
+        assert tuple(x16.shape) == (n, S, S, self.pad) and x16.dtype == self.adt
         self.prepare_weights()
         A = self.arena
         recs = []
-        cur, ld, h = x16, PAD_C, S
+        cur, ld, h = x16, self.pad, S
         li = bi = 0
         downs = []
         for lvl in range(4):
@@ -252,7 +278,7 @@ class Generator(_ModelBase):
                 li += 1
                 bi += 1
             downs.append((cur, ld, h))
-            pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, ld))
+            pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, ld), self.adt)
             ops.avgpool2_fwd(cur, ld, pooled, ld, n, h, h, ld)
             cur, h = pooled, h // 2
         for _ in range(2):                       # the two 1x1 blocks
@@ -263,8 +289,8 @@ class Generator(_ModelBase):
         ups = []
         for lvl in range(4):
             _, _, _, cin, cout = self.layers[li]
-            u = A.get(f"{tag}/u{lvl}", (n, 2 * h, 2 * h, cout))
-            ops.conv2d_transpose_fwd(cur, ld, self.P.vars[2 * li], self.P.vars[2 * li + 1], u, cout, n, h, h, cin,
+            u = A.get(f"{tag}/u{lvl}", (n, 2 * h, 2 * h, cout), self.adt)
+            ops.conv2d_transpose_fwd(cur, ld, self.P.op_vars[2 * li], self.P.vars[2 * li + 1], u, cout, n, h, h, cin,
                                      cout, LRELU)
             ups.append(dict(li=li, x=cur, ldx=ld, u=u, h=h))
             li += 1
@@ -293,19 +319,19 @@ class Generator(_ModelBase):
         li, h, w = rec["li"], rec["h"], rec["w"]
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
-        dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout))       # per layer: read later by the wgrad lane
+        dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
         red = A.get(f"bwd/red/{n * cout}", (n * cout * 2,), torch.float64)
         ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
                    h, w, cout, LRELU)
         if self.debug is not None:           # test diagnostics: keep the per-layer gradients
             self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
-        cin_p = _pad16(cin)
+        cin_p = _padk(cin, self.pad)
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
         self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
                                                   self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
         if need_dx:
             lddx = rec["ldx"]
-            ops.conv2d_dgrad(dz, cout, self.P.vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
+            ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
 
     def backward(self, dy, tag, need_dx=False):
         """dy: gradient wrt gen_Y [N,S,S,1].  Accumulates into the flat gradient (+ f64 region).
@@ -317,7 +343,7 @@ class Generator(_ModelBase):
         nl = len(self.layers)
         # head
         hx = c["head_x"]
-        dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F))
+        dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F), self.gdt)
         ops.head_bwd(hx, F, self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
                      self._acc_slice(2 * (nl - 1) + 1), n * S * S, F, LRELU)
         ri = len(recs) - 1
@@ -328,25 +354,25 @@ class Generator(_ModelBase):
             ri -= 2
             h = r2["h"]
             cout = self.layers[r2["li"]][4]
-            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout))
+            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout), self.gdt)
             self._cnl_bwd(tag, r2, dcur, None, n, True, dmid, None, cout)
             # concat block: split gradient into (du, dskip)
             cu = r1["c1"]
             cs = self.layers[r1["li"]][3] - cu
-            du = A.get(f"bwd/du/{n}x{h}x{cu}", (n, h, h, cu))
-            dsk = A.get(f"bwd/dskip{3 - lvl}/{n}x{h}x{cs}", (n, h, h, cs))
+            du = A.get(f"bwd/du/{n}x{h}x{cu}", (n, h, h, cu), self.gdt)
+            dsk = A.get(f"bwd/dskip{3 - lvl}/{n}x{h}x{cs}", (n, h, h, cs), self.gdt)
             self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu)
             dskips[3 - lvl] = dsk
             # Conv2DTranspose: LeakyReLU', bias grad, wgrad (roles swapped), dgrad = stride-2 conv
             tli = up["li"]
             _, _, _, tcin, tcout = self.layers[tli]
-            dzu = A.get(f"bwd/dzu/L{tli}/{n}", (n, h, h, cu))
+            dzu = A.get(f"bwd/dzu/L{tli}/{n}", (n, h, h, cu), self.adt)
             ops.lrelu_bwd(du, cu, up["u"], cu, dzu, cu, self._acc_slice(2 * tli + 1), n * h * h, cu, LRELU)
             ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, tcout, tcin, 3))
             self.lane.submit(lambda dzu=dzu, up=up, tli=tli, tcout=tcout, tcin=tcin, h=h, ws=ws: ops.conv2d_wgrad(
                 dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout, tcin, 3, 2, 1, ws))
             hin = up["h"]
-            dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin))
+            dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin), self.gdt)
             ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0)
         # bottleneck 1x1 blocks
         for _ in range(2):
@@ -354,7 +380,7 @@ class Generator(_ModelBase):
             ri -= 1
             h = r["h"]
             cin = self.layers[r["li"]][3]
-            dn = A.get(f"bwd/db{ri}/{n}x{h}x{cin}", (n, h, h, cin))
+            dn = A.get(f"bwd/db{ri}/{n}x{h}x{cin}", (n, h, h, cin), self.gdt)
             self._cnl_bwd(tag, r, dcur, None, n, True, dn, None, cin)
             dcur = dn
         dpool = dcur                                   # gradient wrt pool4 output
@@ -363,15 +389,15 @@ class Generator(_ModelBase):
             ri -= 2
             h = r2["h"]
             cout = self.layers[r2["li"]][4]
-            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout))
+            dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout), self.gdt)
             self._cnl_bwd(tag, r2, dskips[lvl], dpool, n, True, dmid, None, cout)
             cin = self.layers[r1["li"]][3]
             if lvl > 0:
-                dpool = A.get(f"bwd/dp/{n}x{h}x{cin}", (n, h, h, cin))
+                dpool = A.get(f"bwd/dp/{n}x{h}x{cin}", (n, h, h, cin), self.gdt)
                 self._cnl_bwd(tag, r1, dmid, None, n, True, dpool, None, cin)
             else:
                 if need_dx:
-                    dx16 = A.get(f"bwd/dx16/{n}", (n, h, h, PAD_C))
+                    dx16 = A.get(f"bwd/dx16/{n}", (n, h, h, self.pad), self.gdt)
                     self._cnl_bwd(tag, r1, dmid, None, n, True, dx16, None, cin)
                     return dx16
                 self._cnl_bwd(tag, r1, dmid, None, n, False)
@@ -392,7 +418,7 @@ class Generator(_ModelBase):
     def __call__(self, x, training=False, tag="call"):
         """Keras-style call on a [N,S,S,10] tensor (reference: self.G(x, training=...))."""
         n = x.shape[0]
-        x16 = self.arena.get(f"{tag}/x16", (n, self.S, self.S, PAD_C))
+        x16 = self.arena.get(f"{tag}/x16", (n, self.S, self.S, self.pad), self.adt)
         x16.zero_()
         x16[..., :10].copy_(x)
         return self.forward(x16, tag)
@@ -411,10 +437,14 @@ class Generator(_ModelBase):
 class Discriminator(_ModelBase):
     name = "SHM_Discriminator"
 
-    def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2, lane=None):
+    def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2, lane=None, dtype=torch.float32,
+                 grad_dtype=None):
         self.S, self.F, self.dev = image_size, filter_size, device
         self.arena, self.ws_provider = arena, ws_provider
         self.lane = lane or WgradLane(device, enabled=False)
+        self.adt = dtype
+        self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32
+        self.pad = pad_channels(dtype)
         self.dropout = dropout
         assert image_size % 32 == 0
         f, s = filter_size, image_size // 32
@@ -424,8 +454,9 @@ class Discriminator(_ModelBase):
         shapes += [(3, 3, 16 * f, 1), (s * s * 16 * f, 5)]
         self.names = ["conv2d_27", "conv2d_28", "conv2d_29", "conv2d_30", "conv2d_33", "conv2d_34", "dense"]
         self.P = _Vars(shapes, list(range(7)), device)
+        self.P.operand_copy(dtype)
         self.betas = [torch.zeros(c, dtype=torch.float32, device=device) for c in self.chan[1:]]
-        self.wk = [torch.zeros(9 * self.chan[i + 1] * _pad16(self.chan[i]), dtype=torch.float32, device=device)
+        self.wk = [torch.zeros(9 * self.chan[i + 1] * _padk(self.chan[i], self.pad), dtype=dtype, device=device)
                    for i in range(5)]
         self.weights_dirty = True
         self.ctx = None
@@ -437,8 +468,9 @@ class Discriminator(_ModelBase):
     def prepare_weights(self):
         if not self.weights_dirty:
             return
+        self.P.refresh_operands()
         for i in range(5):
-            ops.transpose_taps(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _pad16(self.chan[i]))
+            ops.transpose_taps(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _padk(self.chan[i], self.pad))
         self.weights_dirty = False
 
     def zero_grad(self):
@@ -469,7 +501,7 @@ class Discriminator(_ModelBase):
         for i in range(5):
             cout = self.chan[i + 1]
             ho = h // 2
-            bufs.append((A.get(f"d/a{i}/{n}", (n, ho, ho, cout)), A.get(f"d/h{i}/{n}", (n, ho, ho, cout)),
+            bufs.append((A.get(f"d/a{i}/{n}", (n, ho, ho, cout), self.adt), A.get(f"d/h{i}/{n}", (n, ho, ho, cout), self.adt),
                          A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)))
             h = ho
         self._pending = dict(n=n, xd16=xd16, bufs=bufs, keep_mask=keep_mask, mask_rows=mask_rows)
@@ -478,13 +510,13 @@ class Discriminator(_ModelBase):
         """The five Conv(3x3, s2) -> LeakyReLU -> InstanceNorm blocks on samples [r0, r1)."""
         xd16, bufs = self._pending["xd16"], self._pending["bufs"]
         nb = r1 - r0
-        cur, ld, h = xd16[r0:r1], PAD_C, self.S
+        cur, ld, h = xd16[r0:r1], self.pad, self.S
         for i in range(5):
             cin, cout = self.chan[i], self.chan[i + 1]
             ho = h // 2
             a, ahat, stats = bufs[i]
             st = stats[r0 * cout * 2:r1 * cout * 2]
-            ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a[r0:r1], cout, nb, h, h, _pad16(cin), cout, 3, 2,
+            ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a[r0:r1], cout, nb, h, h, _padk(cin, self.pad), cout, 3, 2,
                               LRELU, st, IN_EPS, cin_real=cin)
             ops.in_apply(a[r0:r1], cout, st, self.betas[i], ahat[r0:r1], cout, nb, ho * ho, cout)
             cur, ld, h = ahat[r0:r1], cout, ho
@@ -496,7 +528,7 @@ class Discriminator(_ModelBase):
         keep_mask, mask_rows = pd["keep_mask"], pd["mask_rows"]
         A = self.arena
         recs = []
-        cur, ld, h = xd16, PAD_C, self.S
+        cur, ld, h = xd16, self.pad, self.S
         for i in range(5):
             a, ahat, stats = bufs[i]
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
@@ -522,7 +554,7 @@ class Discriminator(_ModelBase):
         per = s * s * c5
         x5 = c["x5"]
         dz_p = A.get(f"d/bwd/dzp/{n}", (n, s, s, 1))
-        dx5 = A.get(f"d/bwd/dx5/{n}", (n, s, s, c5))
+        dx5 = A.get(f"d/bwd/dx5/{n}", (n, s, s, c5), self.gdt)
         ops.patch_bwd(x5, c5, self.P.vars[5], c["rf"], drf, dz_p, dx5, c5, self.P.grads[5] if params else None, n, s, s,
                       c5, LRELU)
         if dcls is not None:
@@ -537,17 +569,17 @@ class Discriminator(_ModelBase):
             cin, cout = self.chan[i], self.chan[i + 1]
             h = rec["h"]
             ho = h // 2
-            dz = A.get(f"d/bwd/dz{i}/{n}", (n, ho, ho, cout))
+            dz = A.get(f"d/bwd/dz{i}/{n}", (n, ho, ho, cout), self.adt)
             red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 2,), torch.float64)
             ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
             if params:
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))
                 self.lane.submit(lambda rec=rec, dz=dz, i=i, h=h, cin=cin, cout=cout, ws=ws: ops.conv2d_wgrad(
-                    rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _pad16(cin), cout, 3, 2, 0, ws))
+                    rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _padk(cin, self.pad), cout, 3, 2, 0, ws))
             if i > 0 or need_dx:
                 ldx = rec["ldx"]
-                dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx))
-                ops.conv2d_dgrad(dz, cout, self.P.vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2)
+                dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
+                ops.conv2d_dgrad(dz, cout, self.P.op_vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2)
                 dcur = dprev
         return dcur if need_dx else None
 
@@ -567,7 +599,7 @@ class Discriminator(_ModelBase):
     def __call__(self, x, training=False, noise=None, keep_mask=None):
         """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""
         n = x.shape[0]
-        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, PAD_C))
+        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, self.pad), self.adt)
         ops.pack_rgb16(x.contiguous(), noise if training else None, xd, n * self.S * self.S)
         rows = [(0, n, 0)] if (training and keep_mask is not None) else []
         return self.forward(xd, keep_mask, rows)

@@ -70,8 +70,36 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _dt(t):
+    """SHM_F32 / SHM_BF16 code of an activation tensor."""
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise TypeError(f"activation tensors are float32 or bfloat16, got {t.dtype}")
+
+
+def _dtg(act, grad):
+    """dtype code of a call with activation tensor `act` and gradient-signal ([G]) tensor `grad`:
+    SHM_BF16_GF32 when the activations are bf16 and the gradient signal is kept in fp32."""
+    d = _dt(act)
+    if d == 1 and grad is not None and grad.dtype == torch.float32:
+        return 2
+    if grad is not None and d != 2 and _dt(grad) != d:
+        raise TypeError("gradient-signal tensors are float32, or share the activation dtype")
+    return d
+
+
+def _sfx(t):
+    return "/bf16" if t.dtype == torch.bfloat16 else ""
+
+
+def cast_f32(src, dst, n):
+    check(lib().shm_cast_f32(_p(src), _p(dst), n, _dt(dst), _stream()), "shm_cast_f32")
+
+
 def transpose_taps(w, wt, ntaps, rows, cols, rows_pad):
-    check(lib().shm_transpose_taps(_p(w), _p(wt), ntaps, rows, cols, rows_pad, _stream()), "shm_transpose_taps")
+    check(lib().shm_transpose_taps(_p(w), _p(wt), ntaps, rows, cols, rows_pad, _dt(wt), _stream()), "shm_transpose_taps")
 
 
 def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope,
@@ -79,9 +107,9 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
     """cin_real: un-padded input channels, only used for the algorithmic flop count."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
-    _timed(_tile(cout), flops, lambda: check(
+    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
         lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                             cin, cout, ksize, stride, slope, _stream()), "shm_conv2d_fwd"),
+                             cin, cout, ksize, stride, slope, _dtg(x, y), _stream()), "shm_conv2d_fwd"),
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
@@ -90,26 +118,26 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
     """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
-    _timed(_tile(cout), flops, lambda: check(
+    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
         lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                                cin, cout, ksize, stride, slope, _p(stats), eps, _stream()), "shm_conv2d_in_fwd"),
+                                cin, cout, ksize, stride, slope, _p(stats), eps, _dt(x), _stream()), "shm_conv2d_in_fwd"),
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
-    _timed(_tile(cin), flops, lambda: check(
+    _timed(_tile(cin) + _sfx(dy), flops, lambda: check(
         lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
-                               cout, ksize, stride, _stream()), "shm_conv2d_dgrad"),
+                               cout, ksize, stride, _dtg(dy, dx), _stream()), "shm_conv2d_dgrad"),
            f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}")
 
 
 def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
     flops = 2.0 * batch * hi * wi * 9 * cin * cout
-    _timed(_tile(cout), flops, lambda: check(
+    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
         lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
-                                       slope, _stream()), "shm_conv2d_transpose_fwd"),
+                                       slope, _dt(x), _stream()), "shm_conv2d_transpose_fwd"),
            f"convT n{batch} h{hi} {cin}->{cout}")
 
 
@@ -122,33 +150,38 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
     halo = ksize == 3 and stride == 1 and wi % 16 == 0 and hi % 2 == 0 and not (x2 is not None and c1 % 64 != 0)
-    _timed("wgrad_halo_kernel(+reduce)" if halo else "wgrad_kernel<%d>(+reduce)" % (ksize * ksize), flops, lambda: check(
+    if x.dtype == torch.bfloat16:
+        sym = "wgrad_bf16_kernel<%d>(+reduce)" % (ksize * ksize)
+    else:
+        sym = "wgrad_halo_kernel(+reduce)" if halo else "wgrad_kernel<%d>(+reduce)" % (ksize * ksize)
+    _timed(sym, flops, lambda: check(
         lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
                                cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
-                               _stream()), "shm_conv2d_wgrad"),
+                               _dt(x), _stream()), "shm_conv2d_wgrad"),
            f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}")
 
 
 def in_stats(a, lda, stats, batch, hw, c, eps):
-    check(lib().shm_in_stats(_p(a), lda, _p(stats), batch, hw, c, eps, _stream()), "shm_in_stats")
+    check(lib().shm_in_stats(_p(a), lda, _p(stats), batch, hw, c, eps, _dt(a), _stream()), "shm_in_stats")
 
 
 def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
-    check(lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _stream()), "shm_in_apply")
+    check(lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()),
+          "shm_in_apply")
 
 
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
     check(lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
-                           batch, h, w, c, slope, _stream()), "shm_in_bwd")
+                           batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd")
 
 
 def lrelu_bwd(dy, lddy, y, ldy, dz, lddz, dbias, npix, c, slope):
-    check(lib().shm_lrelu_bwd(_p(dy), lddy, _p(y), ldy, _p(dz), lddz, _p(dbias), npix, c, slope, _stream()),
+    check(lib().shm_lrelu_bwd(_p(dy), lddy, _p(y), ldy, _p(dz), lddz, _p(dbias), npix, c, slope, _dtg(y, dy), _stream()),
           "shm_lrelu_bwd")
 
 
 def avgpool2_fwd(x, ldx, y, ldy, batch, h, w, c):
-    check(lib().shm_avgpool2_fwd(_p(x), ldx, _p(y), ldy, batch, h, w, c, _stream()), "shm_avgpool2_fwd")
+    check(lib().shm_avgpool2_fwd(_p(x), ldx, _p(y), ldy, batch, h, w, c, _dt(x), _stream()), "shm_avgpool2_fwd")
 
 
 def cvt_f64_f32(src, dst, n, accumulate):
@@ -160,33 +193,33 @@ def zero(t):
 
 
 def head_fwd(x, ldx, w, bias, y, npix, c, slope):
-    check(lib().shm_head_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, slope, _stream()), "shm_head_fwd")
+    check(lib().shm_head_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, slope, _dt(x), _stream()), "shm_head_fwd")
 
 
 def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope):
     check(lib().shm_head_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), npix, c,
-                             slope, _stream()), "shm_head_bwd")
+                             slope, _dtg(x, dx), _stream()), "shm_head_bwd")
 
 
 def patch_fwd(x, ldx, w, y, batch, h, wd, c, slope):
-    check(lib().shm_patch_fwd(_p(x), ldx, _p(w), _p(y), batch, h, wd, c, slope, _stream()), "shm_patch_fwd")
+    check(lib().shm_patch_fwd(_p(x), ldx, _p(w), _p(y), batch, h, wd, c, slope, _dt(x), _stream()), "shm_patch_fwd")
 
 
 def patch_bwd(x, ldx, w, y, dy, dz, dx, lddx, dw, batch, h, wd, c, slope):
     check(lib().shm_patch_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dz), _p(dx), lddx, _p(dw), batch, h, wd, c,
-                              slope, _stream()), "shm_patch_bwd")
+                              slope, _dtg(x, dx), _stream()), "shm_patch_bwd")
 
 
 def dense_fwd(x, w, y, batch, k, nout):
-    check(lib().shm_dense_fwd(_p(x), _p(w), _p(y), batch, k, nout, _stream()), "shm_dense_fwd")
+    check(lib().shm_dense_fwd(_p(x), _p(w), _p(y), batch, k, nout, _dt(x), _stream()), "shm_dense_fwd")
 
 
 def dense_bwd(x, w, dy, dx, dw, batch, k, nout):
-    check(lib().shm_dense_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), batch, k, nout, _stream()), "shm_dense_bwd")
+    check(lib().shm_dense_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), batch, k, nout, _dtg(x, dx), _stream()), "shm_dense_bwd")
 
 
 def mul_mask(x, mask, y, n, scale):
-    check(lib().shm_mul_mask(_p(x), _p(mask), _p(y), n, scale, _stream()), "shm_mul_mask")
+    check(lib().shm_mul_mask(_p(x), _p(mask), _p(y), n, scale, _dt(x), _stream()), "shm_mul_mask")
 
 
 def rgb2yuv_std(rgb, yuv, acc, scale_out, batch, npix):
@@ -200,24 +233,27 @@ def avg_cbcr(ys, out, n):
 
 def build_gen_input(ys, gen_y, flags_mask, mode, out, batch, npix):
     check(lib().shm_build_gen_input(_p(ys[0]), _p(ys[1]), _p(ys[2]), _p(ys[3]), _p(ys[4]), _p(gen_y), flags_mask,
-                                    mode, _p(out), batch, npix, _stream()), "shm_build_gen_input")
+                                    mode, _p(out), out.shape[-1], batch, npix, _dt(out), _stream()), "shm_build_gen_input")
 
 
 def cyc_input_bwd(dcyc, flags_mask, dgen_y, batch, npix):
-    check(lib().shm_cyc_input_bwd(_p(dcyc), flags_mask, _p(dgen_y), batch, npix, _stream()), "shm_cyc_input_bwd")
+    check(lib().shm_cyc_input_bwd(_p(dcyc), dcyc.shape[-1], flags_mask, _p(dgen_y), batch, npix, _dt(dcyc), _stream()),
+          "shm_cyc_input_bwd")
 
 
 def yuv2rgb(ych, cbcr, noise, rgb, dpad, nimg, batch, npix):
-    check(lib().shm_yuv2rgb(_p(ych), _p(cbcr), _p(noise), _p(rgb), _p(dpad), nimg, batch, npix, _stream()),
-          "shm_yuv2rgb")
+    check(lib().shm_yuv2rgb(_p(ych), _p(cbcr), _p(noise), _p(rgb), _p(dpad), 0 if dpad is None else dpad.shape[-1], nimg,
+                            batch, npix, 0 if dpad is None else _dt(dpad), _stream()), "shm_yuv2rgb")
 
 
 def pack_rgb16(rgb, noise, dpad, npix_total):
-    check(lib().shm_pack_rgb16(_p(rgb), _p(noise), _p(dpad), npix_total, _stream()), "shm_pack_rgb16")
+    check(lib().shm_pack_rgb16(_p(rgb), _p(noise), _p(dpad), dpad.shape[-1], npix_total, _dt(dpad), _stream()),
+          "shm_pack_rgb16")
 
 
 def rgb16_to_dy(d16, dy, npix_total, accumulate):
-    check(lib().shm_rgb16_to_dy(_p(d16), _p(dy), npix_total, int(accumulate), _stream()), "shm_rgb16_to_dy")
+    check(lib().shm_rgb16_to_dy(_p(d16), d16.shape[-1], _p(dy), npix_total, int(accumulate), _dt(d16), _stream()),
+          "shm_rgb16_to_dy")
 
 
 def dhead_losses(rf, cls, loss, drf_d, dcls_d, drf_g, batch, np_, target):
@@ -258,9 +294,9 @@ def maxpool2_fwd(x, ldx, y, ldy, batch, h, w, c):
 
 def conv2d_transpose2x2_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope=1.0):
     flops = 2.0 * batch * hi * wi * 4 * cin * cout
-    _timed(_tile(cout), flops, lambda: check(
+    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
         lib().shm_conv2d_transpose2x2_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
-                                          slope, _stream()), "shm_conv2d_transpose2x2_fwd"),
+                                          slope, _dt(x), _stream()), "shm_conv2d_transpose2x2_fwd"),
            f"convT2 n{batch} h{hi} {cin}->{cout}")
 
 

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .dist import GradReducer, world_size
-from .model import PAD_C, Arena, Discriminator, Generator, WgradLane
+from .model import Arena, Discriminator, Generator, WgradLane, pad_channels
 from .specseg import SpecSeg
 
 
@@ -59,8 +59,22 @@ LOSS_NAMES = ["total_Generator_loss", "total_Discriminator_loss", "total_Classif
               "ssim_cyc_loss", "content_loss", "style_loss", "total_NST_loss", "Spec_loss"]
 
 
+_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32,
+           "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
 class ShmGANwithSSpecSeg:
-    def __init__(self, args=None, device=None, **overrides):
+    def __init__(self, args=None, device=None, compute_dtype="float32", grad_dtype=None, **overrides):
+        """compute_dtype: "float32" (the reference's precision: exact-fp32 MFMA) or "bfloat16" (BASELINE
+        configs 4-5: activations and MFMA operands in bf16, fp32 accumulation, fp32 master weights,
+        statistics, losses, weight gradients and Adam)."""
+        self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
+        # gradient-signal tensors between an input-gradient product and the next IN/LeakyReLU backward:
+        # default = compute_dtype; "float32" with bf16 compute selects SHM_BF16_GF32 (include/shmgan_hip.h)
+        self.grad_dtype = _DTYPES[grad_dtype] if isinstance(grad_dtype, str) else (grad_dtype or self.compute_dtype)
+        if self.compute_dtype == torch.float32:
+            self.grad_dtype = torch.float32
+        self.pad = pad_channels(self.compute_dtype)
         a = dict(_DEFAULTS)
         if args is not None:
             a.update({k: v for k, v in vars(args).items()})
@@ -118,12 +132,13 @@ class ShmGANwithSSpecSeg:
     # ------------------------------------------------------------------ builders
     def build_generator(self):
         """SHM.py:228-327."""
-        return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace, self._get_lane())
+        return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace, self._get_lane(),
+                         dtype=self.compute_dtype, grad_dtype=self.grad_dtype)
 
     def build_discriminator(self):
         """SHM.py:343-380."""
         return Discriminator(self.image_size, self.filter_size, self.device, self.arena, self._workspace,
-                             self.dropout_amnt, self._get_lane())
+                             self.dropout_amnt, self._get_lane(), dtype=self.compute_dtype, grad_dtype=self.grad_dtype)
 
     def build_specseg(self):
         """SHM.py:930-931: SpecSeg(image_size, image_size, 1) then load_model('specsegv3_chkpt.h5').  The
@@ -241,17 +256,18 @@ class ShmGANwithSSpecSeg:
         self.specular_candidate = box["mask"]
 
         # ---- G(1)  SHM.py:517-538
-        gen_in = A.get("g1/in", (B, S, S, PAD_C))
+        adt, PAD_C = self.compute_dtype, self.pad
+        gen_in = A.get("g1/in", (B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, None, fmask, 0, gen_in, B, npix)
         gen_Y = G.forward(gen_in, "g1")
 
         # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
-        xd = A.get("d/x16", (12 * B, S, S, PAD_C))
+        xd = A.get("d/x16", (12 * B, S, S, PAD_C), adt)
         gen_rgb = A.get("g1/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, noise[:B], gen_rgb, xd[0:B], B, B, npix)                  # SHM.py:544-559
 
         # ---- G(2): cyclic  SHM.py:576-624
-        cyc_in = A.get("cyc/in", (5 * B, S, S, PAD_C))
+        cyc_in = A.get("cyc/in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, gen_Y, fmask, 1, cyc_in, B, npix)
         cyc_Y = G.forward(cyc_in, "cyc")
         cyc_rgb = A.get("cyc/rgb", (5 * B, S, S, 3))
@@ -346,13 +362,14 @@ class ShmGANwithSSpecSeg:
         self.specular_candidate = self.SpecSeg.forward_plane(yuv, 3, 0, B, tag="specseg/inf")   # test.py:221
         cbcr = yuv[..., 1:].contiguous()                       # averageCbCr = the input's own CbCr (test.py:224)
         ys = [yuv] * 5
-        gen_in = A.get("inf/in", (B, S, S, PAD_C))
+        adt, PAD_C = self.compute_dtype, self.pad
+        gen_in = A.get("inf/in", (B, S, S, PAD_C), adt)
         ops.build_gen_input(ys, None, 0b11110, 0, gen_in, B, npix)          # views 1..4 zero, one-hot = ED
         gen_Y = G.forward(gen_in, "inf1")
         gen_rgb = A.get("inf/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, None, gen_rgb, None, B, B, npix)
         orig_Ych = gen_rgb[..., 0:1].contiguous()              # test.py:252
-        cyc_in = A.get("inf/cyc_in", (5 * B, S, S, PAD_C))
+        cyc_in = A.get("inf/cyc_in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ys, orig_Ych, 0b11111, 1, cyc_in, B, npix)      # view k zero, the others = orig_Ych
         cyc_Y = G.forward(cyc_in, "inf5")
         cyc_rgb = A.get("inf/cyc_rgb", (5 * B, S, S, 3))
