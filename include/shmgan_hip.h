@@ -115,15 +115,18 @@ int shm_in_apply(const void* a, int lda, const double* stats, const float* beta,
 /* Backward of LeakyReLU -> IN given the gradient at the IN output:
  *   d_out = g1 + 0.25 * g2[h/2][w/2]   (g2 = gradient of AveragePooling2D(2,2), may be NULL)
  *   dz = lrelu'(a) * inv * (d_out - mean(d_out) - xhat * mean(d_out * xhat))
- * red = f64 scratch [batch*c*2]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL).
+ * red = f64 scratch [batch*c*3]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL).
  * g1, g2 are [G] tensors; a and dz are activation-typed. */
 int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
                const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
                int h, int w, int c, float slope, int dtype, void* stream);
 
-/* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y); dy is [G]. */
+/* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y); dy is [G].
+ * dbias = f64 accumulator [c] (NOT zeroed, may be NULL); red = f64 scratch [SHM_LRELU_RED_SLOTS*c]
+ * (needed when dbias is given: the per-channel sums are staged over slots, not on c addresses). */
+#define SHM_LRELU_RED_SLOTS 64
 int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dz, int lddz,
-                  double* dbias, size_t npix, int c, float slope, int dtype, void* stream);
+                  double* dbias, double* red, size_t npix, int c, float slope, int dtype, void* stream);
 
 /* AveragePooling2D(2,2,'same') on even sizes (SHM.py:249,258,267,276). */
 int shm_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int batch, int h, int w, int c,

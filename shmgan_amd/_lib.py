@@ -37,7 +37,7 @@ SIGNATURES = {
     "shm_in_stats": (I, [P, I, P, I, I, I, F, I, P]),
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
-    "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, Z, I, F, I, P]),
+    "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, P, Z, I, F, I, P]),
     "shm_avgpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "shm_cvt_f64_f32": (I, [P, P, Z, I, P]),
     "shm_zero": (I, [P, Z, P]),

@@ -307,6 +307,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     }
     // InstanceNorm statistics of the tile just written: the 64 rows of a wave belong to one sample
     // (hw % 64 == 0), so one f64 atomic per (wave, column, moment).
+    // InstanceNorm statistics of the tile just written: the 64 rows of a wave belong to one sample
+    // (hw % 64 == 0), so one f64 atomic per (wave, column, moment).  (Combining the row-waves of a block
+    // through LDS first was measured: the two extra block barriers cost more than the atomics they save,
+    // -3.5 % fp32 / -12 % bf16 on this kernel.)
     if (a.stats) {
         const int mw = m0 + wm * WTM;
         if (mw < a.M) {
@@ -336,13 +340,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // two taps ahead).  Per tap a wave issues 1 DMA instruction instead of 4, and the A operand moves
 // 6.4x fewer bytes.  Same LDS row format as tapgemm_dma_kernel: 64-byte rows, chunk ^= (row>>2)&3
 // applied on the DMA source side; halo pixels outside the image use offset 0xffffffff (zeros).
-template <typename T, typename TO>
-__global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) {
+template <typename T, typename TO, int BN>
+__global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs a) {
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
-    constexpr int BN = 128, WGN = 2;                  // 8 waves: 4 (M) x 2 (N)
+    constexpr int WGN = BN / 64, NW = 4 * WGN;        // waves: 4 (M) x 2 (N) for BN = 128, 4 x 1 for BN = 64
     constexpr int HC = 18, NHR = 384;                 // halo 18 x 18 = 324 rows, padded to 24 DMA items
     constexpr int ASTG = NHR * 16, BSTG = BN * 16;    // floats per stage
-    constexpr int NA = 3, NB = 1;                     // DMA instructions per wave: A per chunk, B per tap
+    constexpr int NA = 24 / NW, NB = 1;               // DMA instructions per wave: A per chunk, B per tap
     __shared__ __attribute__((aligned(1024))) float smem[2 * ASTG + 3 * BSTG];
     float* const sA = smem;
     float* const sB = smem + 2 * ASTG;
@@ -359,12 +363,12 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
     const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
     const int n0 = blockIdx.y * BN;
 
-    // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+8, w+16
+    // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+NW, ...
     const int drow = lane >> 2, dq = lane & 3;
     unsigned arow1[NA], arow2[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int hrow = 16 * (wave + 8 * j) + drow;
+        const int hrow = 16 * (wave + NW * j) + drow;
         const int hr = hrow / HC, hc = hrow - hr * HC;
         const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
         const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
@@ -400,9 +404,9 @@ __global__ __launch_bounds__(512) void tapgemm_halo_kernel(const TapGemmArgs a) 
             const unsigned r = second ? arow2[j] : arow1[j];
             const unsigned off = r == 0xffffffffu ? r : r + cb;
             if (second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + j * 8 * 256), 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + j * NW * 256), 16, (int)off, 0, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + j * 8 * 256), 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + j * NW * 256), 16, (int)off, 0, 0, 0);
         }
     };
     int ld_tap = 0, ld_chunk = 0, ld_stage = 0;    // position of the next weight DMA
@@ -539,8 +543,11 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
     static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
     static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
     constexpr int BKE = 64 / (int)sizeof(T);
-    if (use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && a.nout > 64 && a.hi % 16 == 0 && a.wi % 16 == 0 &&
-        a.hg == a.hi && a.wg == a.wi) {
+    // Cout <= 64: the 4-wave BN = 64 variant.  In fp32 it is off by default (SHM_TAPGEMM_HALO64=1 to try).
+    static const int halo64 = getenv("SHM_TAPGEMM_HALO64") ? atoi(getenv("SHM_TAPGEMM_HALO64")) : -1;
+    const bool small_ok = halo64 >= 0 ? halo64 != 0 : sizeof(T) == 2;
+    if (use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && (a.nout > 64 || small_ok) && a.hi % 16 == 0 &&
+        a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi) {
         bool unit = true;                      // every tap within the 1-pixel halo
         for (int t = 0; t < 9; ++t) unit = unit && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
         // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
@@ -548,9 +555,14 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
         // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
         static const int halo_min = getenv("SHM_TAPGEMM_HALO_MIN") ? atoi(getenv("SHM_TAPGEMM_HALO_MIN")) : 1024;
         const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
+        if (unit && a.nout <= 64) {
+            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), 1, 1);
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), grid, dim3(256), 0, st, a);
+            return;
+        }
         if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
-            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO>), grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), grid, dim3(512), 0, st, a);
             return;
         }
     }

@@ -181,13 +181,14 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ a, 
     }
     const T* base = a + (size_t)n * hw * lda + pm.cl * 4;
     T* ob = out + (size_t)n * hw * ldo + pm.cl * 4;
+    constexpr int U = sizeof(T) == 2 ? 8 : 4;
     int p = p0 + pm.pp;
-    for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
-        f32x4 x[4];
+    for (; p + (U - 1) * pm.PP < p1; p += U * pm.PP) {
+        f32x4 x[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = ld4(base + (size_t)(p + u * pm.PP) * lda);
+        for (int u = 0; u < U; ++u) x[u] = ld4(base + (size_t)(p + u * pm.PP) * lda);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (x[u][e] - mean[e]) * inv[e] + bt[e];
@@ -231,10 +232,13 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     float slope;
 };
 
-template <typename TG>
+// G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
+// before the branch (s_waitcnt vmcnt(0) + s_cbranch per pixel), which serialises the whole stream
+// (measured 2.0 TB/s instead of 5+).
+template <typename TG, bool G2>
 __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, int cl) {
     f32x4 g = ld4((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
-    if (k.g2) {
+    if constexpr (G2) {
         int y = p / k.w, x = p - y * k.w;
         size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
         f32x4 u = ld4((const TG*)k.g2 + q * k.ldg2 + cl * 4);
@@ -244,7 +248,7 @@ __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, i
     return g;
 }
 
-template <typename T, typename TG>
+template <typename T, typename TG, bool G2>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
     const int n = blockIdx.y, hw = k.h * k.w;
@@ -257,21 +261,23 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             mean[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2];
             inv[e] = (float)k.stats[((size_t)n * k.c + pm.cl * 4 + e) * 2 + 1];
         }
-        // 4 pixels per iteration: 8-12 independent 16-byte loads in flight per thread; the per-pixel
-        // partial sums are combined in fp32 (4 terms) before the fp64 accumulation
+        // U pixels per iteration: the kernel is bound by bytes in flight, not by arithmetic -- 4 pixels of
+        // 16-byte loads in fp32, 8 pixels of 8-byte loads in bf16 keep the same 8-12 x 16 B outstanding
+        // per thread; the per-pixel partial sums are combined in fp32 before the fp64 accumulation
+        constexpr int U = sizeof(T) == 2 ? 8 : 4;
         int p = p0 + pm.pp;
-        for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
-            f32x4 g[4], x[4];
+        for (; p + (U - 1) * pm.PP < p1; p += U * pm.PP) {
+            f32x4 g[U], x[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g[u] = in_bwd_dout<TG>(k, n, p + u * pm.PP, pm.cl);
+            for (int u = 0; u < U; ++u) {
+                g[u] = in_bwd_dout<TG, G2>(k, n, p + u * pm.PP, pm.cl);
                 x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float sg = 0.f, sx = 0.f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     float xh = (x[u][e] - mean[e]) * inv[e];
                     sg += g[u][e];
                     sx += g[u][e] * xh;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             }
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout<TG>(k, n, p, pm.cl);
+            f32x4 g = in_bwd_dout<TG, G2>(k, n, p, pm.cl);
             f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     block_reduce_atomic<2>(v, pm, k.red + (size_t)n * k.c * 2, k.c, true);
 }
 
-template <typename T, typename TG>
+template <typename T, typename TG, bool G2>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
     const int n = blockIdx.y, hw = k.h * k.w;
@@ -310,17 +316,18 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             m1[e] = (float)(k.red[i] / hw);
             m2[e] = (float)(k.red[i + 1] / hw);
         }
+        constexpr int U = sizeof(T) == 2 ? 8 : 4;
         int p = p0 + pm.pp;
-        for (; p + 3 * pm.PP < p1; p += 4 * pm.PP) {
-            f32x4 g[4], x[4];
+        for (; p + (U - 1) * pm.PP < p1; p += U * pm.PP) {
+            f32x4 g[U], x[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g[u] = in_bwd_dout<TG>(k, n, p + u * pm.PP, pm.cl);
+            for (int u = 0; u < U; ++u) {
+                g[u] = in_bwd_dout<TG, G2>(k, n, p + u * pm.PP, pm.cl);
                 x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
             float sd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 f32x4 d;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout<TG>(k, n, p, pm.cl);
+            f32x4 g = in_bwd_dout<TG, G2>(k, n, p, pm.cl);
             f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
             f32x4 d;
 #pragma unroll
@@ -348,7 +355,18 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             st4((T*)k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4, d);
         }
     }
-    if (k.dbias) block_reduce_atomic<1>(v, pm, k.dbias, k.c, true);
+    // bias gradient: staged per sample in red[2*batch*c + n*c + ch] -- one f64 atomic address per (n, ch)
+    // instead of per ch (4096 blocks on 64 addresses cost 90-210 us per launch), folded by dbias_fold_kernel
+    if (k.dbias) block_reduce_atomic<1>(v, pm, k.red + (size_t)gridDim.y * k.c * 2 + (size_t)n * k.c, k.c, true);
+}
+
+// dbias[ch] += sum over slots of part[slot*c + ch]
+__global__ void dbias_fold_kernel(const double* __restrict__ part, double* __restrict__ dbias, int nslot, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0;
+    for (int i = 0; i < nslot; ++i) s += part[(size_t)i * c + ch];
+    dbias[ch] += s;
 }
 
 extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
@@ -359,16 +377,26 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "shm_in_bwd: pooled gradient needs even h,w");
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
-    int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
+    int r = shm_zero(red, (size_t)batch * c * 3 * sizeof(double), stream);
     if (r) return r;
     InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope};
     int hw = h * w;
     int nch = pix_chunks(hw, batch, c);
     k.chunk = shm_cdiv(hw, nch);
     dim3 grid(shm_cdiv(hw, k.chunk), batch);
-    SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG>), grid, dim3(256), 0, st, k));
-    SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-    SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG>), grid, dim3(256), 0, st, k));
+    if (g2) {
+        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+    } else {
+        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+    }
+    if (dbias) {
+        SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, st, (const double*)(red + (size_t)batch * c * 2), dbias, batch, c);
+    }
     SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
     return SHM_OK;
 }
@@ -376,13 +404,36 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
 // ---------------------------------------------------------------------- LeakyReLU backward
 template <typename T, typename TG>
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const TG* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy, T* __restrict__ dz, int lddz,
-                                                        double* dbias, size_t npix, int c, size_t chunk, float slope) {
+                                                        double* dpart, size_t npix, int c, size_t chunk, float slope) {
     PixMap pm(c);
     const size_t p0 = (size_t)blockIdx.x * chunk;
     const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
     double v[1][4] = {};
     if (pm.active) {
-        for (size_t p = p0 + pm.pp; p < p1; p += pm.PP) {
+        constexpr int U = sizeof(T) == 2 ? 8 : 4;
+        size_t p = p0 + pm.pp;
+        for (; p + (size_t)(U - 1) * pm.PP < p1; p += (size_t)U * pm.PP) {
+            f32x4 g[U], x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                g[u] = ld4(dy + (p + (size_t)u * pm.PP) * lddy + pm.cl * 4);
+                x[u] = ld4(y + (p + (size_t)u * pm.PP) * ldy + pm.cl * 4);
+            }
+            float sd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d[e] = x[u][e] > 0.f ? g[u][e] : g[u][e] * slope;
+                    sd[e] += d[e];
+                }
+                st4(dz + (p + (size_t)u * pm.PP) * lddz + pm.cl * 4, d);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
+        }
+        for (; p < p1; p += pm.PP) {
             f32x4 g = ld4(dy + p * lddy + pm.cl * 4);
             f32x4 x = ld4(y + p * ldy + pm.cl * 4);
             f32x4 d;
@@ -394,20 +445,29 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const TG* __restrict__ d
             st4(dz + p * lddz + pm.cl * 4, d);
         }
     }
-    if (dbias) block_reduce_atomic<1>(v, pm, dbias, c, true);
+    if (dpart) block_reduce_atomic<1>(v, pm, dpart + (size_t)(blockIdx.x % SHM_LRELU_RED_SLOTS) * c, c, true);
 }
 
 extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dz, int lddz,
-                             double* dbias, size_t npix, int c, float slope, int dtype, void* stream) {
+                             double* dbias, double* red, size_t npix, int c, float slope, int dtype, void* stream) {
+    SHM_REQUIRE(!dbias || red, SHM_E_SHAPE, "shm_lrelu_bwd: dbias needs the f64 scratch `red`");
     SHM_CHECK_C(c, "shm_lrelu_bwd");
     SHM_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0, SHM_E_SHAPE, "shm_lrelu_bwd: bad pitch");
     if (npix == 0) return SHM_OK;
+    if (dbias) {
+        int r = shm_zero(red, (size_t)SHM_LRELU_RED_SLOTS * c * sizeof(double), stream);
+        if (r) return r;
+    }
     int nch = pix_chunks((long)npix, 1, c);
     size_t chunk = (npix + nch - 1) / nch;
     SHM_DISPATCH_G(dtype, "shm_lrelu_bwd",
                  hipLaunchKernelGGL((lrelu_bwd_kernel<T, TG>), dim3(shm_cdiv((long)npix, (long)chunk)), dim3(256), 0, (hipStream_t)stream, (const TG*)dy, lddy,
-                                    (const T*)y, ldy, (T*)dz, lddz, dbias, npix, c, chunk, slope));
+                                    (const T*)y, ldy, (T*)dz, lddz, dbias ? red : nullptr, npix, c, chunk, slope));
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
+    if (dbias) {
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dbias, SHM_LRELU_RED_SLOTS, c);
+        SHM_LAUNCH_CHECK("shm_lrelu_bwd(fold)");
+    }
     return SHM_OK;
 }
 

@@ -320,7 +320,7 @@ class Generator(_ModelBase):
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
         dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
-        red = A.get(f"bwd/red/{n * cout}", (n * cout * 2,), torch.float64)
+        red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
         ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
                    h, w, cout, LRELU)
         if self.debug is not None:           # test diagnostics: keep the per-layer gradients
@@ -367,7 +367,8 @@ class Generator(_ModelBase):
             tli = up["li"]
             _, _, _, tcin, tcout = self.layers[tli]
             dzu = A.get(f"bwd/dzu/L{tli}/{n}", (n, h, h, cu), self.adt)
-            ops.lrelu_bwd(du, cu, up["u"], cu, dzu, cu, self._acc_slice(2 * tli + 1), n * h * h, cu, LRELU)
+            lred = A.get(f"bwd/lred/{cu}", (ops.LRELU_RED_SLOTS * cu,), torch.float64)
+            ops.lrelu_bwd(du, cu, up["u"], cu, dzu, cu, self._acc_slice(2 * tli + 1), n * h * h, cu, LRELU, lred)
             ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, tcout, tcin, 3))
             self.lane.submit(lambda dzu=dzu, up=up, tli=tli, tcout=tcout, tcin=tcin, h=h, ws=ws: ops.conv2d_wgrad(
                 dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout, tcin, 3, 2, 1, ws))
@@ -570,7 +571,7 @@ class Discriminator(_ModelBase):
             h = rec["h"]
             ho = h // 2
             dz = A.get(f"d/bwd/dz{i}/{n}", (n, ho, ho, cout), self.adt)
-            red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 2,), torch.float64)
+            red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 3,), torch.float64)
             ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
             if params:
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))

@@ -175,8 +175,12 @@ def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w,
                            batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd")
 
 
-def lrelu_bwd(dy, lddy, y, ldy, dz, lddz, dbias, npix, c, slope):
-    check(lib().shm_lrelu_bwd(_p(dy), lddy, _p(y), ldy, _p(dz), lddz, _p(dbias), npix, c, slope, _dtg(y, dy), _stream()),
+LRELU_RED_SLOTS = 64        # SHM_LRELU_RED_SLOTS
+
+
+def lrelu_bwd(dy, lddy, y, ldy, dz, lddz, dbias, npix, c, slope, red=None):
+    """red: f64 scratch [LRELU_RED_SLOTS * c], required with dbias."""
+    check(lib().shm_lrelu_bwd(_p(dy), lddy, _p(y), ldy, _p(dz), lddz, _p(dbias), _p(red), npix, c, slope, _dtg(y, dy), _stream()),
           "shm_lrelu_bwd")
 
 
