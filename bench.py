@@ -175,11 +175,13 @@ def main():
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic = None
-            tpath = ROOT / "profiles" / "r01_v2_traffic_pmc.json"      # rocprofv3 --pmc passes (see profiles/README.md)
+            # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py, profiles/README.md)
+            tpath = ROOT / "profiles" / ("r01_v3_traffic_pmc.json" if args.dtype == "f32" else "r01_v3_traffic_pmc_bf16.json")
             if tpath.exists():
                 tj = json.loads(tpath.read_text())
+                key = dom.split(" (+")[0].replace(" ", "")
                 for name, rec in tj.items():
-                    if name.replace("void ", "").replace(" ", "") == dom.replace(" ", ""):
+                    if name.replace(" ", "") == key:
                         traffic = rec["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,

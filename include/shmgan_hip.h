@@ -49,6 +49,10 @@ extern "C" {
 
 int shm_version(void);
 const char* shm_last_error(void);
+/* Symbol (as rocprofv3 prints it, without the "void " prefix and the argument list) of the MFMA kernel
+ * the calling thread's last convolution entry point dispatched to: the tile/variant choice depends on
+ * shape and dtype, and bench.py's per-kernel roofline keys its HIP-event timings by it. */
+const char* shm_last_kernel(void);
 
 /* ---- weight layout ---------------------------------------------------------------
  * [ntaps][rows][cols] -> [ntaps][cols][rows_pad] (zero padded): HWIO -> K-contiguous
@@ -72,11 +76,14 @@ int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, con
 /* The same convolution fused with the InstanceNormalization statistics of its output
  * (Conv2D -> LeakyReLU -> InstanceNormalization, SHM.py:244-245): the epilogue accumulates
  * sum / sum of squares per (sample, channel); on return (stream order) stats holds
- * (mean, rsqrt(var + eps)) exactly as shm_in_stats would leave it.  stats = f64 [batch*cout*2]. */
+ * (mean, rsqrt(var + eps)) exactly as shm_in_stats would leave it.  stats = f64 [batch*cout*2];
+ * scratch = f64 [SHM_STATS_SLOTS*batch*cout*2] or NULL: slot copies of the running sums, so that the
+ * hw/64 atomic adds per (sample, channel) do not queue on one address. */
+#define SHM_STATS_SLOTS 16
 int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                       const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
-                      int cout, int ksize, int stride, float slope, double* stats, float eps,
-                      int dtype, void* stream);
+                      int cout, int ksize, int stride, float slope, double* stats, double* scratch,
+                      float eps, int dtype, void* stream);
 
 /* Input-gradient of the same conv.  dy [batch,ho,wo,cout] (pitch lddy), w = HWIO
  * [k*k][cin][cout] as stored (it is already K-contiguous for this product), cout % 16 == 0.
@@ -98,6 +105,14 @@ int shm_conv2d_transpose_fwd(const void* x, int ldx, const void* w, const float*
  * input channels to read (multiple of 4, pad channels must be zero), cin = rows stored.
  * workspace: split-K partial slabs, at least shm_conv2d_wgrad_workspace() bytes. */
 size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize);
+/* The two phases of shm_conv2d_wgrad as separate calls (bench.py times the MFMA kernel on its own):
+ * _partial writes *nsplit_out slabs [ksize*ksize][cin][cout] to workspace; _reduce sums them into dw. */
+int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
+                             int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout,
+                             int ksize, int stride, void* workspace, size_t ws_bytes, int dtype,
+                             int* nsplit_out, void* stream);
+int shm_conv2d_wgrad_reduce(const void* workspace, float* dw, size_t n, int nsplit, int accumulate,
+                            void* stream);
 int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
                      int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
                      int cout, int ksize, int stride, int accumulate, void* workspace,

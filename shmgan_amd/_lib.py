@@ -26,13 +26,16 @@ P, I, Z, F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 SIGNATURES = {
     "shm_version": (I, []),
     "shm_last_error": (C.c_char_p, []),
+    "shm_last_kernel": (C.c_char_p, []),
     "shm_transpose_taps": (I, [P, P, I, I, I, I, I, P]),
     "shm_cast_f32": (I, [P, P, Z, I, P]),
     "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
-    "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, F, I, P]),
+    "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, P, F, I, P]),
     "shm_conv2d_dgrad": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "shm_conv2d_transpose_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, I, P]),
     "shm_conv2d_wgrad_workspace": (Z, [I, I, I, I, I, I]),
+    "shm_conv2d_wgrad_partial": (I, [P, P, I, I, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P, P]),
+    "shm_conv2d_wgrad_reduce": (I, [P, P, Z, I, I, P]),
     "shm_conv2d_wgrad": (I, [P, P, I, I, I, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
     "shm_in_stats": (I, [P, I, P, I, I, I, F, I, P]),
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),

@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16_t;            // activation element type of the bf16 path (SHM_BF16)
 
 void shm_set_error(const char* fmt, ...);
+void shm_set_last_kernel(const char* fmt, ...);        // symbol of the MFMA kernel a convolution entry point chose
 
 // 4-channel vector access in either element type; arithmetic is always fp32.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }

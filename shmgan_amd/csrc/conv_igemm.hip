@@ -45,8 +45,10 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
     int is, os;         // A stride, output stride
     int M;              // batch*hg*wg
     unsigned xbytes, x2bytes, wbytes;   // buffer-descriptor extents (bytes)
-    double* stats;      // optional [batch][nout][2] (sum, sum of squares) of the stored outputs
+    double* stats;      // optional [slot][batch][nout][2] (sum, sum of squares) of the stored outputs
     int hw;             // pixels per sample (stats only; hw % 64 == 0)
+    int stats_slots;    // slot copies: wave tile t of a sample adds into slot t % stats_slots
+    unsigned stats_stride;   // batch * nout * 2
     float slope;
     TapPhase ph[4];
 };
@@ -315,13 +317,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const int mw = m0 + wm * WTM;
         if (mw < a.M) {
             const int img = mw / a.hw;
+            const int slot = ((mw - img * a.hw) / WTM) % a.stats_slots;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
                 float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 if (h == 0 && n < a.nout) {
-                    double* dst = a.stats + ((size_t)img * a.nout + n) * 2;
+                    double* dst = a.stats + (size_t)slot * a.stats_stride + ((size_t)img * a.nout + n) * 2;
                     atomicAdd(dst, (double)t1);
                     atomicAdd(dst + 1, (double)t2);
                 }
@@ -520,13 +523,14 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
         }
     }
     if (a.stats) {
+        const int slot = (prem * 4 + wm) % a.stats_slots;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
             float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
             const int n = n0 + wn * 64 + j * 32 + l31;
             if (h == 0 && n < a.nout) {
-                double* dst = a.stats + ((size_t)img * a.nout + n) * 2;
+                double* dst = a.stats + (size_t)slot * a.stats_stride + ((size_t)img * a.nout + n) * 2;
                 atomicAdd(dst, (double)t1);
                 atomicAdd(dst + 1, (double)t2);
             }
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
 }
 
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
-static thread_local int g_conv_hw = 0;
+static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
 template <typename T, typename TO>
 static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStream_t st) {
@@ -543,6 +547,8 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
     static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
     static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
     constexpr int BKE = 64 / (int)sizeof(T);
+    const char* tn = sizeof(T) == 4 ? "float" : "__bf16";
+    const char* ton = sizeof(TO) == 4 ? "float" : "__bf16";
     // Cout <= 64: the 4-wave BN = 64 variant.  In fp32 it is off by default (SHM_TAPGEMM_HALO64=1 to try).
     static const int halo64 = getenv("SHM_TAPGEMM_HALO64") ? atoi(getenv("SHM_TAPGEMM_HALO64")) : -1;
     const bool small_ok = halo64 >= 0 ? halo64 != 0 : sizeof(T) == 2;
@@ -558,29 +564,38 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
         if (unit && a.nout <= 64) {
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), 1, 1);
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), grid, dim3(256), 0, st, a);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64>", tn, ton);
             return;
         }
         if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), grid, dim3(512), 0, st, a);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128>", tn, ton);
             return;
         }
     }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
     if (a.nout > 64 && bk32 && a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0)) {
-        if (bk32 == 2)
+        if (bk32 == 2) {
             hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
-        else
+            shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 4, 16>", tn, ton);
+        } else {
             hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
+            shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 2, 32>", tn, ton);
+        }
     } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 128, 4, 2, 3, 16>", tn, ton);
     } else if (a.nout > 64) {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 3, 16>", tn, ton);
     } else if (dma_small == 0) {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 2, 16>), grid1d(256, 64), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 64, 4, 1, 2, 16>", tn, ton);
     } else {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 64, 2, 2, 3, 16>", tn, ton);
     }
 }
 
@@ -589,6 +604,8 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
                 "%s: dtype %d not in {SHM_F32, SHM_BF16, SHM_BF16_GF32}", who, dtype);
     a.stats = g_conv_stats;
     a.hw = g_conv_hw;
+    a.stats_slots = g_conv_slots;
+    a.stats_stride = (unsigned)batch * (unsigned)a.nout * 2u;
     SHM_REQUIRE(dtype != SHM_BF16_GF32 || a.stats == nullptr, SHM_E_DTYPE, "%s: SHM_BF16_GF32 has no fused statistics", who);
     const int esz = dtype == SHM_F32 ? 4 : 2, bke = 64 / esz, che = 16 / esz;
     SHM_REQUIRE(a.K % bke == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of %d", who, a.K, bke);
@@ -698,12 +715,12 @@ extern "C" int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, in
     return launch_tapgemm(a, batch, 1, dtype, (hipStream_t)stream, "shm_conv2d_fwd");
 }
 
-int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipStream_t st);
+int shm_in_finalize_internal(double* stats, const double* part, int nslot, int total, int hw, double eps, hipStream_t st);
 
 extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                                  const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
-                                 int cout, int ksize, int stride, float slope, double* stats, float eps,
-                                 int dtype, void* stream) {
+                                 int cout, int ksize, int stride, float slope, double* stats, double* scratch,
+                                 float eps, int dtype, void* stream) {
     SHM_REQUIRE(stats, SHM_E_SHAPE, "shm_conv2d_in_fwd: null stats");
     int ho, wo, pt;
     shm_same_pad(hi, ksize, stride, &ho, &pt);
@@ -715,14 +732,21 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
         if (r) return r;
         return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, dtype, stream);
     }
-    int r = shm_zero(stats, (size_t)batch * cout * 2 * sizeof(double), stream);
+    // Every wave tile of a sample adds its column sums with f64 atomics: on one copy that is hw/64 atomics
+    // per address, a serial chain worth ~100 us at 256x256 whatever the batch (measured, bf16 and fp32).
+    // With `scratch` the chain is cut SHM_STATS_SLOTS-fold and the finalize kernel sums the copies.
+    double* acc = scratch ? scratch : stats;
+    const int slots = scratch ? SHM_STATS_SLOTS : 1;
+    int r = shm_zero(acc, (size_t)slots * batch * cout * 2 * sizeof(double), stream);
     if (r) return r;
-    g_conv_stats = stats;
+    g_conv_stats = acc;
+    g_conv_slots = slots;
     g_conv_hw = hw;
     r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
     g_conv_stats = nullptr;
+    g_conv_slots = 1;
     if (r) return r;
-    return shm_in_finalize_internal(stats, batch * cout, hw, (double)eps, (hipStream_t)stream);
+    return shm_in_finalize_internal(stats, scratch, slots, batch * cout, hw, (double)eps, (hipStream_t)stream);
 }
 
 // Transposed stride-2 product shared by Conv2DTranspose forward and the stride-2 dgrad:

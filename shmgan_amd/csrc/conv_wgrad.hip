@@ -616,10 +616,12 @@ extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin,
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
 
-extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
-                                int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
-                                int cout, int ksize, int stride, int accumulate, void* workspace,
-                                size_t ws_bytes, int dtype, void* stream) {
+// Phase 1 of shm_conv2d_wgrad: the MFMA kernel; *nsplit_out receives the number of partial slabs written.
+extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
+                                        int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout,
+                                        int ksize, int stride, void* workspace, size_t ws_bytes, int dtype,
+                                        int* nsplit_out, void* stream) {
+    float* dw = (float*)workspace;      // only checked for non-null below
     SHM_REQUIRE(dtype == SHM_F32 || dtype == SHM_BF16, SHM_E_DTYPE, "shm_conv2d_wgrad: dtype %d not in {SHM_F32, SHM_BF16}", dtype);
     const int esz = dtype == SHM_BF16 ? 2 : 4, vec = 16 / esz;      // 16-byte loads: 4 floats / 8 bf16
     SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_wgrad: ksize %d not in {1,3}", ksize);
@@ -689,6 +691,7 @@ extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, 
             else
                 hipLaunchKernelGGL((wgrad_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
         }
+        shm_set_last_kernel("wgrad_bf16_kernel<%d, %s>", ksize * ksize, straddle ? "true" : "false");
     } else if (ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo) {
         WgradHaloArgs hgs{};
         hgs.x = x;
@@ -714,6 +717,7 @@ extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, 
         ns = nsh;
         dim3 gridh(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
         hipLaunchKernelGGL(wgrad_halo_kernel, gridh, dim3(256), 0, st, hgs);
+        shm_set_last_kernel("wgrad_halo_kernel");
     } else {
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
     if (ksize == 3) {
@@ -727,10 +731,31 @@ extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, 
         else
             hipLaunchKernelGGL((wgrad_kernel<1, false>), grid, dim3(256), 0, st, a);
     }
+    shm_set_last_kernel("wgrad_kernel<%d, %s>", ksize * ksize, straddle ? "true" : "false");
     }
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad");
-    size_t n = (size_t)a.ntaps * cin * cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shm_cdiv((long)n, 64)), dim3(256), 0, st, (const float*)workspace, dw, n, ns, accumulate);
+    if (nsplit_out) *nsplit_out = ns;
+    return SHM_OK;
+}
+
+// Phase 2: dw[i] (+)= sum over the nsplit slabs, in a fixed order.
+extern "C" int shm_conv2d_wgrad_reduce(const void* workspace, float* dw, size_t n, int nsplit, int accumulate, void* stream) {
+    SHM_REQUIRE(workspace && dw && nsplit >= 1, SHM_E_SHAPE, "shm_conv2d_wgrad_reduce: bad arguments");
+    if (n == 0) return SHM_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shm_cdiv((long)n, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, n, nsplit,
+                       accumulate);
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad(reduce)");
     return SHM_OK;
+}
+
+extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
+                                int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld,
+                                int cout, int ksize, int stride, int accumulate, void* workspace,
+                                size_t ws_bytes, int dtype, void* stream) {
+    SHM_REQUIRE(dw, SHM_E_SHAPE, "shm_conv2d_wgrad: null pointer");
+    int ns = 0;
+    int r = shm_conv2d_wgrad_partial(x, x2, c1, ldx, ldx2, dy, lddy, batch, hi, wi, cin, cin_ld, cout, ksize, stride, workspace, ws_bytes, dtype,
+                                     &ns, stream);
+    if (r) return r;
+    return shm_conv2d_wgrad_reduce(workspace, dw, (size_t)ksize * ksize * cin * cout, ns, accumulate, stream);
 }

@@ -20,8 +20,18 @@ void shm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[128] = "";
+
+void shm_set_last_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 extern "C" const char* shm_last_error(void) { return g_err; }
-extern "C" int shm_version(void) { return 100; }
+extern "C" const char* shm_last_kernel(void) { return g_kernel; }
+extern "C" int shm_version(void) { return 110; }
 
 extern "C" int shm_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return SHM_OK;
@@ -130,10 +140,21 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ a, 
     block_reduce_atomic<2>(v, pm, stats + (size_t)n * c * 2, c, true);
 }
 
-__global__ void in_finalize_kernel(double* __restrict__ stats, int total, int hw, double eps) {
+// part != null: the sums were accumulated over `nslot` slot copies part[slot][total][2]
+__global__ void in_finalize_kernel(double* __restrict__ stats, const double* __restrict__ part, int nslot, int total, int hw, double eps) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    double s = stats[2 * i], q = stats[2 * i + 1];
+    double s, q;
+    if (part) {
+        s = q = 0.0;
+        for (int k = 0; k < nslot; ++k) {
+            s += part[((size_t)k * total + i) * 2];
+            q += part[((size_t)k * total + i) * 2 + 1];
+        }
+    } else {
+        s = stats[2 * i];
+        q = stats[2 * i + 1];
+    }
     double mean = s / hw;
     double var = q / hw - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -141,8 +162,8 @@ __global__ void in_finalize_kernel(double* __restrict__ stats, int total, int hw
     stats[2 * i + 1] = 1.0 / sqrt(var + eps);
 }
 
-int shm_in_finalize_internal(double* stats, int total, int hw, double eps, hipStream_t st) {
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, total, hw, eps);
+int shm_in_finalize_internal(double* stats, const double* part, int nslot, int total, int hw, double eps, hipStream_t st) {
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, part, nslot, total, hw, eps);
     SHM_LAUNCH_CHECK("shm_in_finalize");
     return SHM_OK;
 }
@@ -159,7 +180,7 @@ extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, in
     SHM_DISPATCH(dtype, "shm_in_stats",
                  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, (const T*)a, lda, stats, hw, c, chunk));
     SHM_LAUNCH_CHECK("shm_in_stats");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, batch * c, hw, (double)eps);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, (const double*)nullptr, 0, batch * c, hw, (double)eps);
     SHM_LAUNCH_CHECK("shm_in_stats(finalize)");
     return SHM_OK;
 }

@@ -254,8 +254,9 @@ class Generator(_ModelBase):
         a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
         ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt)
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
+        scr = A.get(f"stats_scratch/{n * cout}", (ops.STATS_SLOTS * n * cout * 2,), torch.float64)
         ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
-                          k, 1, LRELU, stats, IN_EPS, cin_real=cin)
+                          k, 1, LRELU, stats, IN_EPS, cin_real=cin, scratch=scr)
         ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
         return ahat, rec
@@ -517,8 +518,9 @@ class Discriminator(_ModelBase):
             ho = h // 2
             a, ahat, stats = bufs[i]
             st = stats[r0 * cout * 2:r1 * cout * 2]
+            scr = self.arena.get(f"d/stats_scratch/{nb * cout}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
             ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a[r0:r1], cout, nb, h, h, _padk(cin, self.pad), cout, 3, 2,
-                              LRELU, st, IN_EPS, cin_real=cin)
+                              LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
             ops.in_apply(a[r0:r1], cout, st, self.betas[i], ahat[r0:r1], cout, nb, ho * ho, cout)
             cur, ld, h = ahat[r0:r1], cout, ho
 

@@ -18,17 +18,21 @@ def _stream():
 class KernelTimer:
     """HIP-event timing of the MFMA conv launches on the stream they run on (bench.py
     `roofline`).  Enabled by setting ops.TIMER = KernelTimer(); records (kernel symbol,
-    algorithmic flops, start event, end event) per launch."""
+    algorithmic flops, start event, end event) per launch.  The symbol is the one the entry point reports
+    through shm_last_kernel() (plus a suffix when the timed region holds more than that kernel)."""
 
     def __init__(self):
         self.recs = []
 
-    def wrap(self, sym, flops, fn, label=""):
+    def wrap(self, sym, flops, fn, label="", fixed=False):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
+        if not fixed:
+            k = lib().shm_last_kernel()               # the variant the entry point actually dispatched to
+            sym = (k.decode() if k else "?") + sym
         self.recs.append((sym, flops, e0, e1, label))
 
     def per_shape(self):
@@ -53,10 +57,6 @@ class KernelTimer:
 
 
 TIMER = None
-
-
-def _tile(nout):
-    return "tapgemm_dma_kernel<128,128,2,2>" if nout > 64 else "tapgemm_dma_kernel<128,64,2,2>"
 
 
 def _timed(sym, flops, fn, label=""):
@@ -90,10 +90,6 @@ def _dtg(act, grad):
     return d
 
 
-def _sfx(t):
-    return "/bf16" if t.dtype == torch.bfloat16 else ""
-
-
 def cast_f32(src, dst, n):
     check(lib().shm_cast_f32(_p(src), _p(dst), n, _dt(dst), _stream()), "shm_cast_f32")
 
@@ -107,27 +103,32 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
     """cin_real: un-padded input channels, only used for the algorithmic flop count."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
-    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
+    _timed("", flops, lambda: check(
         lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
                              cin, cout, ksize, stride, slope, _dtg(x, y), _stream()), "shm_conv2d_fwd"),
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
+STATS_SLOTS = 16            # SHM_STATS_SLOTS
+
+
 def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, eps,
-                  cin_real=None):
-    """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std)."""
+                  cin_real=None, scratch=None):
+    """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std).
+    scratch: optional f64 [STATS_SLOTS * batch * cout * 2] (spreads the statistics atomics)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
-    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
+    _timed("", flops, lambda: check(
         lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                                cin, cout, ksize, stride, slope, _p(stats), eps, _dt(x), _stream()), "shm_conv2d_in_fwd"),
+                                cin, cout, ksize, stride, slope, _p(stats), _p(scratch), eps, _dt(x), _stream()),
+        "shm_conv2d_in_fwd"),
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
-    _timed(_tile(cin) + _sfx(dy), flops, lambda: check(
+    _timed("", flops, lambda: check(
         lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
                                cout, ksize, stride, _dtg(dy, dx), _stream()), "shm_conv2d_dgrad"),
            f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}")
@@ -135,7 +136,7 @@ def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout
 
 def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
     flops = 2.0 * batch * hi * wi * 9 * cin * cout
-    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
+    _timed("", flops, lambda: check(
         lib().shm_conv2d_transpose_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
                                        slope, _dt(x), _stream()), "shm_conv2d_transpose_fwd"),
            f"convT n{batch} h{hi} {cin}->{cout}")
@@ -149,16 +150,23 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
                  accumulate, ws):
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
-    halo = ksize == 3 and stride == 1 and wi % 16 == 0 and hi % 2 == 0 and not (x2 is not None and c1 % 64 != 0)
-    if x.dtype == torch.bfloat16:
-        sym = "wgrad_bf16_kernel<%d>(+reduce)" % (ksize * ksize)
-    else:
-        sym = "wgrad_halo_kernel(+reduce)" if halo else "wgrad_kernel<%d>(+reduce)" % (ksize * ksize)
-    _timed(sym, flops, lambda: check(
-        lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
-                               cout, ksize, stride, int(accumulate), _p(ws), ws.numel() * ws.element_size(),
-                               _dt(x), _stream()), "shm_conv2d_wgrad"),
-           f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}")
+    label = f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}"
+    wsb = ws.numel() * ws.element_size()
+    if TIMER is None:
+        check(lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
+                                     cout, ksize, stride, int(accumulate), _p(ws), wsb, _dt(x), _stream()),
+              "shm_conv2d_wgrad")
+        return
+    # timing mode: the two phases as separate calls, so the MFMA kernel's events hold nothing else
+    import ctypes
+    ns = ctypes.c_int(0)
+    TIMER.wrap("", flops, lambda: check(
+        lib().shm_conv2d_wgrad_partial(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
+                                       ksize, stride, _p(ws), wsb, _dt(x), ctypes.addressof(ns), _stream()),
+        "shm_conv2d_wgrad_partial"), label)
+    TIMER.wrap("wgrad_reduce_kernel", 0.0, lambda: check(
+        lib().shm_conv2d_wgrad_reduce(_p(ws), _p(dw), ksize * ksize * cin * cout, ns.value, int(accumulate), _stream()),
+        "shm_conv2d_wgrad_reduce"), label, fixed=True)
 
 
 def in_stats(a, lda, stats, batch, hw, c, eps):
@@ -298,7 +306,7 @@ def maxpool2_fwd(x, ldx, y, ldy, batch, h, w, c):
 
 def conv2d_transpose2x2_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope=1.0):
     flops = 2.0 * batch * hi * wi * 4 * cin * cout
-    _timed(_tile(cout) + _sfx(x), flops, lambda: check(
+    _timed("", flops, lambda: check(
         lib().shm_conv2d_transpose2x2_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout,
                                           slope, _dt(x), _stream()), "shm_conv2d_transpose2x2_fwd"),
            f"convT2 n{batch} h{hi} {cin}->{cout}")

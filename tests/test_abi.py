@@ -32,8 +32,10 @@ def test_version_and_error_string_without_gpu():
     # shape errors are detected on the host before any launch: safe without a GPU
     rc = L.shm_conv2d_fwd(None, None, 0, 24, 0, None, None, None, 24, 1, 4, 4, 24, 16, 3, 1, 1.0, _lib.F32, None)
     assert rc == -1 and b"null pointer" in L.shm_last_error()
-    rc = L.shm_conv2d_wgrad(None, None, 0, 16, 0, None, 16, None, 1, 4, 4, 16, 16, 16, 5, 1, 0, None, 0, _lib.F32, None)
+    rc = L.shm_conv2d_wgrad(1, None, 0, 16, 0, 1, 16, 1, 1, 4, 4, 16, 16, 16, 5, 1, 0, 1, 0, _lib.F32, None)
     assert rc == -1 and b"ksize" in L.shm_last_error()
+    rc = L.shm_conv2d_wgrad(None, None, 0, 16, 0, None, 16, None, 1, 4, 4, 16, 16, 16, 3, 1, 0, None, 0, _lib.F32, None)
+    assert rc == -1 and b"null pointer" in L.shm_last_error()
     # an unknown element type is SHM_E_DTYPE (-2), also detected before any launch
     rc = L.shm_conv2d_wgrad(1, None, 0, 16, 0, 1, 16, 1, 1, 4, 4, 16, 16, 16, 3, 1, 0, 1, 0, 7, None)
     assert rc == -2 and b"dtype" in L.shm_last_error()

@@ -36,12 +36,14 @@ for dt in (torch.float32, torch.bfloat16):
         dx = torch.empty((n, h, h, cin), device="cuda", dtype=dt)
         dw = torch.empty((3, 3, cin, cout), device="cuda")
         stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.empty(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
         ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 1024, device="cuda")
         flops = 2.0 * n * h * h * 9 * cin * cout
         byts = es * n * h * h * (cin + cout)
         rows = [
             ("fwd", lambda: ops.conv2d_fwd(x, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 0.2)),
             ("fwd+stats", lambda: ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6)),
+            ("fwd+stats16", lambda: ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)),
             ("dgrad", lambda: ops.conv2d_dgrad(dy, cout, wop, dx, None, cin, cin, 0, n, h, h, cin, cout, 3, 1)),
             ("wgrad", lambda: ops.conv2d_wgrad(x, None, 0, cin, 0, dy, cout, dw, n, h, h, cin, cin, cout, 3, 1, 0, ws)),
         ]
