@@ -582,6 +582,161 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 version of the halo-patch weight gradient (3x3, stride 1): the LDS image of wgrad_halo_kernel in
+// the row format of wgrad_bf16_kernel.  Stage = 2 x 16 output pixels: a 4 x 20 halo image (18 columns
+// used; the pitch of 20 keeps bit 1 of the row index independent of the tap's row offset, so one
+// swizzled address per kw serves all taps through immediates) of 128-byte rows (64 channels) and 32 dY
+// rows, brought in by LDS-DMA with the half-swap swizzle applied on the source side; two K steps of 16
+// pixels, nine v_mfma_f32_32x32x16_bf16 each, operands via ds_read_b64_tr_b16.
+__global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
+    constexpr int PW = 16, HP = 20;                     // patch 2 x 16; halo 4 rows, LDS pitch 20 (18 valid)
+    constexpr int NHR = 4 * HP, NPX = 2 * PW;           // 80 halo rows, 32 dY rows
+    constexpr int STAGE = (NHR + NPX) * 64;             // bf16 elements per stage (14 KiB)
+    constexpr int NST = 3;
+    constexpr int NXI = NHR / 8, NDI = NPX / 8;         // DMA items (8 rows of 128 B each): 10 + 4
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[NST * STAGE];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int mi = wave >> 1, ni = wave & 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int pid0 = blockIdx.z * a.patches_per_split;
+    const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
+    const int nstages = pid1 - pid0;
+
+    // DMA lane mapping: lane -> (row l>>3 of the item, 16-byte chunk l&7); LDS chunk j of row r holds source
+    // chunk j ^ (4 * bit1(r)).  Items are 8 rows, so bit1(r) = bit1(l>>3).
+    const int drow = lane >> 3;
+    const int sch = (lane & 7) ^ (((drow >> 1) & 1) << 2);
+    const bool second = ci0 >= a.c1;
+    const int ldX = second ? a.ldx2 : a.ldx;
+    const int cX = ci0 + sch * 8;
+    const bool xvalid = cX < a.cin_ld;
+    const int ccX = second ? cX - a.c1 : cX;
+    const int coD = co0 + sch * 8;
+    const bool dvalid = coD < a.cout;
+    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    // items 0..9: halo rows [8i, 8i+8); items 10..13: dY rows.  Wave w takes items w, w+4, w+8, w+12.
+    int hr[3], hc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int hp = 8 * (wave + 4 * j) + drow;
+        hr[j] = hp / HP;
+        hc[j] = hp - hr[j] * HP;
+    }
+
+    int n, pr, pc;
+    {
+        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int p = pid0 < a.npatch ? pid0 : 0;
+        n = p / ppi;
+        const int r = p - n * ppi;
+        pr = (r / ppr) * 2;
+        pc = (r % ppr) * PW;
+    }
+    auto dma = [&](int stage) {
+        unsigned short* sx = smem + stage * STAGE;
+        unsigned short* sd = sx + NHR * 64;
+        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int item = wave + 4 * j;
+            if (item < NXI) {
+                const int r_ = hr[j < 3 ? j : 0], c_ = hc[j < 3 ? j : 0];
+                const int iy = pr - 1 + r_, ix = pc - 1 + c_;
+                const bool v = xvalid && c_ < PW + 2 && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+                const unsigned off = v ? (unsigned)((org + r_ * a.w + c_) * ldX + ccX) * 2u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
+            } else if (item < NXI + NDI) {
+                const int q = 8 * (item - NXI) + drow;
+                const int oy = pr + (q >> 4), ox = pc + (q & 15);
+                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 2u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - NXI) * 512), 16, (int)off, 0, 0, 0);
+            }
+        }
+        pc += PW;
+        if (pc == a.w) {
+            pc = 0;
+            pr += 2;
+            if (pr == a.h) {
+                pr = 0;
+                ++n;
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read addresses (elements): lane supplies row 8hh + (i>>2) [+4 for the second read] and channels
+    // [32*tile + 16*(g&1) + 4*(i&3), +4); tap (kh,kw) and K step qr enter as immediates, except that kw shifts
+    // the row and with it bit 1 of the row index -> one address per kw
+    const int fq = 8 * hh + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int fa[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int row = fq + kw;
+        fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5));
+    }
+    const int fb = fq * 64 + ((ni * 32 + fcol) ^ (((fq >> 1) & 1) << 5));
+    auto compute = [&](int stage) {
+        const unsigned short* X = smem + stage * STAGE;
+        const unsigned short* D = X + NHR * 64;
+#pragma unroll
+        for (int qr = 0; qr < 2; ++qr) {
+            const bf16x8 bv = tr_frag(D + fb + qr * PW * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf16x8 av = tr_frag(X + fa[t % 3] + (qr + t / 3) * HP * 64);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        dma(0);
+        if (nstages > 1) dma(1);
+        int cur = 0, nxt2 = 2;
+        for (int s = 0; s < nstages; ++s) {
+            if (s + 1 < nstages) {                 // one younger stage in flight: 4 (waves 0,1) or 3 DMA instructions
+                if (wave < 2)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + 2 < nstages) dma(nxt2);
+            compute(cur);
+            asm volatile("" ::: "memory");
+            cur = (cur == NST - 1) ? 0 : cur + 1;
+            nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+        }
+    }
+
+    float* out = a.part + (size_t)blockIdx.z * 9 * a.cin * a.cout;
+    const int con = co0 + ni * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+        }
+    }
+}
+
 // dw[i] (+)= sum_k part[k][i], summed in a fixed order (4 interleaved chains, then 0+1+2+3).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
     __shared__ float red[4][64];
@@ -598,12 +753,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static int wgrad_splits(int batch, int ho, int wo, int cin, int cout) {
+static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 4) {
     // two 256-thread blocks fit per CU (LDS): two rounds of 512 blocks keep every CU busy and
     // the split-K slab traffic (ns * 9*cin*cout floats written + read) small
     long M = (long)batch * ho * wo;
     int tiles = shm_cdiv(cin, 64) * shm_cdiv(cout, 64);
-    static const int target = getenv("SHM_WGRAD_BLOCKS") ? atoi(getenv("SHM_WGRAD_BLOCKS")) : 1024;
+    // (bf16: the MFMA kernel is ~6x faster, so the slab traffic of the split weighs more: 512 blocks measured
+    // best, 35.0 vs 36.0 ms/step at 1024)
+    static const int target_env = getenv("SHM_WGRAD_BLOCKS") ? atoi(getenv("SHM_WGRAD_BLOCKS")) : 0;
+    const int target = target_env ? target_env : (esz == 2 ? 512 : 1024);
     int want = shm_cdiv(target, tiles);
     long maxs = (M + 255) / 256;                 // at least 256 pixels per split
     if (want > maxs) want = (int)maxs;
@@ -659,7 +817,7 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
             a.dw[kh * ksize + kw] = kw - pl;
         }
     a.M = batch * ho * wo;
-    int ns = wgrad_splits(batch, ho, wo, cin, cout);
+    int ns = wgrad_splits(batch, ho, wo, cin, cout, esz);
     size_t need = (size_t)ns * a.ntaps * cin * cout * sizeof(float);
     SHM_REQUIRE(ws_bytes >= need, SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     {
@@ -678,7 +836,33 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     hipStream_t st = (hipStream_t)stream;
     const bool straddle = x2 && (c1 % 64 != 0);
     static const int no_halo = getenv("SHM_WGRAD_NOHALO") ? 1 : 0;
-    if (dtype == SHM_BF16) {
+    const bool halo_ok = ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo;
+    if (dtype == SHM_BF16 && halo_ok) {
+        WgradHaloArgs hgs{};
+        hgs.x = x;
+        hgs.x2 = x2;
+        hgs.c1 = a.c1;
+        hgs.ldx = ldx;
+        hgs.ldx2 = ldx2;
+        hgs.dy = dy;
+        hgs.lddy = lddy;
+        hgs.part = (float*)workspace;
+        hgs.h = hi;
+        hgs.w = wi;
+        hgs.cin_ld = cin_ld;
+        hgs.cin = cin;
+        hgs.cout = cout;
+        hgs.npatch = batch * (hi / 2) * (wi / 16);
+        int nsh = ns < hgs.npatch ? ns : hgs.npatch;
+        hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        hgs.xbytes = a.xbytes;
+        hgs.x2bytes = a.x2bytes;
+        hgs.dybytes = a.dybytes;
+        ns = nsh;
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+        shm_set_last_kernel("wgrad_halo_bf16_kernel");
+    } else if (dtype == SHM_BF16) {
         dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
         if (ksize == 3) {
             if (straddle)
@@ -692,7 +876,7 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
                 hipLaunchKernelGGL((wgrad_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
         }
         shm_set_last_kernel("wgrad_bf16_kernel<%d, %s>", ksize * ksize, straddle ? "true" : "false");
-    } else if (ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo) {
+    } else if (halo_ok) {
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;
