@@ -12,7 +12,8 @@ import subprocess
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libshmgan_hip.so"
+# SHM_LIB_PATH: load another build of the same ABI (tools/ablate_conv.py times ablated kernels this way)
+LIB_PATH = Path(os.environ["SHM_LIB_PATH"]) if os.environ.get("SHM_LIB_PATH") else _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
 SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip"]

@@ -484,7 +484,9 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
         asm volatile("" ::: "memory");
         if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
         if (s + 2 < ksteps) dma_b();
+#ifndef SHM_ABL_NOMFMA
         compute(chunk, tap, bst);
+#endif
         asm volatile("" ::: "memory");
         bst = bst == 2 ? 0 : bst + 1;
         if (++tap == 9) {
@@ -497,6 +499,59 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
     float s1[2], s2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) s1[j] = s2[j] = 0.f;
+    // bf16 outputs: the MFMA accumulator layout gives each lane one 2-byte element per row, i.e. 64 two-byte
+    // store instructions per wave -- measured 29 % of a 64-channel 256x256 layer.  Stage the wave's 64 x 64 tile
+    // through LDS (free once every wave is past its last fragment read) and write 16 bytes per lane instead:
+    // 8 store instructions per wave, each covering 8 pixel rows of 128 contiguous bytes.
+    constexpr bool kWide = sizeof(TO) == 2;
+    const bool wide = kWide && (a.nout % 8 == 0) && (a.n1 % 8 == 0) && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0) &&
+                      (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0)));
+    if constexpr (kWide) if (wide) {
+        __syncthreads();
+        unsigned short* tile = (unsigned short*)smem + wave * (64 * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + l31;
+                    float v = acc[i][j][r];
+                    if (a.bias && n < a.nout) v += a.bias[n];
+                    const TO vo = (TO)shm_lrelu(v, a.slope);
+                    v = n < a.nout ? (float)vo : 0.f;
+                    s1[j] += v;
+                    s2[j] += v * v;
+                    // 16-byte chunk c of row `row` lives at chunk c ^ (row & 7): conflict-free 16-byte reads below
+                    const int col = j * 32 + l31;
+                    tile[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = __builtin_bit_cast(unsigned short, vo);
+                }
+            }
+        }
+        // same-wave LDS hand-off: the ds ops of one wave complete in order; keep the compiler from moving the
+        // (differently typed) reads above the writes
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rr;
+            const u32x4 v = *(const u32x4*)(tile + row * 64 + ((ch ^ (row & 7)) << 3));
+            const int i = row >> 5, r32 = row & 31;
+            const int py = 4 * wm + 2 * i + (r32 >> 4), px = r32 & 15;
+            const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
+            const int n = n0 + wn * 64 + ch * 8;
+#ifndef SHM_ABL_NOSTORE
+            if (n < a.nout) {
+                if (n < a.n1)
+                    *(u32x4*)((unsigned short*)a.y + opix * a.ldy + n) = v;
+                else
+                    *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
+            }
+#endif
+        }
+    }
+    if (!wide) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -514,13 +569,19 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
                     v = (float)vo;
                     s1[j] += v;
                     s2[j] += v * v;
-                    if (n < a.n1)
-                        ((TO*)a.y)[opix * a.ldy + n] = vo;
-                    else
-                        ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
+#ifdef SHM_ABL_NOSTORE
+                    if (v == 123.456f)                  // timing only: keep the value live, store nothing
+#endif
+                    {
+                        if (n < a.n1)
+                            ((TO*)a.y)[opix * a.ldy + n] = vo;
+                        else
+                            ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
+                    }
                 }
             }
         }
+    }
     }
     if (a.stats) {
         const int slot = (prem * 4 + wm) % a.stats_slots;

@@ -1,31 +1,27 @@
-"""Timing-only ablations of the tap-GEMM kernel (outputs are WRONG in the ablated builds)."""
-import ctypes as C, subprocess, sys, time
-from pathlib import Path
-import torch
-ROOT = Path(__file__).resolve().parent.parent
-src = ROOT / "shmgan_amd" / "csrc"
-variants = {"base": [], "nodma": ["-DSHM_ABL_NODMA"], "fixaddr": ["-DSHM_ABL_FIXADDR"], "pin": ["-DSHM_SCHED_PIN"], "sameline": ["-DSHM_ABL_SAMELINE"], "noaddr": ["-DSHM_ABL_NOADDR"], "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"], "nostore": ["-DSHM_ABL_NOSTORE"]
-            }
+"""Timing-only ablations of the tap-GEMM kernels (outputs are WRONG in the ablated builds): builds
+variants of the library into /tmp with -DSHM_ABL_* and runs tools/bench_conv.py against each through
+SHM_LIB_PATH.  Usage: python tools/ablate_conv.py [variant ...] -- [bench_conv shapes ...]"""
 import os
-if os.environ.get("ABL_ONLY"): variants = {k: v for k, v in variants.items() if k in os.environ["ABL_ONLY"].split(",")}
-shapes = [(40, 64, 256, 256), (40, 128, 128, 128), (40, 256, 64, 64), (40, 32, 512, 512)]
-for name, flags in variants.items():
-    so = f"/tmp/abl_{name}.so"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics", *flags,
-                    str(src / "conv_igemm.hip"), str(src / "norm_elem.hip"), "-o", so], check=True)
-    L = C.CDLL(so)
-    res = []
-    for n, h, cin, cout in shapes:
-        x = torch.randn(n, h, h, cin, device="cuda"); w = torch.randn(9 * cout * cin, device="cuda") * 0.05
-        y = torch.empty(n, h, h, cout, device="cuda")
-        P = C.c_void_p
-        def run():
-            L.shm_conv2d_fwd(P(x.data_ptr()), None, 0, cin, 0, P(w.data_ptr()), None, P(y.data_ptr()), cout, n, h, h, cin, cout, 3, 1, C.c_float(0.2), None)
-        for _ in range(3): run()
-        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): run()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        res.append(2.0 * n * h * h * 9 * cin * cout / ms / 1e9)
-    print(f"{name:16s}", " ".join(f"{r:7.1f}" for r in res), "TFLOP/s", flush=True)
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from shmgan_amd import _lib
+
+VARIANTS = {"base": [], "nostore": ["-DSHM_ABL_NOSTORE"], "nomfma": ["-DSHM_ABL_NOMFMA"], "nodma": ["-DSHM_ABL_NODMA"],
+            "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"]}
+args = sys.argv[1:]
+shapes = []
+if "--" in args:
+    shapes = args[args.index("--") + 1:]
+    args = args[:args.index("--")]
+names = args or list(VARIANTS)
+for name in names:
+    so = f"/tmp/libshm_abl_{name}.so"
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *_lib.HIPCC_FLAGS, *VARIANTS[name],
+                    *[str(_lib.CSRC / s) for s in _lib.SOURCES], "-o", so], check=True)
+    print(f"==== {name}", flush=True)
+    env = dict(os.environ, SHM_LIB_PATH=so)
+    subprocess.run([sys.executable, str(ROOT / "tools" / "bench_conv.py"), *shapes], env=env, check=True)
