@@ -435,6 +435,10 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
 
     // fragment addressing.  A: lane -> patch pixel (4 wm + 2 i + (l31 >> 4), l31 & 15), halo row of the
     // centre tap; B: as in tapgemm_dma_kernel
+    // Swizzle (R >> 2) & 3 on the halo row index R: because halo rows start at arbitrary offsets, a third of the
+    // fragment reads see a 2-way bank conflict (SQ_LDS_BANK_CONFLICT).  The conflict-free function for this access
+    // pattern is ((R >> 1) + R / 18) & 3 (exhaustive check over taps and lane groups); it was measured 3 % SLOWER in
+    // both dtypes -- its per-tap address work sits on the barrier -> first ds_read critical path, the conflicts do not.
     int hb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) hb[i] = (4 * wm + 2 * i + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
