@@ -256,6 +256,12 @@ int shm_head_sigmoid_fwd(const float* x, int ldx, const float* w, const float* b
 int shm_spec_loss(const float* cyc_y, const float* cbcr, const float* const* ds, const float* mask,
                   double* loss, int batch, size_t npix, void* stream);
 
+/* ---- input pipeline (datasetLoader.py:47-60: image_dataset_from_directory -> /255 -> flip_up_down) ----
+ * tf.image.resize(bilinear, half-pixel centres, no antialias) of one decoded uint8 image [hin,win,c] to
+ * float32 [ho,wo,c], times `scale` (1/255), optionally flipped top-to-bottom. */
+int shm_resize_bilinear_u8(const unsigned char* src, int hin, int win, int c, float* dst, int ho, int wo,
+                           float scale, int flip_ud, void* stream);
+
 /* ---- optimizer (SHM.py:169-175, 859-872) ------------------------------------------
  * tf.clip_by_value(g,-1,1) + Keras adam_v2.Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
  * w -= alpha * m / (sqrt(v) + eps); alpha = lr_t*sqrt(1-b2^t)/(1-b1^t) computed by the caller.

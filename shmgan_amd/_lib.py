@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SHM_LIB_PATH"]) if os.environ.get("SHM_LIB_PATH") else _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
 F32, BF16 = 0, 1                 # SHM_F32 / SHM_BF16 of include/shmgan_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-local-typedef"]
@@ -68,6 +68,7 @@ SIGNATURES = {
     "shm_conv2d_transpose2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, I, P]),
     "shm_head_sigmoid_fwd": (I, [P, I, P, P, P, Z, I, P]),
     "shm_spec_loss": (I, [P, P, P, P, P, I, Z, P]),
+    "shm_resize_bilinear_u8": (I, [P, I, I, I, P, I, I, F, I, P]),
     "shm_adam_clip": (I, [P, P, P, P, Z, F, F, F, F, F, P]),
 }
 

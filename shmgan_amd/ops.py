@@ -319,3 +319,12 @@ def head_sigmoid_fwd(x, ldx, w, bias, y, npix, c):
 def spec_loss(cyc_y, cbcr, ds_ptrs, mask, loss, batch, npix):
     check(lib().shm_spec_loss(_p(cyc_y), _p(cbcr), ds_ptrs, _p(mask), _p(loss), batch, npix, _stream()),
           "shm_spec_loss")
+
+
+# ---- input pipeline ------------------------------------------------------------------------------
+def resize_bilinear_u8(src_u8, dst, scale=1.0 / 255.0, flip_ud=False):
+    """src_u8 [hin,win,c] uint8 device tensor -> dst [ho,wo,c] float32 (tf.image.resize bilinear, then * scale)."""
+    hin, win, c = src_u8.shape
+    ho, wo, _ = dst.shape
+    check(lib().shm_resize_bilinear_u8(_p(src_u8), hin, win, c, _p(dst), ho, wo, scale, int(flip_ud), _stream()),
+          "shm_resize_bilinear_u8")

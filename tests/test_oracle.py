@@ -255,3 +255,22 @@ def test_specseg_golden_fixture():
     gold = np.load(GOLD / "specseg_S32.npz")
     m = sp.specseg_forward(sp.init_specseg(seed=3), gold["x"])
     assert np.abs(m.numpy() - gold["mask"]).max() < 1e-12
+
+
+# ------------------------------------------------------------------ input pipeline restatement (N4)
+def test_resize_bilinear_known_answers():
+    """Hand-computed values of ResizeBilinear(half_pixel_centers=True): 2x2 -> 4x4 upsampling puts the sample
+    points at -0.25, 0.25, 0.75, 1.25 source pixels (clamped at the border), 4 -> 2 averages pairs."""
+    from oracle import data_np as dn
+    a = np.array([[0.0, 4.0], [8.0, 12.0]])[..., None]
+    out = dn.resize_bilinear(a, 4, 4)[..., 0]
+    assert np.allclose(out[0], [0.0, 1.0, 3.0, 4.0])
+    assert np.allclose(out[:, 0], [0.0, 2.0, 6.0, 8.0])
+    assert np.allclose(out[1, 1], 3.0) and np.allclose(out[3, 3], 12.0)
+    b = np.arange(4.0)[None, :, None]
+    assert np.allclose(dn.resize_bilinear(b, 1, 2)[0, :, 0], [0.5, 2.5])
+    c = np.random.default_rng(0).integers(0, 256, (7, 5, 3)).astype(np.uint8)
+    assert np.array_equal(dn.resize_bilinear(c, 7, 5), c.astype(np.float32))          # identity at equal size
+    v = dn.load_view(c, 8)
+    assert v.shape == (8, 8, 3) and v.min() >= 0 and v.max() <= 1
+    assert np.array_equal(dn.load_view(c, 8, flip_ud=False)[::-1], v)

@@ -407,3 +407,42 @@ def test_spec_loss_kernel():
     total, terms = sp.spec_loss(cyc, [t64(a) for a in ds], t64(mask))
     got = loss.cpu().numpy() / (B * S * S * 3)
     assert np.allclose(got, [float(t) for t in terms], rtol=1e-5)
+
+
+# ------------------------------------------------------------------ dataset loader
+def test_resize_kernel_and_dataset_loader(tmp_path):
+    """shm_resize_bilinear_u8 against the NumPy restatement, then the loader end to end on PNG files:
+    sorted zip of five directories, resize, /255, unconditional flip_up_down (datasetLoader.py:47-61)."""
+    from PIL import Image
+    from oracle import data_np as dn
+    from shmgan_amd import ops
+    from shmgan_amd.data import PSD_SUBDIRS, PolarDataset
+    rng = np.random.default_rng(12)
+    for hin, win, S in ((37, 53, 32), (64, 64, 64), (20, 24, 48), (300, 200, 64)):
+        img = rng.integers(0, 256, (hin, win, 3)).astype(np.uint8)
+        out = torch.empty((S, S, 3), device="cuda")
+        for flip in (False, True):
+            ops.resize_bilinear_u8(torch.from_numpy(img).cuda(), out, 1.0 / 255.0, flip)
+            assert np.abs(host(out) - dn.load_view(img, S, flip)).max() < 2e-6
+    S, n = 32, 3
+    ref = {}
+    for v, sub in enumerate(PSD_SUBDIRS):
+        (tmp_path / sub).mkdir()
+        for i in range(n):
+            img = rng.integers(0, 256, (40 + i, 50, 3)).astype(np.uint8)
+            Image.fromarray(img).save(tmp_path / sub / f"img_{n - i:02d}.png")       # names sort in reverse of creation
+            ref[(v, f"img_{n - i:02d}.png")] = img
+    ds = PolarDataset(str(tmp_path), S, batch_size=1)
+    assert len(ds) == n
+    names = sorted(f"img_{k:02d}.png" for k in range(1, n + 1))
+    for i, batch in enumerate(ds):
+        assert len(batch) == 5
+        for v in range(5):
+            assert tuple(batch[v].shape) == (1, S, S, 3)
+            assert np.abs(host(batch[v][0]) - dn.load_view(ref[(v, names[i])], S, True)).max() < 2e-6
+    # and the trainer takes what the loader yields
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=16, batch_size=1).build()
+    m.train_step(*ds.batch(0))
+    torch.cuda.synchronize()
+    assert np.isfinite(m.losses()["total_Generator_loss"])
