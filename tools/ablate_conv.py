@@ -1,4 +1,4 @@
-"""Timing-only ablations of the tap-GEMM kernels (outputs are WRONG in the ablated builds): builds
+"""Timing-only ablations of the tap-GEMM and weight-gradient kernels (outputs are WRONG in the ablated builds): builds
 variants of the library into /tmp with -DSHM_ABL_* and runs tools/bench_conv.py against each through
 SHM_LIB_PATH.  Usage: python tools/ablate_conv.py [variant ...] -- [bench_conv shapes ...]"""
 import os
@@ -11,7 +11,9 @@ sys.path.insert(0, str(ROOT))
 from shmgan_amd import _lib
 
 VARIANTS = {"base": [], "nostore": ["-DSHM_ABL_NOSTORE"], "nomfma": ["-DSHM_ABL_NOMFMA"], "nodma": ["-DSHM_ABL_NODMA"],
-            "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"]}
+            "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"],
+            # weight gradient (wgrad_kernel): no barrier / no global loads / no LDS stores
+            "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"]}
 args = sys.argv[1:]
 shapes = []
 if "--" in args:
