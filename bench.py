@@ -200,7 +200,7 @@ def main():
                              tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in ps.items()]
                 rows.sort(key=lambda r: -r["ms_per_step"])
                 Path(args.per_shape).write_text(json.dumps(rows, indent=1))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # reported at N=1 only: the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)
         print(json.dumps(out), flush=True)
     if world > 1:
