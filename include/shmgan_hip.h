@@ -136,6 +136,17 @@ int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a
                const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
                int h, int w, int c, float slope, int dtype, void* stream);
 
+/* Input gradient of a FIRST layer when only its sum over a set of input channels is needed (the step never
+ * uses more: d genY sums the cyclic inputs' view channels, SHM.py:576-580; yuv_to_rgb's backward sums r,g,b).
+ * Conv is linear, so the weights are summed first and the 64 -> 10 / 3 channel dgrad becomes a 64 -> 1 stencil:
+ *   shm_sum_input_channels: weff[t][co] = sum_{j : mask bit j} w[t][j][co]   (w = HWIO [9][cin][cout], cin <= 32)
+ *   shm_conv3x3_dgrad_sum1: out[b,y,x] (+)= sum_k sum_taps sum_co dz[k*batch+b, oy, ox, co] * weff[k][tap][co]
+ * dz [nk*batch, ho, wo, c] activation-typed (the layer's pre-activation gradient), weff f32 [nk][9][c],
+ * out f32 [batch, hi, wi]; stride 1 or 2 with TF SAME padding. */
+int shm_sum_input_channels(const float* w, int cin, int cout, unsigned mask, float* weff, void* stream);
+int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* weff, float* out, int nk, int batch,
+                           int hi, int wi, int c, int stride, int accumulate, int dtype, void* stream);
+
 /* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y); dy is [G].
  * dbias = f64 accumulator [c] (NOT zeroed, may be NULL); red = f64 scratch [SHM_LRELU_RED_SLOTS*c]
  * (needed when dbias is given: the per-channel sums are staged over slots, not on c addresses). */

@@ -41,6 +41,8 @@ SIGNATURES = {
     "shm_in_stats": (I, [P, I, P, I, I, I, F, I, P]),
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
+    "shm_sum_input_channels": (I, [P, I, I, C.c_uint, P, P]),
+    "shm_conv3x3_dgrad_sum1": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, P, Z, I, F, I, P]),
     "shm_avgpool2_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "shm_cvt_f64_f32": (I, [P, P, Z, I, P]),

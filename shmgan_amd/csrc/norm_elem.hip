@@ -780,3 +780,83 @@ extern "C" int shm_mul_mask(const void* x, const float* mask, void* y, size_t n,
     SHM_LAUNCH_CHECK("shm_mul_mask");
     return SHM_OK;
 }
+
+// ------------------------------------------------ input gradient of a first layer, summed over input channels
+// The step never needs the per-channel input gradient of the two first layers, only sums over input channels:
+//   generator (cyclic pass, SHM.py:576-580): d genY[b,p] = sum_k sum_{j != k, flags[j]} dX_k[b,p,j]
+//   discriminator (yuv_to_rgb backward):      d Y[i,p]   = sum_{c<3} dX[i,p,c]
+// and conv is linear, so summing the WEIGHTS over those input channels first turns a 64 -> 10 (or 3) channel
+// dgrad -- which fills 10 (3) columns of a 64-wide MFMA tile -- into a 64 -> 1 stencil that is HBM-bound:
+//   out[b,y,x] (+)= sum_k sum_{taps} sum_co dz[k*batch+b, oy, ox, co] * weff[k][tap][co]
+__global__ void weff_kernel(const float* __restrict__ w, int cin, int cout, unsigned mask, float* __restrict__ weff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (tap, co)
+    if (i >= 9 * cout) return;
+    const int t = i / cout, co = i - t * cout;
+    float s = 0.f;
+    for (int j = 0; j < cin; ++j)
+        if ((mask >> j) & 1u) s += w[((size_t)t * cin + j) * cout + co];
+    weff[i] = s;
+}
+
+extern "C" int shm_sum_input_channels(const float* w, int cin, int cout, unsigned mask, float* weff, void* stream) {
+    SHM_REQUIRE(w && weff && cin >= 1 && cin <= 32 && cout >= 1, SHM_E_SHAPE, "shm_sum_input_channels: bad arguments");
+    hipLaunchKernelGGL(weff_kernel, dim3(shm_cdiv(9 * cout, 256)), dim3(256), 0, (hipStream_t)stream, w, cin, cout, mask, weff);
+    SHM_LAUNCH_CHECK("shm_sum_input_channels");
+    return SHM_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_sum1_kernel(const T* __restrict__ dz, int lddz, const float* __restrict__ weff, float* __restrict__ out, int nk,
+                                                         int batch, int hi, int wi, int ho, int wo, int c, int stride, int pt, int pl, int accumulate) {
+    const int lanes_c = c >> 2, PP = 256 / lanes_c;
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
+    const size_t npx = (size_t)batch * hi * wi;
+    const size_t q = (size_t)blockIdx.x * PP + pp;             // output pixel (b, y, x)
+    const bool live = q < npx && pp < PP;
+    const size_t qq = live ? q : 0;
+    const int x = (int)(qq % wi);
+    const size_t t = qq / wi;
+    const int y = (int)(t % hi), b = (int)(t / hi);
+    float s = 0.f;
+    for (int k = 0; k < nk; ++k) {
+        const T* zi = dz + (size_t)(k * batch + b) * ho * wo * lddz + cl * 4;
+        const float* wk = weff + (size_t)k * 9 * c + cl * 4;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ny = y + pt - kh;
+            if (ny < 0 || (stride == 2 && (ny & 1))) continue;
+            const int oy = stride == 2 ? ny >> 1 : ny;
+            if (oy >= ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int nx = x + pl - kw;
+                if (nx < 0 || (stride == 2 && (nx & 1))) continue;
+                const int ox = stride == 2 ? nx >> 1 : nx;
+                if (ox >= wo) continue;
+                const f32x4 g = ld4(zi + ((size_t)oy * wo + ox) * lddz);
+                const f32x4 wv = *(const f32x4*)(wk + (kh * 3 + kw) * c);
+                s += g[0] * wv[0] + g[1] * wv[1] + g[2] * wv[2] + g[3] * wv[3];
+            }
+        }
+    }
+    for (int o = lanes_c >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (live && cl == 0) out[q] = accumulate ? out[q] + s : s;
+}
+
+extern "C" int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* weff, float* out, int nk, int batch, int hi, int wi, int c, int stride,
+                                      int accumulate, int dtype, void* stream) {
+    SHM_REQUIRE(dz && weff && out, SHM_E_SHAPE, "shm_conv3x3_dgrad_sum1: null pointer");
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && lddz % 4 == 0, SHM_E_SHAPE, "shm_conv3x3_dgrad_sum1: channels %d unsupported", c);
+    SHM_REQUIRE(stride == 1 || stride == 2, SHM_E_SHAPE, "shm_conv3x3_dgrad_sum1: stride %d not in {1,2}", stride);
+    int ho, wo, pt, pl;
+    shm_same_pad(hi, 3, stride, &ho, &pt);
+    shm_same_pad(wi, 3, stride, &wo, &pl);
+    const size_t npx = (size_t)batch * hi * wi;
+    if (npx == 0 || nk == 0) return SHM_OK;
+    const int PP = 256 / (c / 4);
+    SHM_DISPATCH(dtype, "shm_conv3x3_dgrad_sum1",
+                 hipLaunchKernelGGL(dgrad_sum1_kernel<T>, dim3(shm_cdiv((long)npx, PP)), dim3(256), 0, (hipStream_t)stream, (const T*)dz, lddz, weff, out, nk,
+                                    batch, hi, wi, ho, wo, c, stride, pt, pl, accumulate));
+    SHM_LAUNCH_CHECK("shm_conv3x3_dgrad_sum1");
+    return SHM_OK;
+}

@@ -333,10 +333,13 @@ class Generator(_ModelBase):
         if need_dx:
             lddx = rec["ldx"]
             ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
+        return dz
 
     def backward(self, dy, tag, need_dx=False):
         """dy: gradient wrt gen_Y [N,S,S,1].  Accumulates into the flat gradient (+ f64 region).
-        Returns the gradient wrt the 16-pitch input if need_dx (channels 0..9 valid)."""
+        need_dx=True: returns the gradient wrt the padded input (channels 0..9 valid).
+        need_dx="dz": returns the first layer's pre-activation gradient dz [N,S,S,F] instead -- the caller only
+        needs channel sums of the input gradient and forms them with ops.conv3x3_dgrad_sum1 (no 64->10 dgrad)."""
         c = self.ctx[tag]
         n, recs, ups = c["n"], c["recs"], c["ups"]
         A = self.arena
@@ -398,11 +401,12 @@ class Generator(_ModelBase):
                 dpool = A.get(f"bwd/dp/{n}x{h}x{cin}", (n, h, h, cin), self.gdt)
                 self._cnl_bwd(tag, r1, dmid, None, n, True, dpool, None, cin)
             else:
-                if need_dx:
+                if need_dx is True:
                     dx16 = A.get(f"bwd/dx16/{n}", (n, h, h, self.pad), self.gdt)
                     self._cnl_bwd(tag, r1, dmid, None, n, True, dx16, None, cin)
                     return dx16
-                self._cnl_bwd(tag, r1, dmid, None, n, False)
+                dz0 = self._cnl_bwd(tag, r1, dmid, None, n, False)
+                return dz0 if need_dx == "dz" else None
         return None
 
     def lrelu_masks(self, tag):
@@ -579,6 +583,8 @@ class Discriminator(_ModelBase):
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))
                 self.lane.submit(lambda rec=rec, dz=dz, i=i, h=h, cin=cin, cout=cout, ws=ws: ops.conv2d_wgrad(
                     rec["x"], None, 0, rec["ldx"], 0, dz, cout, self.P.grads[i], n, h, h, cin, _padk(cin, self.pad), cout, 3, 2, 0, ws))
+            if i == 0 and need_dx == "dz":
+                return dz
             if i > 0 or need_dx:
                 ldx = rec["ldx"]
                 dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
@@ -593,6 +599,11 @@ class Discriminator(_ModelBase):
     def backward_input(self, n, drf):
         """G-loss backward (data gradient only) through the first n samples."""
         return self._backward(n, drf, None, False, True)
+
+    def backward_input_dz(self, n, drf):
+        """Same, but stops at the first layer's pre-activation gradient dz [n,S/2,S/2,F]: the step only needs the
+        r+g+b sum of the image gradient, which ops.conv3x3_dgrad_sum1 forms from dz (no 64->3 dgrad)."""
+        return self._backward(n, drf, None, False, "dz")
 
     def lrelu_masks(self):
         """Sign pattern of the 6 LeakyReLU outputs of the last forward (5 convs + patch logits)."""

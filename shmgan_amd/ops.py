@@ -328,3 +328,13 @@ def resize_bilinear_u8(src_u8, dst, scale=1.0 / 255.0, flip_ud=False):
     ho, wo, _ = dst.shape
     check(lib().shm_resize_bilinear_u8(_p(src_u8), hin, win, c, _p(dst), ho, wo, scale, int(flip_ud), _stream()),
           "shm_resize_bilinear_u8")
+
+
+# ---- first-layer input gradient, summed over input channels -----------------------------------------
+def sum_input_channels(w, cin, cout, mask, weff):
+    check(lib().shm_sum_input_channels(_p(w), cin, cout, mask, _p(weff), _stream()), "shm_sum_input_channels")
+
+
+def conv3x3_dgrad_sum1(dz, lddz, weff, out, nk, batch, hi, wi, c, stride, accumulate):
+    check(lib().shm_conv3x3_dgrad_sum1(_p(dz), lddz, _p(weff), _p(out), nk, batch, hi, wi, c, stride, int(accumulate),
+                                       _dt(dz), _stream()), "shm_conv3x3_dgrad_sum1")

@@ -301,11 +301,19 @@ class ShmGANwithSSpecSeg:
         ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event())
 
         # ---- G-loss gradient through D (data gradient only), then G backward
-        dxd = D.backward_input(6 * B, drf_g)
-        ops.rgb16_to_dy(dxd[0:B], dgen_y, B * npix, 1)
-        ops.rgb16_to_dy(dxd[B:6 * B], dcyc_y, 5 * B * npix, 1)
-        dcyc_in = G.backward(dcyc_y, "cyc", need_dx=True)
-        ops.cyc_input_bwd(dcyc_in, fmask, dgen_y, B, npix)       # G o G chain  SHM.py:576-580
+        # Both first layers are left through the channel-summed stencil (ops.conv3x3_dgrad_sum1): yuv_to_rgb's
+        # backward needs r+g+b of the image gradient, the G o G chain the sum over the substituted view channels.
+        FD = D.chan[1]
+        dzd = D.backward_input_dz(6 * B, drf_g)
+        weff_d = A.get("d/weff", (9, FD))
+        ops.sum_input_channels(D.P.vars[0], 3, FD, 0b111, weff_d)
+        ops.conv3x3_dgrad_sum1(dzd[0:B], FD, weff_d, dgen_y, 1, B, S, S, FD, 2, 1)
+        ops.conv3x3_dgrad_sum1(dzd[B:6 * B], FD, weff_d, dcyc_y, 1, 5 * B, S, S, FD, 2, 1)
+        dzg = G.backward(dcyc_y, "cyc", need_dx="dz")
+        weff_g = A.get("g/weff", (5, 9, F))
+        for k in range(5):                                       # G o G chain  SHM.py:576-580
+            ops.sum_input_channels(G.P.vars[0], 10, F, sum(1 << j for j in range(5) if j != k and flags[j]), weff_g[k])
+        ops.conv3x3_dgrad_sum1(dzg, F, weff_g, dgen_y, 5, B, S, S, F, 1, 1)
         G.backward(dgen_y, "g1", need_dx=False)
         G.finish_grads()
         self._get_lane().join()                 # all weight gradients (both models) are complete

@@ -433,3 +433,35 @@ def test_bn_apply_maxpool_pack_sigmoid():
     ops.head_sigmoid_fwd(out, c, dev(w), dev(b), y, n * h * h, c)
     refy = 1.0 / (1.0 + np.exp(-(host(out) @ w + b)))
     assert np.abs(host(y)[..., 0] - refy).max() < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("nk,batch,h,cin,c,stride,mask", [(5, 2, 16, 10, 64, 1, 0b10110), (1, 3, 16, 3, 16, 2, 0b111), (2, 1, 8, 10, 32, 1, 0b00001)])
+def test_first_layer_dgrad_channel_sum(dt, nk, batch, h, cin, c, stride, mask):
+    """shm_sum_input_channels + shm_conv3x3_dgrad_sum1 == channel sum of the ordinary input gradient."""
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    w = rng.standard_normal((3, 3, cin, c)) * 0.1
+    ho = -(-h // stride)
+    dz = rng.standard_normal((nk * batch, ho, ho, c))
+    if dt == "bf16":
+        dz = torch.from_numpy(dz.astype(np.float32)).to(torch.bfloat16).double().numpy()
+    masks = [(mask << k | mask >> (5 - k)) & 0b11111 if nk > 1 else mask for k in range(nk)]
+    xt = torch.zeros(nk * batch, cin, h, h, dtype=torch.float64, requires_grad=True)
+    full, = torch.autograd.grad(st.conv2d_same(xt, t64(w), stride), xt, nchw(dz))
+    full = nhwc(full).reshape(nk, batch, h, h, cin)
+    ref = np.zeros((batch, h, h))
+    for k in range(nk):
+        for j in range(cin):
+            if (masks[k] >> j) & 1:
+                ref += full[k, ..., j]
+    weff = torch.empty((nk, 9, c), device="cuda")
+    wd = dev(w)
+    for k in range(nk):
+        ops.sum_input_channels(wd, cin, c, masks[k], weff[k])
+    out = torch.full((batch, h, h, 1), 0.5, device="cuda")
+    dzd = dev(dz).to(torch.bfloat16) if dt == "bf16" else dev(dz)
+    ops.conv3x3_dgrad_sum1(dzd, c, weff, out, nk, batch, h, h, c, stride, 1)
+    assert rel_l2(host(out)[..., 0] - 0.5, ref) < 1e-5
+    ops.conv3x3_dgrad_sum1(dzd, c, weff, out, nk, batch, h, h, c, stride, 0)
+    assert rel_l2(host(out)[..., 0], ref) < 1e-5
