@@ -779,12 +779,11 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
                                         int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout,
                                         int ksize, int stride, void* workspace, size_t ws_bytes, int dtype,
                                         int* nsplit_out, void* stream) {
-    float* dw = (float*)workspace;      // only checked for non-null below
     SHM_REQUIRE(dtype == SHM_F32 || dtype == SHM_BF16, SHM_E_DTYPE, "shm_conv2d_wgrad: dtype %d not in {SHM_F32, SHM_BF16}", dtype);
     const int esz = dtype == SHM_BF16 ? 2 : 4, vec = 16 / esz;      // 16-byte loads: 4 floats / 8 bf16
     SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_wgrad: ksize %d not in {1,3}", ksize);
     SHM_REQUIRE(stride == 1 || stride == 2, SHM_E_SHAPE, "shm_conv2d_wgrad: stride %d not in {1,2}", stride);
-    SHM_REQUIRE(x && dy && dw && workspace, SHM_E_SHAPE, "shm_conv2d_wgrad: null pointer");
+    SHM_REQUIRE(x && dy && workspace, SHM_E_SHAPE, "shm_conv2d_wgrad: null pointer");
     SHM_REQUIRE(cin_ld % vec == 0 && cin_ld >= cin && cout % vec == 0, SHM_E_SHAPE,
                 "shm_conv2d_wgrad: cin_ld %d / cout %d must be multiples of %d", cin_ld, cout, vec);
     SHM_REQUIRE(ldx % vec == 0 && lddy % vec == 0 && (!x2 || (ldx2 % vec == 0 && c1 % vec == 0)), SHM_E_SHAPE,
