@@ -641,6 +641,7 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
     }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
+    static const int small_m_min = getenv("SHM_TAPGEMM_SMALLM") ? atoi(getenv("SHM_TAPGEMM_SMALLM")) : 1024;
     if (a.nout > 64 && bk32 && a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0)) {
         if (bk32 == 2) {
             hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
@@ -652,6 +653,11 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
     } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 128, 4, 2, 3, 16>", tn, ton);
+    } else if (a.nout > 64 && small_m_min > 0 && (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase < small_m_min) {
+        // small grids (the n = 8 G(1) pass, 16x16 maps): 64-row tiles double the number of blocks, so a CU holds
+        // two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 64, 128, 2, 2, 3, 16>), grid1d(64, 128), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 64, 128, 2, 2, 3, 16>", tn, ton);
     } else if (a.nout > 64) {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 3, 16>", tn, ton);
