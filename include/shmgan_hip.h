@@ -166,9 +166,10 @@ int shm_zero(void* p, size_t bytes, void* stream);
  * Generator head Conv2D(1, k=1) + LeakyReLU (SHM.py:326). */
 int shm_head_fwd(const void* x, int ldx, const float* w, const float* bias, float* y, size_t npix,
                  int c, float slope, int dtype, void* stream);
-/* dz = dy*lrelu'(y); dx [G] = dz (x) w; dw_acc[c] += sum x*dz; db_acc[0] += sum dz (f64, not zeroed). */
+/* dz = dy*lrelu'(y); dx [G] = dz (x) w; dw_acc[c] += sum x*dz; db_acc[0] += sum dz (f64, not zeroed);
+ * red = f64 scratch [SHM_LRELU_RED_SLOTS*(c+1)] (slot staging of the two sums). */
 int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, void* dx,
-                 int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope,
+                 int lddx, double* dw_acc, double* db_acc, double* red, size_t npix, int c, float slope,
                  int dtype, void* stream);
 /* PatchGAN logits Conv2D(1, k=3, no bias) + LeakyReLU (SHM.py:365-369). x [batch,h,w,c]. */
 int shm_patch_fwd(const void* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,

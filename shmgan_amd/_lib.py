@@ -48,7 +48,7 @@ SIGNATURES = {
     "shm_cvt_f64_f32": (I, [P, P, Z, I, P]),
     "shm_zero": (I, [P, Z, P]),
     "shm_head_fwd": (I, [P, I, P, P, P, Z, I, F, I, P]),
-    "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, Z, I, F, I, P]),
+    "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, P, Z, I, F, I, P]),
     "shm_patch_fwd": (I, [P, I, P, P, I, I, I, I, F, I, P]),
     "shm_patch_bwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, F, I, P]),
     "shm_dense_fwd": (I, [P, P, P, I, I, I, I, P]),

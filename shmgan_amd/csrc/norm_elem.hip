@@ -554,38 +554,82 @@ extern "C" int shm_head_fwd(const void* x, int ldx, const float* w, const float*
 
 template <typename T, typename TG>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
-                                                       TG* __restrict__ dx, int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope) {
+                                                       TG* __restrict__ dx, int lddx, double* dpart, size_t npix, int c, float slope) {
     PixMap pm(c);
     f32x4 wv = *(const f32x4*)(w + pm.cl * 4);
     double v[1][4] = {};
     double dbs = 0.0;
-    for (size_t p = (size_t)blockIdx.x * pm.PP + pm.pp; p < npix; p += (size_t)gridDim.x * pm.PP) {
-        float g = dy[p];
-        float dz = y[p] > 0.f ? g : g * slope;
-        f32x4 xv = ld4(x + p * ldx + pm.cl * 4);
+    constexpr int U = 4;                   // pixels in flight per thread; partial sums in fp32, accumulated in f64
+    const size_t stride = (size_t)gridDim.x * pm.PP;
+    size_t p = (size_t)blockIdx.x * pm.PP + pm.pp;
+    for (; p + (U - 1) * stride < npix; p += U * stride) {
+        float dz[U];
+        f32x4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t q = p + u * stride;
+            const float g = dy[q];
+            dz[u] = y[q] > 0.f ? g : g * slope;
+            xv[u] = ld4(x + q * ldx + pm.cl * 4);
+        }
+        float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            st4(dx + (p + u * stride) * lddx + pm.cl * 4, wv * dz[u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sw[e] += xv[u][e] * dz[u];
+            sb += dz[u];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[0][e] += (double)sw[e];
+        if (pm.cl == 0) dbs += (double)sb;
+    }
+    for (; p < npix; p += stride) {
+        const float g = dy[p];
+        const float dz = y[p] > 0.f ? g : g * slope;
+        const f32x4 xv = ld4(x + p * ldx + pm.cl * 4);
         st4(dx + p * lddx + pm.cl * 4, wv * dz);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[0][e] += (double)xv[e] * (double)dz;
         if (pm.cl == 0) dbs += (double)dz;
     }
-    block_reduce_atomic<1>(v, pm, dw_acc, c, true);
-    // bias gradient: wave sum then one atomic per wave
+    // staged per slot (slot = block % SHM_LRELU_RED_SLOTS): [slot][c] weight-gradient sums, then [slot] bias sums
+    double* slotw = dpart + (size_t)(blockIdx.x % SHM_LRELU_RED_SLOTS) * c;
+    block_reduce_atomic<1>(v, pm, slotw, c, true);
     dbs = shm_wave_sum(dbs);
-    if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(db_acc, dbs);
+    if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(dpart + (size_t)SHM_LRELU_RED_SLOTS * c + (blockIdx.x % SHM_LRELU_RED_SLOTS), dbs);
+}
+
+__global__ void head_fold_kernel(const double* __restrict__ dpart, double* __restrict__ dw_acc, double* __restrict__ db_acc, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch > c) return;
+    double s = 0.0;
+    if (ch < c) {
+        for (int i = 0; i < SHM_LRELU_RED_SLOTS; ++i) s += dpart[(size_t)i * c + ch];
+        dw_acc[ch] += s;
+    } else {
+        for (int i = 0; i < SHM_LRELU_RED_SLOTS; ++i) s += dpart[(size_t)SHM_LRELU_RED_SLOTS * c + i];
+        db_acc[0] += s;
+    }
 }
 
 extern "C" int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, void* dx,
-                            int lddx, double* dw_acc, double* db_acc, size_t npix, int c, float slope, int dtype, void* stream) {
+                            int lddx, double* dw_acc, double* db_acc, double* red, size_t npix, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && ldx % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_head_bwd: channels %d unsupported", c);
+    SHM_REQUIRE(red && dw_acc && db_acc, SHM_E_SHAPE, "shm_head_bwd: null accumulator / scratch");
     if (npix == 0) return SHM_OK;
+    int r = shm_zero(red, (size_t)SHM_LRELU_RED_SLOTS * (c + 1) * sizeof(double), stream);
+    if (r) return r;
     int PP = 256 / (c / 4);
     long blocks = ((long)npix + (long)PP * 8 - 1) / ((long)PP * 8);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     SHM_DISPATCH_G(dtype, "shm_head_bwd",
-                 hipLaunchKernelGGL((head_bwd_kernel<T, TG>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, dw_acc,
-                                    db_acc, npix, c, slope));
+                 hipLaunchKernelGGL((head_bwd_kernel<T, TG>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, red,
+                                    npix, c, slope));
     SHM_LAUNCH_CHECK("shm_head_bwd");
+    hipLaunchKernelGGL(head_fold_kernel, dim3(shm_cdiv(c + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dw_acc, db_acc, c);
+    SHM_LAUNCH_CHECK("shm_head_bwd(fold)");
     return SHM_OK;
 }
 

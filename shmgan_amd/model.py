@@ -348,8 +348,9 @@ class Generator(_ModelBase):
         # head
         hx = c["head_x"]
         dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F), self.gdt)
+        hred = A.get(f"bwd/hred/{F}", (ops.LRELU_RED_SLOTS * (F + 1),), torch.float64)
         ops.head_bwd(hx, F, self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
-                     self._acc_slice(2 * (nl - 1) + 1), n * S * S, F, LRELU)
+                     self._acc_slice(2 * (nl - 1) + 1), n * S * S, F, LRELU, hred)
         ri = len(recs) - 1
         dskips = [None] * 4
         for lvl in range(3, -1, -1):

@@ -208,8 +208,11 @@ def head_fwd(x, ldx, w, bias, y, npix, c, slope):
     check(lib().shm_head_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, slope, _dt(x), _stream()), "shm_head_fwd")
 
 
-def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope):
-    check(lib().shm_head_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), npix, c,
+def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope, red=None):
+    """red: f64 scratch [LRELU_RED_SLOTS * (c + 1)] (allocated per call when omitted: tests only)."""
+    if red is None:
+        red = torch.empty(LRELU_RED_SLOTS * (c + 1), dtype=torch.float64, device=x.device)
+    check(lib().shm_head_bwd(_p(x), ldx, _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), _p(red), npix, c,
                              slope, _dtg(x, dx), _stream()), "shm_head_bwd")
 
 
