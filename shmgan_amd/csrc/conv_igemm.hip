@@ -343,13 +343,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // two taps ahead).  Per tap a wave issues 1 DMA instruction instead of 4, and the A operand moves
 // 6.4x fewer bytes.  Same LDS row format as tapgemm_dma_kernel: 64-byte rows, chunk ^= (row>>2)&3
 // applied on the DMA source side; halo pixels outside the image use offset 0xffffffff (zeros).
-template <typename T, typename TO, int BN>
-__global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs a) {
+// PH = patch height (16 or 8 pixel rows of 16): M = PH*16 rows, PH/4 row-waves.  PH = 8 halves the A stages
+// (3 four-wave blocks per CU instead of 2 eight-wave ones: smaller barrier groups) at 11 % more halo traffic.
+template <typename T, typename TO, int BN, int PH = 16>
+__global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemmArgs a) {
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
-    constexpr int WGN = BN / 64, NW = 4 * WGN;        // waves: 4 (M) x 2 (N) for BN = 128, 4 x 1 for BN = 64
-    constexpr int HC = 18, NHR = 384;                 // halo 18 x 18 = 324 rows, padded to 24 DMA items
+    constexpr int WGM = PH / 4, WGN = BN / 64, NW = WGM * WGN;          // waves: (PH/4) (M) x (BN/64) (N)
+    constexpr int HC = 18, NIT = PH == 16 ? 24 : 12;  // halo (PH+2) x 18 rows, padded to NIT DMA items of 16 rows
+    constexpr int NHR = NIT * 16;
     constexpr int ASTG = NHR * 16, BSTG = BN * 16;    // floats per stage
-    constexpr int NA = 24 / NW, NB = 1;               // DMA instructions per wave: A per chunk, B per tap
+    constexpr int NA = NIT / NW, NB = (BN / 16) / NW; // DMA instructions per wave: A per chunk, B per tap
+    static_assert(NIT % NW == 0 && (BN / 16) % NW == 0, "DMA items divide over the waves");
     __shared__ __attribute__((aligned(1024))) float smem[2 * ASTG + 3 * BSTG];
     float* const sA = smem;
     float* const sB = smem + 2 * ASTG;
@@ -361,9 +365,9 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
     // block -> (image, patch)
-    const int ppr = a.wi >> 4, ppi = (a.hi >> 4) * ppr;
+    const int ppr = a.wi >> 4, ppi = (a.hi / PH) * ppr;
     const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
-    const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
+    const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
     const int n0 = blockIdx.y * BN;
 
     // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+NW, ...
@@ -374,17 +378,18 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
         const int hrow = 16 * (wave + NW * j) + drow;
         const int hr = hrow / HC, hc = hrow - hr * HC;
         const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-        const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
         const int pix = (img * a.hi + iy) * a.wi + ix;
         const int coff = (dq ^ ((hrow >> 2) & 3)) * CHE;
         arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * (unsigned)ESZ : 0xffffffffu;
         arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * (unsigned)ESZ : 0xffffffffu;
     }
-    unsigned wrow;
-    {
-        const int row = wave * 16 + drow;                  // B rows [16 wave, 16 wave + 16)
+    unsigned wrow[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave + NW * j) * 16 + drow;       // B item wave + NW j = rows [16 item, 16 item + 16)
         const int nn = n0 + row;
-        wrow = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * CHE) * (unsigned)ESZ : 0xffffffffu;
+        wrow[j] = nn < a.nout ? (unsigned)(nn * a.K + (dq ^ ((row >> 2) & 3)) * CHE) * (unsigned)ESZ : 0xffffffffu;
     }
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
@@ -416,8 +421,11 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
     auto dma_b = [&]() {
         const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
         const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + ld_chunk * BKE) * (unsigned)ESZ;
-        const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sB + ld_stage * BSTG + wave * 256), 16, (int)off, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned off = wrow[j] == 0xffffffffu ? wrow[j] : wrow[j] + wbase;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sB + ld_stage * BSTG + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
+        }
         if (++ld_tap == 9) {
             ld_tap = 0;
             ++ld_chunk;
@@ -486,8 +494,10 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifndef SHM_ABL_NODMA
         if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
         if (s + 2 < ksteps) dma_b();
+#endif
 #ifndef SHM_ABL_NOMFMA
         compute(chunk, tap, bst);
 #endif
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(BN * 4) void tapgemm_halo_kernel(const TapGemmArgs 
     }
     }
     if (a.stats) {
-        const int slot = (prem * 4 + wm) % a.stats_slots;
+        const int slot = (prem * WGM + wm) % a.stats_slots;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
@@ -630,6 +640,16 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), 1, 1);
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), grid, dim3(256), 0, st, a);
             shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64>", tn, ton);
+            return;
+        }
+        // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
+        // bf16 (806-975 vs 795-994 TFLOP/s over the four big layer shapes), so the barrier group size is not what
+        // holds the bf16 loop at ~45 % MFMA utilisation.  Kept selectable.
+        static const int ph8 = getenv("SHM_TAPGEMM_PH8") ? atoi(getenv("SHM_TAPGEMM_PH8")) : 0;
+        if (unit && ph8 && sizeof(T) == 2) {
+            dim3 grid(batch * (a.hi / 8) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 8>), grid, dim3(256), 0, st, a);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
             return;
         }
         if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
