@@ -639,7 +639,7 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
         if (unit && a.nout <= 64) {
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), 1, 1);
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), grid, dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64>", tn, ton);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16>", tn, ton);
             return;
         }
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
@@ -655,7 +655,7 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
         if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
             dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), grid, dim3(512), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128>", tn, ton);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16>", tn, ton);
             return;
         }
     }
