@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """(Re)build libshmgan_hip.so in-tree when it is missing or older than its sources (hipcc cross-compiles
+    gfx950 without a GPU).  The product itself never builds on demand: shmgan_amd._lib.lib() raises."""
+    from shmgan_amd import _lib
+    _lib.build()
+
+
 def _has_gpu():
     try:
         import torch

@@ -274,3 +274,11 @@ def test_resize_bilinear_known_answers():
     v = dn.load_view(c, 8)
     assert v.shape == (8, 8, 3) and v.min() >= 0 and v.max() <= 1
     assert np.array_equal(dn.load_view(c, 8, flip_ud=False)[::-1], v)
+
+
+def test_dataset_listing_is_sorted_and_filtered(tmp_path):
+    """image_dataset_from_directory(shuffle=False) order: sorted file names, image extensions only."""
+    from shmgan_amd.data import list_images
+    for name in ("b_10.png", "a_2.PNG", "a_10.jpg", "notes.txt", "c.bmp"):
+        (tmp_path / name).write_bytes(b"x")
+    assert [p.split("/")[-1] for p in list_images(tmp_path)] == ["a_10.jpg", "a_2.PNG", "b_10.png", "c.bmp"]
