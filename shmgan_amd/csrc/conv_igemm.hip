@@ -453,6 +453,9 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
     const int swb = (l31 >> 2) & 3;
     const int fb0 = l31 * 16 + ((0 + h) ^ swb) * 4, fb1 = l31 * 16 + ((2 + h) ^ swb) * 4;
 
+#ifdef SHM_ABL_NOLDS
+    const f32x4 abl_frag = *(const f32x4*)(sA + lane * 4);
+#endif
     auto compute = [&](int chunk, int tap, int bstage) {
         const float* Ab = sA + (chunk & 1) * ASTG;
         const float* Bb = sB + bstage * BSTG + wn * 64 * 16;
@@ -468,10 +471,17 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f32x4 av[2], bv[2];
+#ifdef SHM_ABL_NOLDS
+            // timing only: fragments from registers (one read per block), MFMAs + barriers + DMA unchanged
+            for (int i = 0; i < 2; ++i) av[i] = abl_frag;
+            for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
+            asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(Ab + fa[i][kk]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+#endif
             tap_mfma<T, 2, 2>(av, bv, acc);
         }
     };

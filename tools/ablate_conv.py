@@ -10,7 +10,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from shmgan_amd import _lib
 
-VARIANTS = {"base": [], "nostore": ["-DSHM_ABL_NOSTORE"], "nomfma": ["-DSHM_ABL_NOMFMA"], "nodma": ["-DSHM_ABL_NODMA"],
+VARIANTS = {"base": [], "nostore": ["-DSHM_ABL_NOSTORE"], "nomfma": ["-DSHM_ABL_NOMFMA"], "nolds": ["-DSHM_ABL_NOLDS"],
+            "nolds_nodma": ["-DSHM_ABL_NOLDS", "-DSHM_ABL_NODMA"], "nodma": ["-DSHM_ABL_NODMA"],
             "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"],
             # weight gradient (wgrad_kernel): no barrier / no global loads / no LDS stores
             "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"]}
