@@ -78,7 +78,8 @@ int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, con
  * sum / sum of squares per (sample, channel); on return (stream order) stats holds
  * (mean, rsqrt(var + eps)) exactly as shm_in_stats would leave it.  stats = f64 [batch*cout*2];
  * scratch = f64 [SHM_STATS_SLOTS*batch*cout*2] or NULL: slot copies of the running sums, so that the
- * hw/64 atomic adds per (sample, channel) do not queue on one address. */
+ * hw/64 atomic adds per (sample, channel) do not queue on one address.  The scratch must be ZERO on entry
+ * (zero it once when allocating) and is zero again on return: no memset per call. */
 #define SHM_STATS_SLOTS 16
 int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                       const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,

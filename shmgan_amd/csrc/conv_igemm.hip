@@ -816,7 +816,7 @@ extern "C" int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, in
     return launch_tapgemm(a, batch, 1, dtype, (hipStream_t)stream, "shm_conv2d_fwd");
 }
 
-int shm_in_finalize_internal(double* stats, const double* part, int nslot, int total, int hw, double eps, hipStream_t st);
+int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, hipStream_t st);
 
 extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                                  const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
@@ -836,9 +836,11 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
     // Every wave tile of a sample adds its column sums with f64 atomics: on one copy that is hw/64 atomics
     // per address, a serial chain worth ~100 us at 256x256 whatever the batch (measured, bf16 and fp32).
     // With `scratch` the chain is cut SHM_STATS_SLOTS-fold and the finalize kernel sums the copies.
+    // `scratch` is zero on entry by contract and left zero (the finalize kernel clears what it sums); without it the
+    // sums go to `stats`, which is zeroed here.
     double* acc = scratch ? scratch : stats;
     const int slots = scratch ? SHM_STATS_SLOTS : 1;
-    int r = shm_zero(acc, (size_t)slots * batch * cout * 2 * sizeof(double), stream);
+    int r = scratch ? SHM_OK : shm_zero(stats, (size_t)batch * cout * 2 * sizeof(double), stream);
     if (r) return r;
     g_conv_stats = acc;
     g_conv_slots = slots;

@@ -140,16 +140,20 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ a, 
     block_reduce_atomic<2>(v, pm, stats + (size_t)n * c * 2, c, true);
 }
 
-// part != null: the sums were accumulated over `nslot` slot copies part[slot][total][2]
-__global__ void in_finalize_kernel(double* __restrict__ stats, const double* __restrict__ part, int nslot, int total, int hw, double eps) {
+// part != null: the sums were accumulated over `nslot` slot copies part[slot][total][2]; the copies are zeroed
+// again as they are consumed, so the scratch is zero whenever no call is in flight (no memset per launch)
+__global__ void in_finalize_kernel(double* __restrict__ stats, double* __restrict__ part, int nslot, int total, int hw, double eps) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     double s, q;
     if (part) {
         s = q = 0.0;
         for (int k = 0; k < nslot; ++k) {
-            s += part[((size_t)k * total + i) * 2];
-            q += part[((size_t)k * total + i) * 2 + 1];
+            double* pk = part + ((size_t)k * total + i) * 2;
+            s += pk[0];
+            q += pk[1];
+            pk[0] = 0.0;
+            pk[1] = 0.0;
         }
     } else {
         s = stats[2 * i];
@@ -162,7 +166,7 @@ __global__ void in_finalize_kernel(double* __restrict__ stats, const double* __r
     stats[2 * i + 1] = 1.0 / sqrt(var + eps);
 }
 
-int shm_in_finalize_internal(double* stats, const double* part, int nslot, int total, int hw, double eps, hipStream_t st) {
+int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, hipStream_t st) {
     hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, part, nslot, total, hw, eps);
     SHM_LAUNCH_CHECK("shm_in_finalize");
     return SHM_OK;
@@ -180,7 +184,7 @@ extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, in
     SHM_DISPATCH(dtype, "shm_in_stats",
                  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, (const T*)a, lda, stats, hw, c, chunk));
     SHM_LAUNCH_CHECK("shm_in_stats");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, (const double*)nullptr, 0, batch * c, hw, (double)eps);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, (double*)nullptr, 0, batch * c, hw, (double)eps);
     SHM_LAUNCH_CHECK("shm_in_stats(finalize)");
     return SHM_OK;
 }

@@ -46,7 +46,10 @@ class Arena:
         key = (name, tuple(shape), dtype)
         t = self.t.get(key)
         if t is None:
-            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            # f64 buffers are kernel scratch (slot copies of statistics etc.): some are "zero on entry, zero on
+            # return" by contract, so they start out zeroed
+            alloc = torch.zeros if dtype == torch.float64 else torch.empty
+            t = alloc(tuple(shape), dtype=dtype, device=self.device)
             self.t[key] = t
         return t
 

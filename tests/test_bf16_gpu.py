@@ -66,7 +66,7 @@ def test_conv2d_fwd_bf16(n, h, cin, cout, k, s):
     ho = ref.shape[1]
     y = torch.empty((n, ho, ho, cout), device="cuda", dtype=BF)
     stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
-    scr = torch.empty(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda") if (n + h) % 2 == 0 else None
+    scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda") if (n + h) % 2 == 0 else None
     ops.conv2d_in_fwd(bf(x), None, 0, cin, 0, _wk(w, cin), torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin,
                       cout, k, s, 0.2, stats, 1e-6, scratch=scr)
     assert rel_l2(host(y.float()), ref) < TOL

@@ -36,7 +36,7 @@ for dt in (torch.float32, torch.bfloat16):
         dx = torch.empty((n, h, h, cin), device="cuda", dtype=dt)
         dw = torch.empty((3, 3, cin, cout), device="cuda")
         stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
-        scr = torch.empty(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
         ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 1024, device="cuda")
         flops = 2.0 * n * h * h * 9 * cin * cout
         byts = es * n * h * h * (cin + cout)
