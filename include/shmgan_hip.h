@@ -19,7 +19,8 @@
  *    staged as 64-byte rows, so contraction channel counts and concat splits are multiples of
  *    16 (fp32) or 32 (bf16), pitches multiples of 4 (fp32) or 8 (bf16); the 3- and 10-channel
  *    images are stored in a 16-float / 32-bf16 pitch (zero padded);
- *  - "f64 scratch" arguments are small double accumulators the call zeroes itself;
+ *  - "f64 scratch" arguments are small double accumulators; where a comment says "zero on entry" the caller
+ *    zeroes them ONCE (at allocation) and every call leaves them zero again, otherwise the call zeroes them;
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *  - return value: SHM_OK or a negative error; shm_last_error() gives the text.
  */
@@ -131,7 +132,8 @@ int shm_in_apply(const void* a, int lda, const double* stats, const float* beta,
 /* Backward of LeakyReLU -> IN given the gradient at the IN output:
  *   d_out = g1 + 0.25 * g2[h/2][w/2]   (g2 = gradient of AveragePooling2D(2,2), may be NULL)
  *   dz = lrelu'(a) * inv * (d_out - mean(d_out) - xhat * mean(d_out * xhat))
- * red = f64 scratch [batch*c*3]; dbias = f64 accumulator [c] (NOT zeroed, may be NULL).
+ * red = f64 scratch [batch*c*3], ZERO on entry and zero again on return; dbias = f64 accumulator [c]
+ * (NOT zeroed, may be NULL).
  * g1, g2 are [G] tensors; a and dz are activation-typed. */
 int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
                const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
@@ -149,8 +151,9 @@ int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* weff, float* o
                            int hi, int wi, int c, int stride, int accumulate, int dtype, void* stream);
 
 /* LeakyReLU backward for blocks without IN (Conv2DTranspose, SHM.py:298): dz = dy*lrelu'(y); dy is [G].
- * dbias = f64 accumulator [c] (NOT zeroed, may be NULL); red = f64 scratch [SHM_LRELU_RED_SLOTS*c]
- * (needed when dbias is given: the per-channel sums are staged over slots, not on c addresses). */
+ * dbias = f64 accumulator [c] (NOT zeroed, may be NULL); red = f64 scratch [SHM_LRELU_RED_SLOTS*c], zero on
+ * entry and on return (needed when dbias is given: the per-channel sums are staged over slots, not on c
+ * addresses). */
 #define SHM_LRELU_RED_SLOTS 64
 int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dz, int lddz,
                   double* dbias, double* red, size_t npix, int c, float slope, int dtype, void* stream);

@@ -386,11 +386,19 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
 }
 
 // dbias[ch] += sum over slots of part[slot*c + ch]
-__global__ void dbias_fold_kernel(const double* __restrict__ part, double* __restrict__ dbias, int nslot, int c) {
+// `clear` != null: also zero the 2*nslot*c reduction sums in front of `part` (shm_in_bwd's scratch is zero on return)
+__global__ void dbias_fold_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c, double* __restrict__ clear) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     double s = 0.0;
-    for (int i = 0; i < nslot; ++i) s += part[(size_t)i * c + ch];
+    for (int i = 0; i < nslot; ++i) {
+        s += part[(size_t)i * c + ch];
+        part[(size_t)i * c + ch] = 0.0;
+        if (clear) {
+            clear[((size_t)i * c + ch) * 2] = 0.0;
+            clear[((size_t)i * c + ch) * 2 + 1] = 0.0;
+        }
+    }
     dbias[ch] += s;
 }
 
@@ -402,8 +410,7 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "shm_in_bwd: pooled gradient needs even h,w");
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
-    int r = shm_zero(red, (size_t)batch * c * 3 * sizeof(double), stream);
-    if (r) return r;
+    // `red` is zero on entry by contract and zero again on return (no memset in front of every launch)
     InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope};
     int hw = h * w;
     int nch = pix_chunks(hw, batch, c);
@@ -418,9 +425,12 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
         SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
         SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
     }
+    SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
     if (dbias) {
-        SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, st, (const double*)(red + (size_t)batch * c * 2), dbias, batch, c);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red);
+    } else {
+        int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
+        if (r) return r;
     }
     SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
     return SHM_OK;
@@ -479,10 +489,6 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
     SHM_CHECK_C(c, "shm_lrelu_bwd");
     SHM_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0, SHM_E_SHAPE, "shm_lrelu_bwd: bad pitch");
     if (npix == 0) return SHM_OK;
-    if (dbias) {
-        int r = shm_zero(red, (size_t)SHM_LRELU_RED_SLOTS * c * sizeof(double), stream);
-        if (r) return r;
-    }
     int nch = pix_chunks((long)npix, 1, c);
     size_t chunk = (npix + nch - 1) / nch;
     SHM_DISPATCH_G(dtype, "shm_lrelu_bwd",
@@ -490,7 +496,7 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
                                     (const T*)y, ldy, (T*)dz, lddz, dbias ? red : nullptr, npix, c, chunk, slope));
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
     if (dbias) {
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dbias, SHM_LRELU_RED_SLOTS, c);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr);
         SHM_LAUNCH_CHECK("shm_lrelu_bwd(fold)");
     }
     return SHM_OK;

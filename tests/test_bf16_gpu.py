@@ -198,7 +198,7 @@ def test_instance_norm_fwd_bwd_bf16(n, h, c):
     ops.in_stats(ad, c, stats, n, h * h, c, 1e-6)
     ops.in_apply(ad, c, stats, torch.from_numpy(beta.astype(np.float32)).cuda(), out, c, n, h * h, c)
     assert rel_l2(host(out.float()), nhwc(yt.detach())) < TOL
-    red = torch.empty(n * c * 3, dtype=torch.float64, device="cuda")
+    red = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
     dz = torch.empty((n, h, h, c), device="cuda", dtype=BF)
     db = torch.zeros(c, dtype=torch.float64, device="cuda")
     ops.in_bwd(bf(g1), c, bf(g2), c, ad, c, stats, red, dz, c, db, n, h, h, c, 0.2)
@@ -222,7 +222,7 @@ def test_small_layers_bf16():
     y, dy = rb(rng.standard_normal((n, h, h, c))), rb(rng.standard_normal((n, h, h, c)))
     dz = torch.empty((n, h, h, c), device="cuda", dtype=BF)
     db = torch.zeros(c, dtype=torch.float64, device="cuda")
-    ops.lrelu_bwd(bf(dy), c, bf(y), c, dz, c, db, n * h * h, c, 0.2, torch.empty(64 * c, dtype=torch.float64, device="cuda"))
+    ops.lrelu_bwd(bf(dy), c, bf(y), c, dz, c, db, n * h * h, c, 0.2, torch.zeros(64 * c, dtype=torch.float64, device="cuda"))
     ref = np.where(y > 0, dy, 0.2 * dy)
     assert rel_l2(host(dz.float()), ref) < TOL and rel_l2(host(db), ref.sum(axis=(0, 1, 2))) < 1e-3
     # head

@@ -210,7 +210,7 @@ def test_instance_norm_fwd_bwd(n, h, c):
     ops.in_stats(ad, c, stats, n, h * h, c, 1e-6)
     ops.in_apply(ad, c, stats, dev(beta), out, c, n, h * h, c)
     assert rel_l2(host(out), nhwc(yt.detach())) < TOL
-    red = torch.empty(n * c * 3, dtype=torch.float64, device="cuda")
+    red = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
     dz = torch.empty((n, h, h, c), device="cuda")
     db = torch.zeros(c, dtype=torch.float64, device="cuda")
     ops.in_bwd(dev(g1), c, dev(g2), c, ad, c, stats, red, dz, c, db, n, h, h, c, 0.2)
@@ -235,7 +235,7 @@ def test_lrelu_bwd_head_patch_dense_mask():
     dy = rng.standard_normal((n, h, h, c))
     dz = torch.empty((n, h, h, c), device="cuda")
     db = torch.zeros(c, dtype=torch.float64, device="cuda")
-    ops.lrelu_bwd(dev(dy), c, dev(y), c, dz, c, db, n * h * h, c, 0.2, torch.empty(64 * c, dtype=torch.float64, device="cuda"))
+    ops.lrelu_bwd(dev(dy), c, dev(y), c, dz, c, db, n * h * h, c, 0.2, torch.zeros(64 * c, dtype=torch.float64, device="cuda"))
     ref = np.where(y > 0, dy, 0.2 * dy)
     assert rel_l2(host(dz), ref) < 1e-6 and rel_l2(host(db), ref.sum(axis=(0, 1, 2))) < TOL
     # head 1x1 conv -> 1 channel

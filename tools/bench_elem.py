@@ -30,8 +30,8 @@ for dt in (torch.float32, torch.bfloat16):
     g2 = torch.randn((n, h // 2, h // 2, c), device=dev).to(dt)
     out = torch.empty_like(a)
     stats = torch.empty(n * c * 2, dtype=torch.float64, device=dev)
-    red = torch.empty(n * c * 3, dtype=torch.float64, device=dev)
-    lred = torch.empty(64 * c, dtype=torch.float64, device=dev)
+    red = torch.zeros(n * c * 3, dtype=torch.float64, device=dev)
+    lred = torch.zeros(64 * c, dtype=torch.float64, device=dev)
     beta = torch.zeros(c, device=dev)
     db = torch.zeros(c, dtype=torch.float64, device=dev)
     ops.in_stats(a, c, stats, n, h * h, c, 1e-6)
