@@ -692,8 +692,8 @@ static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStr
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 3, 16>", tn, ton);
     } else if (dma_small == 0) {
-        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 2, 16>), grid1d(256, 64), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 64, 4, 1, 2, 16>", tn, ton);
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 3, 16>), grid1d(256, 64), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 64, 4, 1, 3, 16>", tn, ton);
     } else {
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 64, 2, 2, 3, 16>", tn, ton);
