@@ -449,3 +449,30 @@ def test_resize_kernel_and_dataset_loader(tmp_path):
     m.train_step(*ds.batch(0))
     torch.cuda.synchronize()
     assert np.isfinite(m.losses()["total_Generator_loss"])
+
+
+@pytest.mark.parametrize("S,B,dt", [(128, 2, "float32"), (128, 1, "bfloat16"), (96, 1, "float32")])
+def test_other_image_sizes_run_and_track_fp32(S, B, dt):
+    """image_size 128 is the reference's default (main.py:36, the committed summaries); 96 exercises maps that are not
+    multiples of 16 (every 3x3 layer then takes the DMA tap GEMM, the weight gradient the generic kernel).
+    Checks: finite named losses, parameter counts of the summaries at 128, and bf16 within 2e-2 of fp32."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    F = 64
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(5, B, S, F)
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+    m.train_step(*inp, draws=dr, apply=False)
+    torch.cuda.synchronize()
+    l = m.losses()
+    assert all(np.isfinite(v) for k, v in l.items() if k != "ssim")
+    if S == 128:
+        assert m.G.count_params() == 18525569 and m.D.count_params() == 6359744      # Generator/Discriminator_summary.txt
+    assert float(m.G.P.grad.abs().sum()) > 0 and float(m.D.P.grad.abs().sum()) > 0
+    if dt != "float32":
+        m32 = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+        m32.train_step(*inp, draws=dr, apply=False)
+        torch.cuda.synchronize()
+        l32 = m32.losses()
+        for k, v in l32.items():
+            if k != "ssim":
+                assert abs(l[k] - v) <= 2e-2 * max(1.0, abs(v)), (k, l[k], v)
