@@ -400,6 +400,9 @@ class ShmGANwithSSpecSeg:
             d[f"{name}/adam_m"] = M.P.m.cpu().numpy()
             d[f"{name}/adam_v"] = M.P.v.cpu().numpy()
             d[f"{name}/iterations"] = np.int64(M.P.iterations)
+        if self.SpecSeg is not None:
+            for i, w in enumerate(self.SpecSeg.get_weights()):
+                d[f"SpecSeg/var{i:02d}"] = w
         np.savez(path, **d)
 
     def load_npz(self, path):
@@ -412,6 +415,10 @@ class ShmGANwithSSpecSeg:
             M.P.m.copy_(torch.from_numpy(z[f"{name}/adam_m"]))
             M.P.v.copy_(torch.from_numpy(z[f"{name}/adam_v"]))
             M.P.iterations = int(z[f"{name}/iterations"])
+        if "SpecSeg/var00" in z.files:
+            if self.SpecSeg is None:
+                self.SpecSeg = self.build_specseg()
+            self.SpecSeg.set_weights([z[f"SpecSeg/var{i:02d}"] for i in range(len(self.SpecSeg.vars))])
 
     def _img_ws(self, B):
         n = ops.image_losses_workspace(B, self.image_size)

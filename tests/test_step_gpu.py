@@ -284,16 +284,19 @@ def test_inference_path_matches_oracle(tmp_path):
     m.train_step(*st.make_inputs(B, S), draws=st.make_draws(0, B, S, F))
     torch.cuda.synchronize()
     p = tmp_path / "ckpt.npz"
+    m.SpecSeg.set_weights(sp.init_specseg(seed=9))
     m.save_npz(p)
     from shmgan_amd import ShmGANwithSSpecSeg
     m2 = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build(seed=1, beta_seed=2)
     m2.load_npz(p)
     assert torch.equal(m2.G.P.flat, m.G.P.flat) and torch.equal(m2.D.P.flat, m.D.P.flat)
+    assert torch.equal(m2.SpecSeg.flat, m.SpecSeg.flat)
     assert torch.equal(m2.G.P.m, m.G.P.m) and m2.G.P.iterations == 1
     a, _ = m.infer(rgb)
     a = host(a).copy()
+    mask_a = host(m.specular_candidate).copy()           # test.py:221: the mask of the input image
     b, _ = m2.infer(rgb)
-    assert np.array_equal(a, host(b))
+    assert np.array_equal(a, host(b)) and np.array_equal(mask_a, host(m2.specular_candidate))
 
 
 def test_three_steps_track_the_oracle():
