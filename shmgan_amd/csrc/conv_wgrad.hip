@@ -583,6 +583,150 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// Thin-input variant of wgrad_halo_kernel (fp32, 3x3 stride 1, 9*cin <= 96: the generator's 10-channel first
+// layer).  The general kernel gives every tap its own 64-row ci tile, of which 10 rows are real (22 TFLOP/s, 1.65 ms
+// per step).  Here the (tap, ci) pairs are PACKED into the MFMA rows -- row r of the 96 holds (tap r / cin,
+// ci r % cin) -- which only changes the per-lane offset of the ds_read_b32 into the same LDS halo image (16 floats =
+// one 64-byte row per halo pixel).  Wave w takes column tile w & 1 and patch row w >> 1; the two patch rows write
+// separate split-K slabs.
+template <int NRT>
+__global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHaloArgs a) {
+    constexpr int PW = 16, HC = PW + 2, XP = 16;
+    constexpr int NHP = 4 * HC, NPX = 2 * PW;
+    constexpr int NXI = (NHP * XP * 4 + 1023) / 1024;    // 5 DMA items for the halo (the last one half used), 8 for dY
+    constexpr int XF = NXI * 256;                        // halo region padded to whole 1 KiB items
+    constexpr int STAGE = XF + NPX * 64;                 // floats: 1280 + 2048 (13 KB)
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ni = wave & 1, qr = wave >> 1;
+    const int co0 = blockIdx.y * 64;
+    const int pid0 = blockIdx.z * a.patches_per_split;
+    const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
+    const int nstages = pid1 - pid0;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    // X items: lane -> (halo pixel 16 i + (l >> 2), 4-float chunk l & 3); D items: lane -> (pixel 4 j + (l >> 4), chunk l & 15)
+    const int xpx = lane >> 2, xch = lane & 3;
+    const bool xcv = xch * 4 < a.cin_ld;
+    const int dpx = lane >> 4, dch = lane & 15;
+    const int coD = co0 + dch * 4;
+    const bool dvalid = coD < a.cout;
+
+    int n, pr, pc;
+    {
+        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int p = pid0 < a.npatch ? pid0 : 0;
+        n = p / ppi;
+        const int r = p - n * ppi;
+        pr = (r / ppr) * 2;
+        pc = (r % ppr) * PW;
+    }
+    auto dma = [&](int stage) {
+        float* sx = smem + stage * STAGE;
+        float* sd = sx + XF;
+        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int item = wave + 4 * j;
+            if (item < NXI) {
+                const int hp = 16 * item + xpx;
+                const int hr = hp / HC, hc = hp - hr * HC;
+                const int iy = pr - 1 + hr, ix = pc - 1 + hc;
+                const bool v = xcv && hp < NHP && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+                const unsigned off = v ? (unsigned)((org + hr * a.w + hc) * a.ldx + xch * 4) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
+            } else if (item < NXI + 8) {
+                const int q = 4 * (item - NXI) + dpx;
+                const int oy = pr + (q >> 4), ox = pc + (q & 15);
+                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - NXI) * 256), 16, (int)off, 0, 0, 0);
+            }
+        }
+        pc += PW;
+        if (pc == a.w) {
+            pc = 0;
+            pr += 2;
+            if (pr == a.h) {
+                pr = 0;
+                ++n;
+            }
+        }
+    };
+
+    f32x16 acc[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // packed rows: lane's row of row-tile rt is (tap, ci) = divmod(rt*32 + l31, cin); rows >= 9*cin read a valid
+    // address and are never stored
+    const int rows = 9 * a.cin;
+    int xoff[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int idx = rt * 32 + l31;
+        const int tap = idx < rows ? idx / a.cin : 0, ci = idx < rows ? idx - tap * a.cin : 0;
+        xoff[rt] = ((tap / 3) * HC + tap % 3) * XP + ci;
+    }
+    const int xb = (qr * HC + hh) * XP;                   // + 2*kk*XP
+    const int db = (qr * PW + hh) * 64 + ni * 32 + l31;   // + 2*kk*64
+    auto compute = [&](int stage) {
+        const float* X = smem + stage * STAGE + xb;
+        const float* D = smem + stage * STAGE + XF + db;
+#pragma unroll
+        for (int kk = 0; kk < PW / 2; ++kk) {
+            const float bv = D[kk * 128];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const float av = X[kk * 2 * XP + xoff[rt]];
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rt], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        dma(0);
+        if (nstages > 1) dma(1);
+        int cur = 0, nxt2 = 2;
+        for (int s = 0; s < nstages; ++s) {
+            if (s + 1 < nstages) {                 // one younger stage in flight: 4 (wave 0) or 3 DMA instructions
+                if (wave == 0)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + 2 < nstages) dma(nxt2);
+            compute(cur);
+            asm volatile("" ::: "memory");
+            cur = (cur == NST - 1) ? 0 : cur + 1;
+            nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+        }
+    }
+
+    float* out = a.part + ((size_t)blockIdx.z * 2 + qr) * 9 * a.cin * a.cout;
+    const int con = co0 + ni * 32 + l31;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;       // = tap*cin + ci
+            if (idx < rows && con < a.cout) out[(size_t)idx * a.cout + con] = acc[rt][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 version of the halo-patch weight gradient (3x3, stride 1): the LDS image of wgrad_halo_kernel in
 // the row format of wgrad_bf16_kernel.  Stage = 2 x 16 output pixels: a 4 x 20 halo image (18 columns
 // used; the pitch of 20 keeps bit 1 of the row index independent of the tap's row offset, so one
@@ -771,6 +915,7 @@ static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 
 
 extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize) {
     int ns = wgrad_splits(batch, ho, wo, cin, cout);
+    if (9 * cin <= 96) ns *= 2;                          // wgrad_halo_thin_kernel writes two slabs per split
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
 
@@ -876,6 +1021,8 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         }
         shm_set_last_kernel("wgrad_bf16_kernel<%d, %s>", ksize * ksize, straddle ? "true" : "false");
     } else if (halo_ok) {
+        static const int no_thin = getenv("SHM_WGRAD_NOTHIN") ? 1 : 0;
+        const bool thin = !no_thin && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16;
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;
@@ -898,9 +1045,16 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
         ns = nsh;
+        if (thin) {                                    // two slabs per block (one per patch row)
+            SHM_REQUIRE(ws_bytes >= (size_t)2 * nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace too small");
+            ns = 2 * nsh;
+            hipLaunchKernelGGL(wgrad_halo_thin_kernel<3>, dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+            shm_set_last_kernel("wgrad_halo_thin_kernel<3>");
+        } else {
         dim3 gridh(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
         hipLaunchKernelGGL(wgrad_halo_kernel, gridh, dim3(256), 0, st, hgs);
         shm_set_last_kernel("wgrad_halo_kernel");
+        }
     } else {
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
     if (ksize == 3) {
