@@ -583,20 +583,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
 }
 
 // ------------------------------------------------------------------------------------------
-// Thin-input variant of wgrad_halo_kernel (fp32, 3x3 stride 1, 9*cin <= 96: the generator's 10-channel first
-// layer).  The general kernel gives every tap its own 64-row ci tile, of which 10 rows are real (22 TFLOP/s, 1.65 ms
-// per step).  Here the (tap, ci) pairs are PACKED into the MFMA rows -- row r of the 96 holds (tap r / cin,
-// ci r % cin) -- which only changes the per-lane offset of the ds_read_b32 into the same LDS halo image (16 floats =
-// one 64-byte row per halo pixel).  Wave w takes column tile w & 1 and patch row w >> 1; the two patch rows write
-// separate split-K slabs.
-template <int NRT>
+// Thin-input variant of wgrad_halo_kernel (fp32, 3x3, 9*cin <= 96: the generator's 10-channel and the
+// discriminator's 3-channel first layers).  The general kernels give every tap its own 64-row ci tile, of which
+// 10 (3) rows are real (22 / 6 TFLOP/s, 2.6 ms per step).  Here the (tap, ci) pairs are PACKED into the MFMA rows --
+// row r holds (tap r / cin, ci r % cin) -- which only changes the per-lane offset of the ds_read_b32 into the same
+// LDS halo image (16 floats = one 64-byte row per halo pixel).  IS = conv stride: the halo of a 2 x 16 output patch
+// is 4 x 18 input pixels at stride 1 (SAME pad 1 before) and 5 x 33 at stride 2 (pad 0 before).  Wave w takes column
+// tile w & 1 and patch row w >> 1; the two patch rows write separate split-K slabs.
+template <int NRT, int IS>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHaloArgs a) {
-    constexpr int PW = 16, HC = PW + 2, XP = 16;
-    constexpr int NHP = 4 * HC, NPX = 2 * PW;
-    constexpr int NXI = (NHP * XP * 4 + 1023) / 1024;    // 5 DMA items for the halo (the last one half used), 8 for dY
-    constexpr int XF = NXI * 256;                        // halo region padded to whole 1 KiB items
-    constexpr int STAGE = XF + NPX * 64;                 // floats: 1280 + 2048 (13 KB)
+    constexpr int PW = 16, XP = 16;
+    constexpr int HR = 2 * IS + 3 - IS, HC = PW * IS + 3 - IS, PAD = IS == 1 ? 1 : 0;
+    constexpr int NHP = HR * HC, NPX = 2 * PW;
+    constexpr int NXI = (NHP * XP * 4 + 1023) / 1024;    // DMA items (1 KiB = 16 halo pixels) for the halo; 8 more for dY
+    constexpr int XF = NXI * 256;                        // halo region padded to whole items
+    constexpr int STAGE = XF + NPX * 64;                 // floats
     constexpr int NST = 3;
+    constexpr int NIT = NXI + 8, CHI = (NIT + 3) / 4, CLO = NIT / 4, NHI = NIT % 4;   // items per wave: CHI for waves < NHI
     __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
     const int pid0 = blockIdx.z * a.patches_per_split;
     const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
     const int nstages = pid1 - pid0;
+    const int ho = a.h / IS, wo = a.w / IS;
 
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
@@ -618,9 +622,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
     const int coD = co0 + dch * 4;
     const bool dvalid = coD < a.cout;
 
-    int n, pr, pc;
+    int n, pr, pc;                                       // patch origin in OUTPUT pixels
     {
-        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int ppr = wo / PW, ppi = (ho / 2) * ppr;
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
@@ -630,29 +634,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
     auto dma = [&](int stage) {
         float* sx = smem + stage * STAGE;
         float* sd = sx + XF;
-        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);
+        const int y0 = IS * pr - PAD, x0 = IS * pc - PAD;       // input pixel of halo (0,0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CHI; ++j) {
             const int item = wave + 4 * j;
             if (item < NXI) {
                 const int hp = 16 * item + xpx;
                 const int hr = hp / HC, hc = hp - hr * HC;
-                const int iy = pr - 1 + hr, ix = pc - 1 + hc;
+                const int iy = y0 + hr, ix = x0 + hc;
                 const bool v = xcv && hp < NHP && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-                const unsigned off = v ? (unsigned)((org + hr * a.w + hc) * a.ldx + xch * 4) * 4u : 0xffffffffu;
+                const unsigned off = v ? (unsigned)(((n * a.h + iy) * a.w + ix) * a.ldx + xch * 4) * 4u : 0xffffffffu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
-            } else if (item < NXI + 8) {
+            } else if (item < NIT) {
                 const int q = 4 * (item - NXI) + dpx;
                 const int oy = pr + (q >> 4), ox = pc + (q & 15);
-                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 4u : 0xffffffffu;
+                const unsigned off = dvalid ? (unsigned)(((n * ho + oy) * wo + ox) * a.lddy + coD) * 4u : 0xffffffffu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - NXI) * 256), 16, (int)off, 0, 0, 0);
             }
         }
         pc += PW;
-        if (pc == a.w) {
+        if (pc == wo) {
             pc = 0;
             pr += 2;
-            if (pr == a.h) {
+            if (pr == ho) {
                 pr = 0;
                 ++n;
             }
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
         const int tap = idx < rows ? idx / a.cin : 0, ci = idx < rows ? idx - tap * a.cin : 0;
         xoff[rt] = ((tap / 3) * HC + tap % 3) * XP + ci;
     }
-    const int xb = (qr * HC + hh) * XP;                   // + 2*kk*XP
+    const int xb = (IS * qr * HC + IS * hh) * XP;         // + IS*2*kk*XP
     const int db = (qr * PW + hh) * 64 + ni * 32 + l31;   // + 2*kk*64
     auto compute = [&](int stage) {
         const float* X = smem + stage * STAGE + xb;
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
             const float bv = D[kk * 128];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                const float av = X[kk * 2 * XP + xoff[rt]];
+                const float av = X[kk * 2 * IS * XP + xoff[rt]];
                 acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rt], 0, 0, 0);
             }
         }
@@ -696,11 +700,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
         if (nstages > 1) dma(1);
         int cur = 0, nxt2 = 2;
         for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {                 // one younger stage in flight: 4 (wave 0) or 3 DMA instructions
-                if (wave == 0)
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (s + 1 < nstages) {                 // one younger stage in flight: CHI or CLO DMA instructions of this wave
+                if (NHI != 0 && wave < NHI)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHI) : "memory");
                 else
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CLO) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -981,6 +985,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     const bool straddle = x2 && (c1 % 64 != 0);
     static const int no_halo = getenv("SHM_WGRAD_NOHALO") ? 1 : 0;
     const bool halo_ok = ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo;
+    static const int no_thin = getenv("SHM_WGRAD_NOTHIN") ? 1 : 0;
+    // thin first layers: (tap, ci) pairs packed into the MFMA rows; patches of 2 x 16 OUTPUT pixels
+    const bool thin_ok = !no_thin && !no_halo && ksize == 3 && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16 && wo % 16 == 0 && ho % 2 == 0 &&
+                         hi % stride == 0 && wi % stride == 0;
     if (dtype == SHM_BF16 && halo_ok) {
         WgradHaloArgs hgs{};
         hgs.x = x;
@@ -1020,9 +1028,36 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
                 hipLaunchKernelGGL((wgrad_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
         }
         shm_set_last_kernel("wgrad_bf16_kernel<%d, %s>", ksize * ksize, straddle ? "true" : "false");
+    } else if (dtype == SHM_F32 && thin_ok && stride == 2) {
+        // first layer of the discriminator (3 channels, stride 2): patches over the OUTPUT map
+        WgradHaloArgs hgs{};
+        hgs.x = x;
+        hgs.ldx = ldx;
+        hgs.dy = dy;
+        hgs.lddy = lddy;
+        hgs.part = (float*)workspace;
+        hgs.h = hi;
+        hgs.w = wi;
+        hgs.cin_ld = cin_ld;
+        hgs.cin = cin;
+        hgs.cout = cout;
+        hgs.npatch = batch * (ho / 2) * (wo / 16);
+        int nsh = ns < hgs.npatch ? ns : hgs.npatch;
+        hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        hgs.xbytes = a.xbytes;
+        hgs.dybytes = a.dybytes;
+        SHM_REQUIRE(ws_bytes >= (size_t)2 * nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace too small");
+        ns = 2 * nsh;
+        if (9 * cin <= 32) {
+            hipLaunchKernelGGL((wgrad_halo_thin_kernel<1, 2>), dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+            shm_set_last_kernel("wgrad_halo_thin_kernel<1, 2>");
+        } else {
+            hipLaunchKernelGGL((wgrad_halo_thin_kernel<3, 2>), dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+            shm_set_last_kernel("wgrad_halo_thin_kernel<3, 2>");
+        }
     } else if (halo_ok) {
-        static const int no_thin = getenv("SHM_WGRAD_NOTHIN") ? 1 : 0;
-        const bool thin = !no_thin && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16;
+        const bool thin = thin_ok;
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;
@@ -1048,8 +1083,8 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         if (thin) {                                    // two slabs per block (one per patch row)
             SHM_REQUIRE(ws_bytes >= (size_t)2 * nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace too small");
             ns = 2 * nsh;
-            hipLaunchKernelGGL(wgrad_halo_thin_kernel<3>, dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
-            shm_set_last_kernel("wgrad_halo_thin_kernel<3>");
+            hipLaunchKernelGGL((wgrad_halo_thin_kernel<3, 1>), dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+            shm_set_last_kernel("wgrad_halo_thin_kernel<3, 1>");
         } else {
         dim3 gridh(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
         hipLaunchKernelGGL(wgrad_halo_kernel, gridh, dim3(256), 0, st, hgs);

@@ -132,6 +132,7 @@ def _ws(nbytes):
     (2, 16, 64, 64, 3, 1), (1, 32, 16, 64, 3, 1), (3, 8, 128, 192, 3, 1), (2, 16, 64, 128, 1, 1),
     (2, 16, 32, 64, 3, 2), (4, 8, 3, 16, 3, 2), (1, 8, 10, 32, 3, 1), (7, 5, 16, 16, 3, 1),
     (3, 32, 10, 64, 3, 1), (2, 16, 10, 96, 3, 1), (2, 16, 7, 64, 3, 1),       # thin-input kernel: (tap, ci) packed into the MFMA rows
+    (3, 64, 3, 64, 3, 2), (2, 32, 3, 16, 3, 2), (2, 32, 10, 32, 3, 2),        # ... and its stride-2 form (discriminator conv1)
 ])
 def test_conv2d_wgrad(n, h, cin, cout, k, s):
     ops = _ops()
