@@ -63,13 +63,13 @@ int shm_transpose_taps(const float* w, void* wt, int ntaps, int rows, int cols, 
 /* dst[i] = (dtype) src[i]: operand copies of weights that are already K-contiguous as stored. */
 int shm_cast_f32(const float* src, void* dst, size_t n, int dtype, void* stream);
 
-/* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) -----------------------
+/* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16) ------
  * Keras Conv2D(k in {1,3}, strides in {1,2}, padding='same') + bias + LeakyReLU(slope)
  * (SHM.py:244-245, 254-326, 365-369, 387).  y is [G]-typed under SHM_BF16_GF32 (the call is then the
  * input-gradient of a Conv2DTranspose).  Input = channel concat of x (c1 channels,
  * pitch ldx) and optional x2 (cin-c1 channels, pitch ldx2): Concatenate() SHM.py:299,306,
- * 313,320 is never materialised.  wk = [k*k][cout][cin] (shm_transpose_taps of HWIO),
- * cin % 16 == 0.  bias may be NULL; slope 1.0f = no activation. */
+ * 313,320 is never materialised.  wk = [k*k][cout][cin] (shm_transpose_taps of HWIO, in the call's dtype),
+ * cin and c1 multiples of 16 (fp32) / 32 (bf16).  bias may be NULL; slope 1.0f = no activation, 0.0f = ReLU. */
 int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                    const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                    int cout, int ksize, int stride, float slope, int dtype, void* stream);
@@ -88,7 +88,8 @@ int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, 
                       float eps, int dtype, void* stream);
 
 /* Input-gradient of the same conv.  dy [batch,ho,wo,cout] (pitch lddy), w = HWIO
- * [k*k][cin][cout] as stored (it is already K-contiguous for this product), cout % 16 == 0.
+ * [k*k][cin][cout] as stored (it is already K-contiguous for this product; in bf16 mode the shm_cast_f32 copy),
+ * cout a multiple of 16 (fp32) / 32 (bf16).
  * dx channels [0,n1) go to dx (pitch lddx), [n1,cin) to dx2 (pitch lddx2): the split of a
  * concat gradient.  Pass dx2=NULL, n1=cin for a single destination.  dx, dx2 are [G] tensors. */
 int shm_conv2d_dgrad(const void* dy, int lddy, const void* w, void* dx, void* dx2, int n1,
@@ -104,8 +105,9 @@ int shm_conv2d_transpose_fwd(const void* x, int ldx, const void* w, const float*
 /* Weight gradient: dw[t][ci][co] (+)= sum_pixels x[pix*stride + tap][ci] * dy[pix][co]
  * (HWIO).  For Conv2DTranspose pass x = dz of the transposed conv (2H res), dy = its input
  * (H res), stride 2: the result is the Keras [3][3][cout][cin] layout.  cin_ld = number of
- * input channels to read (multiple of 4, pad channels must be zero), cin = rows stored.
- * workspace: split-K partial slabs, at least shm_conv2d_wgrad_workspace() bytes. */
+ * input channels to read (multiple of 4 fp32 / 8 bf16, pad channels must be zero), cin = rows stored; dw is
+ * always fp32.  workspace: split-K partial slabs (fp32), at least shm_conv2d_wgrad_workspace() bytes; the
+ * slabs are summed in a fixed order (deterministic, no float atomics). */
 size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize);
 /* The two phases of shm_conv2d_wgrad as separate calls (bench.py times the MFMA kernel on its own):
  * _partial writes *nsplit_out slabs [ksize*ksize][cin][cout] to workspace; _reduce sums them into dw. */
