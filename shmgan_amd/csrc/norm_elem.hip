@@ -386,20 +386,26 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
 }
 
 // dbias[ch] += sum over slots of part[slot*c + ch]
-// `clear` != null: also zero the 2*nslot*c reduction sums in front of `part` (shm_in_bwd's scratch is zero on return)
-__global__ void dbias_fold_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c, double* __restrict__ clear) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+// `clear` != null: also zero the 2*nslot*c reduction sums in front of `part` (shm_in_bwd's scratch is zero on return).
+// Block = 64 channels x 4 slot groups (a serial loop over the slots per channel was latency bound: 10 us per launch).
+__global__ __launch_bounds__(256) void dbias_fold_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c,
+                                                         double* __restrict__ clear) {
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int i = 0; i < nslot; ++i) {
-        s += part[(size_t)i * c + ch];
-        part[(size_t)i * c + ch] = 0.0;
-        if (clear) {
-            clear[((size_t)i * c + ch) * 2] = 0.0;
-            clear[((size_t)i * c + ch) * 2 + 1] = 0.0;
+    if (ch < c)
+        for (int i = g; i < nslot; i += 4) {
+            s += part[(size_t)i * c + ch];
+            part[(size_t)i * c + ch] = 0.0;
+            if (clear) {
+                clear[((size_t)i * c + ch) * 2] = 0.0;
+                clear[((size_t)i * c + ch) * 2 + 1] = 0.0;
+            }
         }
-    }
-    dbias[ch] += s;
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && ch < c) dbias[ch] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
@@ -427,7 +433,7 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     }
     SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
     if (dbias) {
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red);
     } else {
         int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
         if (r) return r;
@@ -496,7 +502,7 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
                                     (const T*)y, ldy, (T*)dz, lddz, dbias ? red : nullptr, npix, c, chunk, slope));
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
     if (dbias) {
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr);
         SHM_LAUNCH_CHECK("shm_lrelu_bwd(fold)");
     }
     return SHM_OK;
