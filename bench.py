@@ -113,6 +113,9 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    if world > 1:            # bring the RCCL communicator up outside any timed region, whatever --warmup is
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
     lane = model._get_lane()
     lane_stream = lane.stream
     if args.serialize:
