@@ -17,8 +17,8 @@ a property of the kernel any more), the event pass is a serialized replay of the
 the same process right after the timed region (`roofline.region`); `--serialize` runs the timed
 region itself without the second stream, which is the command the committed rocprofv3 summaries
 (profiles/) were taken with.
-`cpu_baseline` times the CPU oracle (PyTorch-CPU/oneDNN restatement of the same step, fp32) on
-this box's host cores on a bounded sample (B=1 steps at the same image size).
+`cpu_baseline` times the CPU oracle (PyTorch-CPU/oneDNN restatement of the same step, fp32, with clip+Adam) on
+this box's host cores on a bounded sample: BASELINE configs[0]'s batch of 2, median of 3 steps after one warm-up.
 """
 import argparse
 import json
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serialize", action="store_true", help="no second stream for weight gradients (profiling)")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median), after one warm-up")
     ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: all ranks share GPU 0")
@@ -211,23 +211,35 @@ def main():
 
 
 def cpu_baseline(S, F, steps, note=lambda m: None):
-    """The oracle (PyTorch-CPU / oneDNN restatement of the step) in fp32 on the host cores."""
+    """The oracle (PyTorch-CPU / oneDNN restatement of the step) in fp32 on the host cores, as BASELINE.md section 3 /
+    BASELINE.json configs[0] specify it: batch 2, forward + both gradient passes + clip + Adam on both models,
+    median of `steps` (3) timed steps after one warm-up step."""
+    import statistics
     import torch
     from oracle import step_torch as st
     # the GPU box gives one GPU's share of the host (16 cores); more threads than that only oversubscribe
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    B = 2
     g, d, gb, db = st.init_params(F, S)
-    inp = st.make_inputs(1, S)
+    gv = [torch.from_numpy(a).clone() for a in g]
+    dv = [torch.from_numpy(a).clone() for a in d]
+    sg = st.AdamState([torch.zeros_like(a) for a in gv], [torch.zeros_like(a) for a in gv])
+    sd = st.AdamState([torch.zeros_like(a) for a in dv], [torch.zeros_like(a) for a in dv])
+    inp = st.make_inputs(B, S)
     sf = st.style_factor_intended(S)
-    st.train_step(g, d, gb, db, inp, st.make_draws(0, 1, S, F), sf, F, dtype=torch.float32)      # warm-up
-    note("cpu baseline warm-up step done")
-    t0 = time.perf_counter()
-    for i in range(steps):
-        st.train_step(g, d, gb, db, inp, st.make_draws(1 + i, 1, S, F), sf, F, dtype=torch.float32)
-        note(f"cpu baseline step {i} done")
-    dt = time.perf_counter() - t0
-    return {"value": round(steps / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of B=1 at {S}x{S}, fp32, forward+both gradient passes (no optimizer apply), "
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        r = st.train_step(gv, dv, gb, db, inp, st.make_draws(i, B, S, F), sf, F, dtype=torch.float32)
+        st.adam_apply(dv, r["gD"], sd, 2e-5, 0.5, 0.99)
+        st.adam_apply(gv, r["gG"], sg, 2e-5, 0.5, 0.99)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+        note(f"cpu baseline step {i} ({'warm-up' if i == 0 else 'timed'}): {dt:.2f}s")
+    med = statistics.median(times)
+    return {"value": round(B / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of {steps} steps of B={B} at {S}x{S}, fp32, forward + both gradient passes + clip + Adam on G and D, "
                       "after 1 warm-up step"}
 
 

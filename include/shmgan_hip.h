@@ -20,7 +20,9 @@
  *    16 (fp32) or 32 (bf16), pitches multiples of 4 (fp32) or 8 (bf16); the 3- and 10-channel
  *    images are stored in a 16-float / 32-bf16 pitch (zero padded);
  *  - "f64 scratch" arguments are small double accumulators; where a comment says "zero on entry" the caller
- *    zeroes them ONCE (at allocation) and every call leaves them zero again, otherwise the call zeroes them;
+ *    zeroes them ONCE (at allocation) and every call leaves them zero again -- also when it returns an error
+ *    (the entry point clears the scratch itself if a launch after the one that filled it fails); otherwise
+ *    the call zeroes them;
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *  - return value: SHM_OK or a negative error; shm_last_error() gives the text.
  */
@@ -54,6 +56,34 @@ const char* shm_last_error(void);
  * the calling thread's last convolution entry point dispatched to: the tile/variant choice depends on
  * shape and dtype, and bench.py's per-kernel roofline keys its HIP-event timings by it. */
 const char* shm_last_kernel(void);
+
+/* ---- dispatch tuning ---------------------------------------------------------------
+ * The convolution entry points choose among several MFMA kernel variants by shape and dtype.  These
+ * process-wide integer knobs override that choice (parity tests force every variant; tools sweep them):
+ *   "tapgemm.variant"           0 automatic (default), or one of SHM_TG_*: a forced variant the shape is not
+ *                               eligible for makes the conv call return SHM_E_SHAPE (it never falls back silently)
+ *   "tapgemm.halo_min_blocks"   fp32: smallest grid that takes the 16x16-patch halo kernel (default 1024)
+ *   "tapgemm.small_grid_blocks" grids with fewer 128x128 tiles take the 64x128 tile (default 1024)
+ *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing
+ *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 512 bf16)
+ *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
+ * value < 0 restores the knob's default; key "reset" restores all.  Initial values may be given in the
+ * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_WGRAD_VARIANT,
+ * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION), read once.  Knobs change scheduling only, never results beyond the
+ * summation order of a tile shape. */
+#define SHM_TG_AUTO 0
+#define SHM_TG_HALO128 1
+#define SHM_TG_HALO64 2
+#define SHM_TG_DMA_128x128 3
+#define SHM_TG_DMA_64x128 4
+#define SHM_TG_DMA_128x64 5
+#define SHM_TG_DMA_256x64 6
+#define SHM_TG_DMA_256x128 7
+#define SHM_TG_HALO128_PH8 8
+#define SHM_TG_DMA_128x128_BK32 9
+#define SHM_TG_DMA_128x128_NST4 10
+int shm_set_tuning(const char* key, int value);
+int shm_get_tuning(const char* key, int* value);
 
 /* ---- weight layout ---------------------------------------------------------------
  * [ntaps][rows][cols] -> [ntaps][cols][rows_pad] (zero padded): HWIO -> K-contiguous

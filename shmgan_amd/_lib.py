@@ -28,6 +28,8 @@ SIGNATURES = {
     "shm_version": (I, []),
     "shm_last_error": (C.c_char_p, []),
     "shm_last_kernel": (C.c_char_p, []),
+    "shm_set_tuning": (I, [C.c_char_p, I]),
+    "shm_get_tuning": (I, [C.c_char_p, P]),
     "shm_transpose_taps": (I, [P, P, I, I, I, I, I, P]),
     "shm_cast_f32": (I, [P, P, Z, I, P]),
     "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),

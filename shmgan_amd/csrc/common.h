@@ -15,6 +15,22 @@ typedef __bf16 bf16_t;            // activation element type of the bf16 path (S
 void shm_set_error(const char* fmt, ...);
 void shm_set_last_kernel(const char* fmt, ...);        // symbol of the MFMA kernel a convolution entry point chose
 
+// Dispatch knobs behind shm_set_tuning()/shm_get_tuning() (include/shmgan_hip.h lists the keys).  Process-wide
+// atomics read at every launch; the initial value comes from the environment variable named in the table of
+// norm_elem.hip (so tools/ablate_conv.py keeps working), -1/0 = the built-in choice.
+enum ShmTune {
+    SHM_TUNE_TAPGEMM_VARIANT = 0,     // SHM_TG_* below; 0 = automatic
+    SHM_TUNE_TAPGEMM_HALO_MIN,        // fp32: smallest grid (blocks) that takes the 16x16-patch halo kernel
+    SHM_TUNE_TAPGEMM_SMALL_GRID,      // grids below this many 128x128 tiles take the 64x128 tile
+    SHM_TUNE_WGRAD_VARIANT,           // 0 = automatic, 1 = generic kernel only, 2 = halo kernel but no thin-input packing
+    SHM_TUNE_WGRAD_BLOCKS,            // split-K target (blocks), 0 = automatic
+    SHM_TUNE_STATS_FUSION,            // 1 = InstanceNorm statistics in the conv epilogue (default), 0 = separate pass
+    SHM_TUNE_COUNT
+};
+int shm_tune(int id);
+
+#define SHM_TG_COUNT 11           // SHM_TG_* of include/shmgan_hip.h
+
 // 4-channel vector access in either element type; arithmetic is always fp32.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
@@ -87,6 +103,18 @@ __device__ __forceinline__ float rnd_as(const bf16_t*, float v) { return (float)
     do {                                                                        \
         hipError_t e__ = hipGetLastError();                                     \
         if (e__ != hipSuccess) {                                                \
+            shm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return SHM_E_HIP;                                                   \
+        }                                                                       \
+    } while (0)
+
+// The same for an entry point whose f64 scratch is "zero on entry, zero on return": if a launch after the one that
+// filled the scratch fails, clear it (best effort) so that a transient error does not poison every later call.
+#define SHM_LAUNCH_CHECK_CLEAR(name, ptr, bytes, st)                            \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            (void)hipMemsetAsync((ptr), 0, (bytes), (st));                      \
             shm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
             return SHM_E_HIP;                                                   \
         }                                                                       \

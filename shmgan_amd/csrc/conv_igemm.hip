@@ -626,78 +626,95 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
+// Variant choice.  `forced` (shm_set_tuning("tapgemm.variant", SHM_TG_*)) overrides the automatic choice; a forced
+// variant the shape is not eligible for is an error (SHM_E_SHAPE), so a parity test that forces a variant knows it ran.
 template <typename T, typename TO>
-static void launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStream_t st) {
-    static const int dma_small = getenv("SHM_TAPGEMM_SMALL") ? atoi(getenv("SHM_TAPGEMM_SMALL")) : 1;
-    static const int dma_big = getenv("SHM_TAPGEMM_BIG") ? atoi(getenv("SHM_TAPGEMM_BIG")) : 0;
-    static const int use_halo = getenv("SHM_TAPGEMM_NOHALO") ? 0 : 1;
+static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
     constexpr int BKE = 64 / (int)sizeof(T);
     const char* tn = sizeof(T) == 4 ? "float" : "__bf16";
     const char* ton = sizeof(TO) == 4 ? "float" : "__bf16";
-    // Cout <= 64: the 4-wave BN = 64 variant.  In fp32 it is off by default (SHM_TAPGEMM_HALO64=1 to try).
-    static const int halo64 = getenv("SHM_TAPGEMM_HALO64") ? atoi(getenv("SHM_TAPGEMM_HALO64")) : -1;
-    const bool small_ok = halo64 >= 0 ? halo64 != 0 : sizeof(T) == 2;
-    if (use_halo && nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && (a.nout > 64 || small_ok) && a.hi % 16 == 0 &&
-        a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi) {
-        bool unit = true;                      // every tap within the 1-pixel halo
-        for (int t = 0; t < 9; ++t) unit = unit && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
+    const int forced = shm_tune(SHM_TUNE_TAPGEMM_VARIANT);
+    // the 16x16-patch halo kernels: unit-stride 3x3 (forward or flipped taps), whole patches
+    bool halo_ok = nphase == 1 && a.is == 1 && a.os == 1 && a.ph[0].ntaps == 9 && a.hi % 16 == 0 && a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi;
+    if (halo_ok)
+        for (int t = 0; t < 9; ++t)             // every tap within the 1-pixel halo
+            halo_ok = halo_ok && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
+    const bool bk32_ok = a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0);
+    int v = forced;
+    if (v == SHM_TG_AUTO) {
         // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
         // grid quantization than the halo reuse gains in fp32 (measured: 32x32 maps 113 vs 133 TFLOP/s).
         // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
-        static const int halo_min = getenv("SHM_TAPGEMM_HALO_MIN") ? atoi(getenv("SHM_TAPGEMM_HALO_MIN")) : 1024;
         const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
-        if (unit && a.nout <= 64) {
-            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), 1, 1);
-            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), grid, dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16>", tn, ton);
-            return;
-        }
-        // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
-        // bf16 (806-975 vs 795-994 TFLOP/s over the four big layer shapes), so the barrier group size is not what
-        // holds the bf16 loop at ~45 % MFMA utilisation.  Kept selectable.
-        static const int ph8 = getenv("SHM_TAPGEMM_PH8") ? atoi(getenv("SHM_TAPGEMM_PH8")) : 0;
-        if (unit && ph8 && sizeof(T) == 2) {
-            dim3 grid(batch * (a.hi / 8) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
-            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 8>), grid, dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
-            return;
-        }
-        if (unit && (nblk >= halo_min || sizeof(T) == 2)) {
-            dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, 128), 1);
-            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), grid, dim3(512), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16>", tn, ton);
-            return;
-        }
+        const long tiles128 = (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase;
+        if (halo_ok && a.nout <= 64 && sizeof(T) == 2)
+            v = SHM_TG_HALO64;                  // fp32: the 4-wave 64-channel halo block measures like the 128x64 DMA tile
+        else if (halo_ok && a.nout > 64 && (sizeof(T) == 2 || nblk >= shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)))
+            v = SHM_TG_HALO128;
+        else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID))
+            // small grids (the n = 8 G(1) pass, 16x16 maps): 64-row tiles double the number of blocks, so a CU holds
+            // two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
+            v = SHM_TG_DMA_64x128;
+        else if (a.nout > 64)
+            v = SHM_TG_DMA_128x128;
+        else
+            v = SHM_TG_DMA_128x64;
     }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
-    static const int bk32 = getenv("SHM_TAPGEMM_BK32") ? atoi(getenv("SHM_TAPGEMM_BK32")) : 0;
-    static const int small_m_min = getenv("SHM_TAPGEMM_SMALLM") ? atoi(getenv("SHM_TAPGEMM_SMALLM")) : 1024;
-    if (a.nout > 64 && bk32 && a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0)) {
-        if (bk32 == 2) {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 4, 16>", tn, ton);
-        } else {
-            hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 2, 32>", tn, ton);
+    const int npatch = batch * (a.hi / 16) * (a.wi / 16);
+    switch (v) {
+    case SHM_TG_HALO128:
+        SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128 needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
+        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16>", tn, ton);
+        break;
+    case SHM_TG_HALO64:
+        SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64 needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
+        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16>", tn, ton);
+        break;
+    case SHM_TG_HALO128_PH8:
+        // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
+        // bf16 (806-975 vs 795-994 TFLOP/s over the four big layer shapes).  Kept selectable.
+        SHM_REQUIRE(halo_ok && sizeof(T) == 2, SHM_E_SHAPE, "%s: forced variant halo128/ph8 is bf16, unit-stride 3x3, map multiple of 16", who);
+        if constexpr (sizeof(T) == 2) {
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 8>), dim3(batch * (a.hi / 8) * (a.wi / 16), shm_cdiv(a.nout, 128), 1), dim3(256), 0, st, a);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
         }
-    } else if (a.nout > 64 && dma_big && a.M >= 256 * 512) {
-        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
-        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 128, 4, 2, 3, 16>", tn, ton);
-    } else if (a.nout > 64 && small_m_min > 0 && (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase < small_m_min) {
-        // small grids (the n = 8 G(1) pass, 16x16 maps): 64-row tiles double the number of blocks, so a CU holds
-        // two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
-        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 64, 128, 2, 2, 3, 16>), grid1d(64, 128), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 64, 128, 2, 2, 3, 16>", tn, ton);
-    } else if (a.nout > 64) {
+        break;
+    case SHM_TG_DMA_128x128:
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 3, 16>", tn, ton);
-    } else if (dma_small == 0) {
-        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 3, 16>), grid1d(256, 64), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 64, 4, 1, 3, 16>", tn, ton);
-    } else {
+        break;
+    case SHM_TG_DMA_64x128:
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 64, 128, 2, 2, 3, 16>), grid1d(64, 128), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 64, 128, 2, 2, 3, 16>", tn, ton);
+        break;
+    case SHM_TG_DMA_128x64:
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 64, 2, 2, 3, 16>", tn, ton);
+        break;
+    case SHM_TG_DMA_256x64:
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 3, 16>), grid1d(256, 64), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 64, 4, 1, 3, 16>", tn, ton);
+        break;
+    case SHM_TG_DMA_256x128:
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 128, 4, 2, 3, 16>), grid1d(256, 128), dim3(512), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 256, 128, 4, 2, 3, 16>", tn, ton);
+        break;
+    case SHM_TG_DMA_128x128_BK32:
+        SHM_REQUIRE(bk32_ok, SHM_E_SHAPE, "%s: forced variant bk32 needs channel counts that are multiples of %d", who, 2 * BKE);
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 2, 32>), grid1d(128, 128), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 2, 32>", tn, ton);
+        break;
+    case SHM_TG_DMA_128x128_NST4:
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 4, 16>), grid1d(128, 128), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 4, 16>", tn, ton);
+        break;
+    default:
+        SHM_REQUIRE(false, SHM_E_SHAPE, "%s: unknown tapgemm.variant %d", who, v);
     }
+    return SHM_OK;
 }
 
 static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipStream_t st, const char* who) {
@@ -729,12 +746,14 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
         a.x2bytes = (unsigned)x2b;
         a.wbytes = (unsigned)wb;
     }
+    int rc;
     if (dtype == SHM_BF16)
-        launch_tapgemm_t<bf16_t, bf16_t>(a, batch, nphase, st);
+        rc = launch_tapgemm_t<bf16_t, bf16_t>(a, batch, nphase, st, who);
     else if (dtype == SHM_BF16_GF32)
-        launch_tapgemm_t<bf16_t, float>(a, batch, nphase, st);
+        rc = launch_tapgemm_t<bf16_t, float>(a, batch, nphase, st, who);
     else
-        launch_tapgemm_t<float, float>(a, batch, nphase, st);
+        rc = launch_tapgemm_t<float, float>(a, batch, nphase, st, who);
+    if (rc) return rc;
     SHM_LAUNCH_CHECK(who);
     return SHM_OK;
 }
@@ -827,8 +846,7 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
     shm_same_pad(hi, ksize, stride, &ho, &pt);
     shm_same_pad(wi, ksize, stride, &wo, &pt);
     const int hw = ho * wo;
-    static const int fuse = getenv("SHM_NO_STATS_FUSION") ? 0 : 1;
-    if (!fuse || hw % 64 != 0) {       // tiny maps: separate statistics pass
+    if (!shm_tune(SHM_TUNE_STATS_FUSION) || hw % 64 != 0) {       // tiny maps: separate statistics pass
         int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
         if (r) return r;
         return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, dtype, stream);
@@ -848,8 +866,10 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
     r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
     g_conv_stats = nullptr;
     g_conv_slots = 1;
-    if (r) return r;
-    return shm_in_finalize_internal(stats, scratch, slots, batch * cout, hw, (double)eps, (hipStream_t)stream);
+    if (r == SHM_OK) r = shm_in_finalize_internal(stats, scratch, slots, batch * cout, hw, (double)eps, (hipStream_t)stream);
+    // "zero on entry, zero on return" also on the error path: a failed launch must not leave sums behind
+    if (r != SHM_OK && scratch) (void)hipMemsetAsync(scratch, 0, (size_t)SHM_STATS_SLOTS * batch * cout * 2 * sizeof(double), (hipStream_t)stream);
+    return r;
 }
 
 // Transposed stride-2 product shared by Conv2DTranspose forward and the stride-2 dgrad:

@@ -908,8 +908,8 @@ static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 
     int tiles = shm_cdiv(cin, 64) * shm_cdiv(cout, 64);
     // (bf16: the MFMA kernel is ~6x faster, so the slab traffic of the split weighs more: 512 blocks measured
     // best, 35.0 vs 36.0 ms/step at 1024)
-    static const int target_env = getenv("SHM_WGRAD_BLOCKS") ? atoi(getenv("SHM_WGRAD_BLOCKS")) : 0;
-    const int target = target_env ? target_env : (esz == 2 ? 512 : 1024);
+    const int target_tuned = shm_tune(SHM_TUNE_WGRAD_BLOCKS);
+    const int target = target_tuned ? target_tuned : (esz == 2 ? 512 : 1024);
     int want = shm_cdiv(target, tiles);
     long maxs = (M + 255) / 256;                 // at least 256 pixels per split
     if (want > maxs) want = (int)maxs;
@@ -983,9 +983,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     a.pix_per_split = pps;
     hipStream_t st = (hipStream_t)stream;
     const bool straddle = x2 && (c1 % 64 != 0);
-    static const int no_halo = getenv("SHM_WGRAD_NOHALO") ? 1 : 0;
+    const int wv = shm_tune(SHM_TUNE_WGRAD_VARIANT);       // 0 automatic, 1 generic kernels only, 2 no thin-input packing
+    const int no_halo = wv == 1;
     const bool halo_ok = ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo;
-    static const int no_thin = getenv("SHM_WGRAD_NOTHIN") ? 1 : 0;
+    const int no_thin = wv == 2;
     // thin first layers: (tap, ci) pairs packed into the MFMA rows; patches of 2 x 16 OUTPUT pixels
     const bool thin_ok = !no_thin && !no_halo && ksize == 3 && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16 && wo % 16 == 0 && ho % 2 == 0 &&
                          hi % stride == 0 && wi % stride == 0;

@@ -29,9 +29,81 @@ void shm_set_last_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- dispatch tuning (shm_set_tuning / shm_get_tuning) -------------------------------------------------
+#include <atomic>
+#include <stdlib.h>
+#include <string.h>
+namespace {
+struct TuneDef {
+    const char* key;
+    const char* env;       // initial value (read once) -- keeps the ablation tools' environment knobs alive
+    int dflt, lo, hi;
+};
+const TuneDef kTune[SHM_TUNE_COUNT] = {
+    {"tapgemm.variant", "SHM_TAPGEMM_VARIANT", 0, 0, SHM_TG_COUNT - 1},
+    {"tapgemm.halo_min_blocks", "SHM_TAPGEMM_HALO_MIN", 1024, 0, 1 << 30},
+    {"tapgemm.small_grid_blocks", "SHM_TAPGEMM_SMALLM", 1024, 0, 1 << 30},
+    {"wgrad.variant", "SHM_WGRAD_VARIANT", 0, 0, 2},
+    {"wgrad.blocks", "SHM_WGRAD_BLOCKS", 0, 0, 1 << 20},
+    {"stats.fusion", "SHM_STATS_FUSION", 1, 0, 1},
+};
+std::atomic<int> g_tune[SHM_TUNE_COUNT];
+std::atomic<int> g_tune_init{0};
+void tune_init() {
+    if (g_tune_init.load(std::memory_order_acquire) == 2) return;
+    int expect = 0;
+    if (g_tune_init.compare_exchange_strong(expect, 1)) {
+        for (int i = 0; i < SHM_TUNE_COUNT; ++i) {
+            const char* e = getenv(kTune[i].env);
+            int v = e ? atoi(e) : kTune[i].dflt;
+            if (v < kTune[i].lo || v > kTune[i].hi) v = kTune[i].dflt;
+            g_tune[i].store(v);
+        }
+        g_tune_init.store(2, std::memory_order_release);
+    } else {
+        while (g_tune_init.load(std::memory_order_acquire) != 2) {
+        }
+    }
+}
+int tune_find(const char* key) {
+    if (!key) return -1;
+    for (int i = 0; i < SHM_TUNE_COUNT; ++i)
+        if (strcmp(key, kTune[i].key) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+int shm_tune(int id) {
+    tune_init();
+    return g_tune[id].load(std::memory_order_relaxed);
+}
+
+extern "C" int shm_set_tuning(const char* key, int value) {
+    tune_init();
+    if (key && strcmp(key, "reset") == 0) {            // every knob back to its built-in default
+        for (int i = 0; i < SHM_TUNE_COUNT; ++i) g_tune[i].store(kTune[i].dflt);
+        return SHM_OK;
+    }
+    const int i = tune_find(key);
+    SHM_REQUIRE(i >= 0, SHM_E_SHAPE, "shm_set_tuning: unknown key '%s'", key ? key : "(null)");
+    if (value < 0) value = kTune[i].dflt;                // negative = default
+    SHM_REQUIRE(value >= kTune[i].lo && value <= kTune[i].hi, SHM_E_SHAPE, "shm_set_tuning: %s = %d outside [%d, %d]", key, value,
+                kTune[i].lo, kTune[i].hi);
+    g_tune[i].store(value);
+    return SHM_OK;
+}
+
+extern "C" int shm_get_tuning(const char* key, int* value) {
+    tune_init();
+    const int i = tune_find(key);
+    SHM_REQUIRE(i >= 0 && value, SHM_E_SHAPE, "shm_get_tuning: unknown key '%s'", key ? key : "(null)");
+    *value = g_tune[i].load();
+    return SHM_OK;
+}
+
 extern "C" const char* shm_last_error(void) { return g_err; }
 extern "C" const char* shm_last_kernel(void) { return g_kernel; }
-extern "C" int shm_version(void) { return 110; }
+extern "C" int shm_version(void) { return 200; }
 
 extern "C" int shm_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return SHM_OK;
@@ -431,14 +503,15 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
         SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
         SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
     }
-    SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
+    const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
+    SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(apply)", red, red_bytes, st);
     if (dbias) {
         hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red);
     } else {
         int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
         if (r) return r;
     }
-    SHM_LAUNCH_CHECK("shm_in_bwd(apply)");
+    SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
     return SHM_OK;
 }
 
@@ -503,7 +576,7 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
     if (dbias) {
         hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr);
-        SHM_LAUNCH_CHECK("shm_lrelu_bwd(fold)");
+        SHM_LAUNCH_CHECK_CLEAR("shm_lrelu_bwd(fold)", red, (size_t)SHM_LRELU_RED_SLOTS * c * sizeof(double), (hipStream_t)stream);
     }
     return SHM_OK;
 }

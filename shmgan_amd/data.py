@@ -53,28 +53,47 @@ class PolarDataset:
         from PIL import Image
         with Image.open(path) as im:
             a = np.array(im.convert("RGB"), dtype=np.uint8)             # own, writable copy
+        # allocated, filled and consumed on the loader stream: the caching allocator hands the block back to
+        # loader-stream allocations only, which are ordered behind the resize kernel -- no host sync needed
         src = torch.from_numpy(a).to(self.dev, non_blocking=False)
         ops.resize_bilinear_u8(src, out, 1.0 / 255.0, self.flip_ud)
-        return src                                   # keep alive until the kernel has run
+
+    def prepare(self, index):
+        """Start batch `index` (0-based) on the loader's stream; returns (five [B,S,S,3] tensors, ready event).
+        The outputs are ALLOCATED on the loader stream: a block the consumer has dropped is then only reused
+        after the consumer stream's work recorded by `take()` has finished (train_step is fully asynchronous and
+        reads its inputs late in the step, so allocating them on the consumer stream would let the next batch's
+        resize kernels overwrite images that queued step kernels still read)."""
+        with torch.cuda.stream(self.stream):
+            outs = [torch.empty((self.B, self.S, self.S, 3), device=self.dev) for _ in range(5)]
+            for v in range(5):
+                for b in range(self.B):
+                    self._load(self.files[v][index * self.B + b], outs[v][b])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return tuple(outs), ev
+
+    def take(self, prepared):
+        """Hand a prepared batch to the current stream."""
+        outs, ev = prepared
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in outs:
+            t.record_stream(cur)
+        return outs
 
     def batch(self, index):
         """Batch `index` (0-based) as five [B,S,S,3] tensors; prepared on the loader's stream."""
-        outs = [torch.empty((self.B, self.S, self.S, 3), device=self.dev) for _ in range(5)]
-        keep = []
-        with torch.cuda.stream(self.stream):
-            for v in range(5):
-                for b in range(self.B):
-                    keep.append(self._load(self.files[v][index * self.B + b], outs[v][b]))
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        torch.cuda.current_stream().wait_event(ev)
-        self.stream.synchronize()                    # host buffers of `keep` may go
-        return tuple(outs)
+        return self.take(self.prepare(index))
 
     def __iter__(self):
-        for _ in range(self.epochs):
-            for i in range(len(self)):
-                yield self.batch(i)
+        """One batch is always in preparation on the loader stream while the previous one is consumed."""
+        order = [i for _ in range(self.epochs) for i in range(len(self))]
+        nxt = self.prepare(order[0]) if order else None
+        for j in range(len(order)):
+            cur = nxt
+            nxt = self.prepare(order[j + 1]) if j + 1 < len(order) else None
+            yield self.take(cur)
 
 
 def datasetLoad(trainer, subdirs=PSD_SUBDIRS, flip_ud=True):

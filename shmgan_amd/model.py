@@ -526,7 +526,8 @@ class Discriminator(_ModelBase):
             ho = h // 2
             a, ahat, stats = bufs[i]
             st = stats[r0 * cout * 2:r1 * cout * 2]
-            scr = self.arena.get(f"d/stats_scratch/{nb * cout}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
+            # keyed by the row range: two parts evaluated on two streams must not share a zero-on-entry scratch
+            scr = self.arena.get(f"d/stats_scratch/{r0}:{r1}/{cout}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
             ops.conv2d_in_fwd(cur, None, 0, ld, 0, self.wk[i], None, a[r0:r1], cout, nb, h, h, _padk(cin, self.pad), cout, 3, 2,
                               LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
             ops.in_apply(a[r0:r1], cout, st, self.betas[i], ahat[r0:r1], cout, nb, ho * ho, cout)

@@ -90,6 +90,31 @@ def _dtg(act, grad):
     return d
 
 
+# SHM_TG_* of include/shmgan_hip.h
+TAPGEMM_VARIANTS = {"auto": 0, "halo128": 1, "halo64": 2, "dma128x128": 3, "dma64x128": 4, "dma128x64": 5, "dma256x64": 6,
+                    "dma256x128": 7, "halo128_ph8": 8, "dma128x128_bk32": 9, "dma128x128_nst4": 10}
+
+
+def set_tuning(key, value):
+    """shm_set_tuning: dispatch knobs of the MFMA kernels ("tapgemm.variant", "wgrad.variant", ... see the header);
+    `value` may be a TAPGEMM_VARIANTS name.  set_tuning("reset", 0) restores every default."""
+    if isinstance(value, str):
+        value = TAPGEMM_VARIANTS[value]
+    check(lib().shm_set_tuning(key.encode(), int(value)), "shm_set_tuning")
+
+
+def get_tuning(key):
+    import ctypes
+    v = ctypes.c_int(0)
+    check(lib().shm_get_tuning(key.encode(), ctypes.addressof(v)), "shm_get_tuning")
+    return v.value
+
+
+def last_kernel():
+    k = lib().shm_last_kernel()
+    return k.decode() if k else ""
+
+
 def cast_f32(src, dst, n):
     check(lib().shm_cast_f32(_p(src), _p(dst), n, _dt(dst), _stream()), "shm_cast_f32")
 

@@ -317,7 +317,10 @@ class ShmGANwithSSpecSeg:
         G.backward(dgen_y, "g1", need_dx=False)
         G.finish_grads()
         self._get_lane().join()                 # all weight gradients (both models) are complete
-        ev_g = self._allreduce_async(G.P.grad)
+        update_g = self.epoch >= self.train_G_after
+        # no collective for a gradient nobody applies (it would also still be in flight when the next step
+        # zeroes the bucket)
+        ev_g = self._allreduce_async(G.P.grad) if (update_g or not apply) else None
 
         # ---- clip + Adam  SHM.py:859-872
         if apply:
@@ -326,7 +329,7 @@ class ShmGANwithSSpecSeg:
                 cur.wait_event(ev_d)
             self.optimizer_D.apply(D.P, 1.0 / world)
             D.weights_dirty = True
-            if self.epoch >= self.train_G_after:
+            if update_g:
                 if ev_g is not None:
                     cur.wait_event(ev_g)
                 self.optimizer_G.apply(G.P, 1.0 / world)
@@ -349,6 +352,87 @@ class ShmGANwithSSpecSeg:
         self._last = SimpleNamespace(dl=dl, il=il, sl=sl, npix=npix, B=B, flags=flags, T=T, scales=scales, ds=ds, cbcr=cbcr)
         self._loss_cache = None
         return None
+
+    # ------------------------------------------------------------------ the training loop (SHM.py:889-1139)
+    def train(self, args=None, *, max_steps=None, print_fn=print):
+        """`shmgan.train(args)` of /root/reference/main.py:107 (loop: SHM.py:889-1139): datasetLoad ->
+        build_generator / build_discriminator (+ summaries) -> SpecSeg -> restore the latest checkpoint ->
+        for epoch / for batch in range(batches_per_epoch - 1): TARGET_LABELS ~ U(0.8, 1.2) (SHM.py:986),
+        next 5-tuple (SHM.py:990), train_step (SHM.py:998) -> checkpoint every `checkpoint_save_step` epochs
+        (SHM.py:1125-1128) and once more at the end (SHM.py:1133).
+
+        Differences, all outside the arithmetic: checkpoints are the neutral .npz of save_npz (Keras variable order
+        and layouts; newest 3 kept, as CheckpointManager(max_to_keep=3)) instead of TF checkpoints; the summaries go
+        to `log_dir`; the Comet histogram upload at step 100 (which raises AttributeError in the reference, SURVEY
+        section 3.1) and the per-step gc.collect() are not reproduced.  `max_steps` (tests) stops early.  Returns the
+        number of train_step calls made."""
+        import os
+        import time
+        from .data import datasetLoad
+        if args is not None:
+            for k, v in vars(args).items():
+                setattr(self.args, k, v)
+                if k in self.__dict__:
+                    setattr(self, k, v)
+        start = time.perf_counter()
+        self.length_dataset, dataset = datasetLoad(self)                       # SHM.py:904
+        if self.G is None:
+            self.build()                                                       # SHM.py:911-912, 930-931
+        os.makedirs(self.log_dir, exist_ok=True)
+        for mdl, fn in ((self.G, "Generator_summary.txt"), (self.D, "Discriminator_summary.txt"), (self.SpecSeg, "SpecSeg_summary.txt")):
+            with open(os.path.join(self.log_dir, fn), "w") as f:               # SHM.py:914-919, 933-935
+                mdl.summary(print_fn=lambda x: f.write(x + "\n"))
+        os.makedirs(self.checkpoint_save_dir, exist_ok=True)
+        latest = self._latest_checkpoint()
+        if latest is not None:                                                 # SHM.py:949-951 (delete_old_checkpoints is False)
+            self.load_npz(latest)
+            print_fn(f"Latest checkpoint restored!! ({latest})")
+        iterator = iter(dataset)                                               # SHM.py:955
+        batches_per_epoch = int(self.length_dataset / self.batch_size)         # SHM.py:957
+        self.batch_step = 0
+        done = False
+        for epoch in range(self.num_epochs):                                   # SHM.py:969
+            self.epoch = epoch
+            print_fn(f"\nStart of Training Epoch {self.epoch}")
+            for batch in range(batches_per_epoch - 1):                         # SHM.py:979
+                self.batch_step += 1
+                self.random_flip = bool(self._rng.random() >= 0.5)            # SHM.py:983 (inert: the map lambda is already traced)
+                self.TARGET_LABELS = float(self._rng.uniform(0.8, 1.2))       # SHM.py:986
+                element = next(iterator)                                       # SHM.py:990
+                self.train_step(*element)                                      # SHM.py:998
+                if max_steps is not None and self.batch_step >= max_steps:
+                    done = True
+                    break
+            if (self.epoch + 1) % self.log_step == 0:                          # SHM.py:1099-1106
+                torch.cuda.current_stream().synchronize()
+                print_fn("Time taken for epoch {} is {} min\n".format(self.epoch + 1, (time.perf_counter() - start) / 60))
+            if (self.epoch + 1) % self.checkpoint_save_step == 0:              # SHM.py:1125-1128
+                print_fn("Saving checkpoint for epoch {} at {}".format(self.epoch + 1, self._save_checkpoint()))
+            if done:
+                break
+        print_fn("Saving checkpoint for epoch {} at {}".format(self.epoch + 1, self._save_checkpoint()))   # SHM.py:1133
+        return self.batch_step
+
+    def _checkpoints(self):
+        import glob
+        import os
+        return sorted(glob.glob(os.path.join(self.checkpoint_save_dir, "ckpt-*.npz")),
+                      key=lambda p: int(os.path.basename(p)[5:-4]))
+
+    def _latest_checkpoint(self):
+        c = self._checkpoints()
+        return c[-1] if c else None
+
+    def _save_checkpoint(self, max_to_keep=3):
+        """tf.train.CheckpointManager(ckpt, checkpoint_dir, max_to_keep=3).save() (SHM.py:944, 1127)."""
+        import os
+        c = self._checkpoints()
+        n = int(os.path.basename(c[-1])[5:-4]) + 1 if c else 1
+        path = os.path.join(self.checkpoint_save_dir, f"ckpt-{n}.npz")
+        self.save_npz(path)
+        for old in (c + [path])[:-max_to_keep]:
+            os.remove(old)
+        return path
 
     # ------------------------------------------------------------------ inference (test.py:218-297)
     def infer(self, rgb):

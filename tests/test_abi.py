@@ -57,3 +57,31 @@ def test_product_does_not_import_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
     for p in pathlib.Path(_lib.__file__).resolve().parent.glob("*.py"):
         assert not pat.search(p.read_text()), f"{p} imports the oracle (test infrastructure only)"
+
+
+def test_trainer_surface_matches_the_reference_object():
+    """The methods and signatures main.py / test.py use on the reference's trainer object:
+    __init__(args), build_generator(), build_discriminator(), train_step(5 tensors), train(args) (main.py:107),
+    custom_per_image_standardization, gram_matrix."""
+    import inspect
+    from shmgan_amd import ShmGANwithSSpecSeg as T
+    assert list(inspect.signature(T.train).parameters)[:2] == ["self", "args"]
+    assert list(inspect.signature(T.train_step).parameters)[:6] == ["self", "orig0", "orig45", "orig90", "orig135", "origED"]
+    for name in ("build_generator", "build_discriminator", "custom_per_image_standardization", "gram_matrix", "infer",
+                 "save_npz", "load_npz"):
+        assert callable(getattr(T, name))
+
+
+def test_tuning_keys_roundtrip_without_gpu():
+    L = _lib.lib()
+    v = C.c_int(-5)
+    assert L.shm_get_tuning(b"tapgemm.variant", C.addressof(v)) == 0 and v.value == 0
+    assert L.shm_set_tuning(b"tapgemm.variant", 3) == 0
+    assert L.shm_get_tuning(b"tapgemm.variant", C.addressof(v)) == 0 and v.value == 3
+    assert L.shm_set_tuning(b"tapgemm.variant", 99) == -1 and b"outside" in L.shm_last_error()
+    assert L.shm_set_tuning(b"bogus", 1) == -1 and b"unknown key" in L.shm_last_error()
+    assert L.shm_set_tuning(b"reset", 0) == 0
+    assert L.shm_get_tuning(b"tapgemm.variant", C.addressof(v)) == 0 and v.value == 0
+    for key, dflt in ((b"tapgemm.halo_min_blocks", 1024), (b"tapgemm.small_grid_blocks", 1024), (b"wgrad.variant", 0),
+                      (b"wgrad.blocks", 0), (b"stats.fusion", 1)):
+        assert L.shm_get_tuning(key, C.addressof(v)) == 0 and v.value == dflt, key

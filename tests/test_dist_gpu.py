@@ -1,0 +1,78 @@
+"""The PRODUCT's data-parallel path on the device: two ranks share the one GPU of the test box (gloo moves the CUDA
+buckets; RCCL refuses two ranks on one device), each runs ShmGANwithSSpecSeg.train_step on one sample, and the result
+must equal one single-process step on both samples (sum over ranks, 1/world inside clip+Adam).  This
+executes GradReducer's side-stream branch (ready / after / done events), the D bucket launched behind the weight-gradient
+lane, the G bucket, the 1/world gscale and the wait before Adam."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import step_torch as st
+from util import cosine, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+S, F = 64, 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shmgan_amd import ShmGANwithSSpecSeg
+    from shmgan_amd.dist import world_size
+    assert world_size() == world
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=1).build()
+    inp2 = st.make_inputs(2, S)
+    dr = st.make_draws(1, 2, S, F)
+    drb = st.StepDraws(dr.flags, dr.target_label, dr.noise[[rank, 2 + rank]], dr.keep_mask[[rank, 2 + rank]])
+    sf = st.style_factor_intended(S)
+    m.train_step(*[a[rank:rank + 1] for a in inp2], draws=drb, style_factor=sf, apply=True)
+    torch.cuda.synchronize()
+    assert m._reducer.stream is not None               # the collectives ran on the side stream
+    q.put((rank, m.G.P.grad.cpu().numpy(), m.D.P.grad.cpu().numpy(), m.G.P.flat.cpu().numpy(), m.D.P.flat.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_batch_of_two():
+    from shmgan_amd import ShmGANwithSSpecSeg
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    # the single-process reference: B = 2, same draws
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=2).build()
+    m.train_step(*st.make_inputs(2, S), draws=st.make_draws(1, 2, S, F), style_factor=st.style_factor_intended(S), apply=True)
+    torch.cuda.synchronize()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=900)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    refs = (host(m.G.P.grad), host(m.D.P.grad), host(m.G.P.flat), host(m.D.P.flat))
+    for rank in (0, 1):
+        gG, gD, wG, wD = got[rank]
+        # the reduced buckets hold the SUM over ranks of per-sample means: /world = the mean over both samples
+        assert rel_l2(gG / 2, refs[0]) < 1e-3 and cosine(gG / 2, refs[0]) > 0.99999, rel_l2(gG / 2, refs[0])
+        assert rel_l2(gD / 2, refs[1]) < 1e-3 and cosine(gD / 2, refs[1]) > 0.99999, rel_l2(gD / 2, refs[1])
+        # ... and clip + Adam with gscale = 1/world leaves the same weights on every rank
+        assert np.abs(wG - refs[2]).max() < 2e-5 and np.abs(wD - refs[3]).max() < 2e-5
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])     # replicas stay identical

@@ -1,0 +1,109 @@
+"""The callers of train_step on the device: `train(args)` (SHM.py:889-1139, called by main.py:107), the dataset
+loader's stream safety, and the run-to-run reproducibility of a step."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_np as dn
+from oracle import step_torch as st
+from util import host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(root, n, rng, hw=(40, 50)):
+    from PIL import Image
+    from shmgan_amd.data import PSD_SUBDIRS
+    ref = {}
+    for v, sub in enumerate(PSD_SUBDIRS):
+        (root / sub).mkdir(parents=True)
+        for i in range(n):
+            img = rng.integers(0, 256, (hw[0], hw[1], 3)).astype(np.uint8)
+            Image.fromarray(img).save(root / sub / f"img_{i:03d}.png")
+            ref[(v, i)] = img
+    return ref
+
+
+def test_train_entry_runs_epochs_and_checkpoints(tmp_path):
+    """main.py:103-107: ShmGANwithSSpecSeg(args).train(args) on 4 five-view tuples: (4 - 1) steps per epoch (SHM.py:979),
+    TARGET_LABELS redrawn per step (SHM.py:986), a checkpoint per `checkpoint_save_step` epochs + one at exit, newest 3
+    kept; a second train() restores the latest one (SHM.py:949-951)."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    _write_dataset(tmp_path / "data", 4, np.random.default_rng(1))
+    args = argparse.Namespace(mode="train", image_size=32, batch_size=1, filter_size=16, num_epochs=2, g_lr=2e-5, d_lr=2e-5,
+                              beta1=0.5, beta2=0.99, data_dir=str(tmp_path / "data"), checkpoint_save_dir=str(tmp_path / "ckpt"),
+                              log_dir=str(tmp_path / "logs"), log_step=1, checkpoint_save_step=1)
+    shmgan = ShmGANwithSSpecSeg(args)
+    lines, labels = [], []
+    step0 = shmgan.train_step
+
+    def spy(*a, **k):
+        labels.append(shmgan.TARGET_LABELS)
+        return step0(*a, **k)
+
+    shmgan.train_step = spy
+    n = shmgan.train(args, print_fn=lines.append)
+    torch.cuda.synchronize()
+    assert n == 6 and shmgan.G.P.iterations == 6 and shmgan.D.P.iterations == 6 and shmgan.epoch == 1
+    assert len(set(labels)) == 6 and all(0.8 <= t <= 1.2 for t in labels)
+    assert np.isfinite(shmgan.losses()["total_Generator_loss"])
+    names = sorted(p.name for p in (tmp_path / "ckpt").glob("*.npz"))
+    assert names == ["ckpt-1.npz", "ckpt-2.npz", "ckpt-3.npz"]
+    assert (tmp_path / "logs" / "Generator_summary.txt").read_text().count("Conv2D") >= 23
+    assert any("Start of Training Epoch 1" in l for l in lines)
+    # resume
+    args.num_epochs = 1
+    again = ShmGANwithSSpecSeg(args)
+    lines2 = []
+    assert again.train(args, max_steps=2, print_fn=lines2.append) == 2
+    assert any("Latest checkpoint restored" in l for l in lines2)
+    assert again.G.P.iterations == 8
+    assert sorted(p.name for p in (tmp_path / "ckpt").glob("*.npz")) == ["ckpt-3.npz", "ckpt-4.npz", "ckpt-5.npz"]
+
+
+def test_loader_batches_survive_an_asynchronous_consumer(tmp_path):
+    """The consumer stream runs far behind the host (as train_step does when nobody reads the losses): every batch is
+    copied by a kernel queued behind a long matmul chain and dropped at once.  The loader allocates its outputs on its
+    own stream and records the consumer stream on them, so the next batches' resize kernels must not land in memory the
+    queued copies still read."""
+    from shmgan_amd.data import PolarDataset
+    S, n = 64, 8
+    ref = _write_dataset(tmp_path, n, np.random.default_rng(2), hw=(70, 90))
+    ds = PolarDataset(str(tmp_path), S, batch_size=1)
+    big = torch.randn(4096, 4096, device="cuda")
+    copies = []
+    for batch in ds:
+        acc = big
+        for _ in range(6):                       # ~50 ms of queued work per batch in front of the copies
+            acc = acc @ big * 1e-3
+        copies.append([v.clone() for v in batch])
+        del batch, acc
+    torch.cuda.synchronize()
+    assert len(copies) == n
+    for i, c in enumerate(copies):
+        for v in range(5):
+            assert np.abs(host(c[v][0]) - dn.load_view(ref[(v, i)], S, True)).max() < 2e-6, (i, v)
+
+
+def test_step_is_reproducible_run_to_run():
+    """The only floating-point atomics in the step are float64 adds (InstanceNorm statistics slots, IN-backward sums, bias
+    gradients); weight gradients use fixed-order slab sums.  Stated bound: two identical steps agree in every named loss
+    to 1e-6 relative and in both flat gradients to rel-L2 <= 1e-6 (float64 rounding of a differently ordered sum is
+    ~1e-16 and survives the cast to fp32 only if it crosses a rounding boundary)."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 128, 32, 2
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+    inp, dr = st.make_inputs(B, S), st.make_draws(4, B, S, F)
+    runs = []
+    for _ in range(2):
+        m.train_step(*inp, draws=dr, apply=False)
+        torch.cuda.synchronize()
+        runs.append((dict(m.losses()), m.G.P.grad.clone(), m.D.P.grad.clone(), m.gen_Y.clone()))
+    (l0, g0, d0, y0), (l1, g1, d1, y1) = runs
+    for k, v in l0.items():
+        if k != "ssim":
+            assert abs(l1[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, v, l1[k])
+    assert rel_l2(host(y1), host(y0)) <= 1e-6
+    assert rel_l2(host(g1), host(g0)) <= 1e-6 and rel_l2(host(d1), host(d0)) <= 1e-6

@@ -1,0 +1,308 @@
+"""Every MFMA kernel variant the convolution entry points can dispatch to, against the float64 oracle.
+
+The variant a call takes depends on shape, dtype and grid size, so the small shapes of test_ops_gpu.py only ever
+reach some of them.  Here each variant is FORCED through the C ABI (shm_set_tuning("tapgemm.variant", SHM_TG_*));
+a forced variant that the shape is not eligible for is an error, and shm_last_kernel() is checked, so a passing case
+proves that variant computed the result.  The second half runs real layer shapes of BASELINE configs[1]
+(S=256, F=64, B=8) through the DEFAULT dispatch and asserts which kernel took them.
+
+Tolerances: fp32 rel-L2 <= 1e-5 (single conv op); bf16 operands rounded for the oracle, results
+<= 4e-3 (one bf16 rounding), fused statistics as in test_bf16_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_torch as st
+from util import conv_ref, host, nchw, nhwc, rel_l2, t64
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+TOL = {"f32": 1e-5, "bf16": 4e-3}
+SYMBOL = {
+    "halo128": "tapgemm_halo_kernel<{t}, {t}, 128, 16>", "halo64": "tapgemm_halo_kernel<{t}, {t}, 64, 16>",
+    "halo128_ph8": "tapgemm_halo_kernel<{t}, {t}, 128, 8>",
+    "dma128x128": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 3, 16>", "dma64x128": "tapgemm_dma_kernel<{t}, {t}, 64, 128, 2, 2, 3, 16>",
+    "dma128x64": "tapgemm_dma_kernel<{t}, {t}, 128, 64, 2, 2, 3, 16>", "dma256x64": "tapgemm_dma_kernel<{t}, {t}, 256, 64, 4, 1, 3, 16>",
+    "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
+    "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
+    "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
+}
+HALO = ["halo128", "halo64"]
+DMA = ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
+
+
+def _ops():
+    from shmgan_amd import ops
+    return ops
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    yield
+    _ops().set_tuning("reset", 0)
+
+
+def _sym(variant, dt):
+    return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16")
+
+
+def _dev(a, dt):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return t.to(BF) if dt == "bf16" else t
+
+
+def _rnd(a, dt):
+    """the operand as the device holds it (float64)."""
+    if dt == "bf16":
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(BF).double().numpy()
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def _wk(w_hwio, cin_pad, dt):
+    ops = _ops()
+    k, _, cin, cout = w_hwio.shape
+    wt = torch.zeros(k * k * cout * cin_pad, device="cuda", dtype=BF if dt == "bf16" else torch.float32)
+    ops.transpose_taps(torch.from_numpy(np.ascontiguousarray(w_hwio, dtype=np.float32)).cuda(), wt, k * k, cin, cout, cin_pad)
+    return wt
+
+
+def _check_stats(stats, y, n, cout, dt):
+    yy = y.reshape(n, -1, cout)
+    s = host(stats).reshape(n, cout, 2)
+    assert np.abs(s[..., 0] - yy.mean(1)).max() < (1e-4 if dt == "bf16" else 1e-6)
+    ref_inv = 1.0 / np.sqrt(yy.var(1) + 1e-6)
+    assert np.abs(s[..., 1] / ref_inv - 1).max() < (1e-3 if dt == "bf16" else 1e-5)
+
+
+def _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=0):
+    """Conv2D(+concat) + bias + LeakyReLU + fused InstanceNorm statistics under a forced variant."""
+    ops = _ops()
+    rng = np.random.default_rng(100 + seed)
+    cin = c1 + c2
+    xa = rng.standard_normal((n, h, h, c1))
+    xb = rng.standard_normal((n, h, h, c2)) if c2 else None
+    w = rng.standard_normal((k, k, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    xr = _rnd(xa, dt) if xb is None else np.concatenate([_rnd(xa, dt), _rnd(xb, dt)], -1)
+    ref = conv_ref(xr, _rnd(w, dt), s) + b
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    ho = ref.shape[1]
+    y = torch.full((n, ho, ho, cout), 9.0, device="cuda", dtype=BF if dt == "bf16" else torch.float32)
+    stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+    ops.set_tuning("tapgemm.variant", variant)
+    ops.conv2d_in_fwd(_dev(xa, dt), None if xb is None else _dev(xb, dt), c1 if c2 else 0, c1, c2, _wk(w, cin, dt),
+                      torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout, k, s, 0.2, stats, 1e-6, scratch=scr)
+    torch.cuda.synchronize()
+    assert ops.last_kernel() == _sym(variant, dt), ops.last_kernel()
+    got = host(y.float())
+    assert rel_l2(got, ref) < TOL[dt], (variant, dt, rel_l2(got, ref))
+    if (ho * ho) % 64 == 0:                   # the fused path (smaller maps take a separate statistics pass)
+        _check_stats(stats, got, n, cout, dt)
+        assert float(scr.abs().max()) == 0.0  # "zero on entry, zero on return"
+
+
+# ---- unit-stride 3x3 on maps that are multiples of 16: every variant is eligible
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", HALO + DMA)
+@pytest.mark.parametrize("n,h,c1,c2,cout", [
+    (3, 16, 64, 0, 64),          # one tile wide
+    (2, 32, 64, 0, 160),         # ragged N (160 = 128 + 32), several patches per image
+    (2, 16, 64, 128, 128),       # Concatenate([up, skip]) read from two tensors
+    (5, 16, 128, 0, 48),         # odd batch, Cout < 64 (ragged inside one tile)
+])
+def test_conv3x3_s1_forced_variant(variant, dt, n, h, c1, c2, cout):
+    _fwd_case(variant, dt, n, h, c1, c2, cout, 3, 1)
+
+
+@pytest.mark.parametrize("variant", HALO)
+def test_halo_ph8_and_halo_need_eligible_shape(variant):
+    """halo variants refuse shapes they cannot take (no silent fallback); the 8-row patch variant is bf16 only."""
+    from shmgan_amd._lib import ShmError
+    ops = _ops()
+    _fwd_case("halo128_ph8", "bf16", 2, 16, 64, 0, 128, 3, 1)
+    x = torch.zeros((1, 12, 12, 64), device="cuda")
+    w = torch.zeros(9 * 64 * 64, device="cuda")
+    y = torch.zeros((1, 12, 12, 64), device="cuda")
+    ops.set_tuning("tapgemm.variant", variant)
+    with pytest.raises(ShmError):             # 12 x 12 is not a whole number of 16 x 16 patches
+        ops.conv2d_fwd(x, None, 0, 64, 0, w, None, y, 64, 1, 12, 12, 64, 64, 3, 1, 1.0)
+    with pytest.raises(ShmError):             # stride 2
+        ops.conv2d_fwd(torch.zeros((1, 32, 32, 64), device="cuda"), None, 0, 64, 0, w, None, y, 64, 1, 32, 32, 64, 64, 3, 2, 1.0)
+    with pytest.raises(ShmError):
+        ops.set_tuning("tapgemm.variant", 99)
+    with pytest.raises(ShmError):
+        ops.set_tuning("no.such.knob", 1)
+    ops.set_tuning("tapgemm.variant", -1)
+    assert ops.get_tuning("tapgemm.variant") == 0 and ops.get_tuning("tapgemm.halo_min_blocks") == 1024
+
+
+# ---- shapes only the DMA tap GEMM takes: stride 2, 1x1, maps that are not multiples of 16, tail rows
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", DMA)
+@pytest.mark.parametrize("n,h,c1,c2,cout,k,s", [
+    (2, 32, 64, 0, 128, 3, 2),       # discriminator block
+    (3, 10, 64, 0, 96, 3, 1),        # 10 x 10 map: M = 300 (tail rows in every tile height), ragged N
+    (2, 16, 128, 0, 64, 1, 1),       # 1x1 bottleneck
+    (1, 8, 64, 64, 192, 3, 1),       # concat, M = 64 < every tile height
+])
+def test_dma_forced_variant_other_shapes(variant, dt, n, h, c1, c2, cout, k, s):
+    _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=1)
+
+
+# ---- input gradient (flipped taps / four stride-2 phases, split destination) under forced variants
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128"])
+def test_dgrad_s1_forced_variant(variant, dt):
+    ops = _ops()
+    rng = np.random.default_rng(7)
+    n, h, c1, c2, cout = 2, 16, 64, 32, 64              # dx split into (upsampled, skip) parts: n1 = 64
+    cin = c1 + c2
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    dy = rng.standard_normal((n, h, h, cout))
+    xt = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(_rnd(w, dt)), 1), xt, nchw(_rnd(dy, dt)))
+    ref = nhwc(ref)
+    adt = BF if dt == "bf16" else torch.float32
+    d1 = torch.full((n, h, h, c1), 7.0, device="cuda", dtype=adt)
+    d2 = torch.full((n, h, h, c2), 7.0, device="cuda", dtype=adt)
+    ops.set_tuning("tapgemm.variant", variant)
+    ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), d1, d2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
+    assert ops.last_kernel() == _sym(variant, dt)
+    assert rel_l2(host(d1.float()), ref[..., :c1]) < TOL[dt] and rel_l2(host(d2.float()), ref[..., c1:]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32"])
+def test_dgrad_s2_and_transpose_forced_variant(variant, dt):
+    """Stride-2 input gradient and Conv2DTranspose forward: the four-phase launches (blockIdx.z = output phase)."""
+    ops = _ops()
+    rng = np.random.default_rng(8)
+    n, h, cin, cout = 2, 16, 64, 128
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    dy = rng.standard_normal((n, h // 2, h // 2, cout))
+    xt = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(_rnd(w, dt)), 2), xt, nchw(_rnd(dy, dt)))
+    adt = BF if dt == "bf16" else torch.float32
+    dx = torch.full((n, h, h, cin), 7.0, device="cuda", dtype=adt)
+    ops.set_tuning("tapgemm.variant", variant)
+    ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), dx, None, cin, cin, 0, n, h, h, cin, cout, 3, 2)
+    assert ops.last_kernel() == _sym(variant, dt)
+    assert rel_l2(host(dx.float()), nhwc(ref)) < TOL[dt]
+    # Conv2DTranspose(3x3, s2) + bias + LeakyReLU
+    hi, ci, co = 8, 64, 96
+    x = rng.standard_normal((n, hi, hi, ci))
+    wt = rng.standard_normal((3, 3, co, ci)) * 0.1
+    b = rng.standard_normal(co)
+    r = nhwc(st.conv2d_transpose_same(nchw(_rnd(x, dt)), t64(_rnd(wt, dt)))) + b
+    r = np.where(r > 0, r, 0.2 * r)
+    y = torch.empty((n, 2 * hi, 2 * hi, co), device="cuda", dtype=adt)
+    ops.conv2d_transpose_fwd(_dev(x, dt), ci, _dev(wt, dt), torch.from_numpy(b.astype(np.float32)).cuda(), y, co, n, hi, hi, ci, co, 0.2)
+    assert ops.last_kernel() == _sym(variant, dt)
+    assert rel_l2(host(y.float()), r) < TOL[dt]
+
+
+# ---- weight gradient: generic / halo / thin-input kernels on the same shapes
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("wv,expect", [(0, None), (1, "wgrad_"), (2, "wgrad_halo")])
+@pytest.mark.parametrize("n,h,cin,cout,blocks", [(2, 32, 64, 64, 0), (3, 16, 10, 64, 0), (2, 32, 128, 192, 64), (4, 16, 64, 128, 7)])
+def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    pitch = 32 if dt == "bf16" else 16
+    ld = (cin + pitch - 1) // pitch * pitch
+    x = np.zeros((n, h, h, ld))
+    x[..., :cin] = rng.standard_normal((n, h, h, cin))
+    dy = rng.standard_normal((n, h, h, cout))
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(_rnd(x[..., :cin], dt)), wt, 1), wt, nchw(_rnd(dy, dt)))
+    ops.set_tuning("wgrad.variant", wv)
+    ops.set_tuning("wgrad.blocks", blocks)
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 1024, device="cuda")
+    dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+    ops.conv2d_wgrad(_dev(x, dt), None, 0, ld, 0, _dev(dy, dt), cout, dw, n, h, h, cin, ld, cout, 3, 1, 0, ws)
+    k = ops.last_kernel()
+    if wv == 1:
+        assert k.startswith("wgrad_kernel<") or k.startswith("wgrad_bf16_kernel<"), k
+    elif wv == 2:
+        assert k in ("wgrad_halo_kernel", "wgrad_halo_bf16_kernel"), k
+    assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
+
+
+# ======================================================================================================
+# Real layer shapes of BASELINE configs[1] (S=256, F=64, B=8) through the DEFAULT dispatch.  The float64
+# reference convolutions take a few seconds each on the GPU box's host cores.
+# ======================================================================================================
+def test_default_dispatch_fp32_halo128_on_a_generator_layer():
+    """Generator conv2d_5 (128 -> 128 at 128 x 128).  At the G(1) batch n = 8 the grid is 512 halo blocks / 1024 DMA tiles:
+    below the halo threshold, so the 128x128 DMA tile takes it; n = 16 reaches the halo kernel; n = 4 the 64x128 tile."""
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    h, cin, cout = 128, 128, 128
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.05
+    b = rng.standard_normal(cout) * 0.1
+    wk = _wk(w, cin, "f32")
+    for n, sym in ((4, "dma64x128"), (8, "dma128x128"), (16, "halo128")):
+        x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+        ref = conv_ref(x, w.astype(np.float32), 1) + b
+        ref = np.where(ref > 0, ref, 0.2 * ref)
+        y = torch.empty((n, h, h, cout), device="cuda")
+        stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+        ops.conv2d_in_fwd(_dev(x, "f32"), None, 0, cin, 0, wk, torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout,
+                          3, 1, 0.2, stats, 1e-6, scratch=scr)
+        assert ops.last_kernel() == _sym(sym, "f32"), ops.last_kernel()
+        got = host(y)
+        assert rel_l2(got, ref) < 1e-5
+        _check_stats(stats, got, n, cout, "f32")
+
+
+def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
+    """dgrad of generator conv2d_24's skip half at full resolution (n = 8, 256 x 256, 64 <- 64 ... the 128-channel concat
+    gradient: nout = 128 -> halo 128) and a discriminator block (64 -> 128, stride 2, n = 32: 1024 tiles -> DMA 128x128)."""
+    ops = _ops()
+    rng = np.random.default_rng(22)
+    n, h, cin, cout = 8, 256, 128, 64
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+    dy = rng.standard_normal((n, h, h, cout)).astype(np.float32)
+    xt = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(w), 1), xt, nchw(dy))
+    d1 = torch.empty((n, h, h, 64), device="cuda")
+    d2 = torch.empty((n, h, h, 64), device="cuda")
+    ops.conv2d_dgrad(_dev(dy, "f32"), cout, _dev(w, "f32"), d1, d2, 64, 64, 64, n, h, h, cin, cout, 3, 1)
+    assert ops.last_kernel() == _sym("halo128", "f32"), ops.last_kernel()
+    ref = nhwc(ref.detach())
+    assert rel_l2(host(d1), ref[..., :64]) < 1e-5 and rel_l2(host(d2), ref[..., 64:]) < 1e-5
+    del ref, xt
+    n, h, cin, cout = 32, 128, 64, 128
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+    ref = conv_ref(x, w, 2)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    y = torch.empty((n, h // 2, h // 2, cout), device="cuda")
+    ops.conv2d_fwd(_dev(x, "f32"), None, 0, cin, 0, _wk(w, cin, "f32"), None, y, cout, n, h, h, cin, cout, 3, 2, 0.2)
+    assert ops.last_kernel() == _sym("dma128x128", "f32"), ops.last_kernel()
+    assert rel_l2(host(y), ref) < 1e-5
+
+
+def test_default_dispatch_fp32_cout64_at_256():
+    """The headline block: 64 -> 64 at 256 x 256, n = 8 (fp32 default = DMA 128x64 tile)."""
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    n, h, c = 8, 256, 64
+    x = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, c, c)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    ref = conv_ref(x, w, 1) + b
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    y = torch.empty((n, h, h, c), device="cuda")
+    stats = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
+    ops.conv2d_in_fwd(_dev(x, "f32"), None, 0, c, 0, _wk(w, c, "f32"), torch.from_numpy(b).cuda(), y, c, n, h, h, c, c, 3, 1, 0.2, stats,
+                      1e-6, scratch=scr)
+    assert ops.last_kernel() == _sym("dma128x64", "f32"), ops.last_kernel()
+    got = host(y)
+    assert rel_l2(got, ref) < 1e-5
+    _check_stats(stats, got, n, c, "f32")
