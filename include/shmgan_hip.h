@@ -82,6 +82,7 @@ const char* shm_last_kernel(void);
 #define SHM_TG_HALO128_PH8 8
 #define SHM_TG_DMA_128x128_BK32 9
 #define SHM_TG_DMA_128x128_NST4 10
+#define SHM_TG_WREG 11                 /* bf16, 3x3 s1, <= 64 input channels: weights in registers, persistent blocks */
 int shm_set_tuning(const char* key, int value);
 int shm_get_tuning(const char* key, int* value);
 

@@ -45,6 +45,7 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
     int is, os;         // A stride, output stride
     int M;              // batch*hg*wg
     unsigned xbytes, x2bytes, wbytes;   // buffer-descriptor extents (bytes)
+    unsigned ybytes, y2bytes;           // output extents, 0 when an output is larger than 4 GiB (kernels with buffer stores are then not eligible)
     double* stats;      // optional [slot][batch][nout][2] (sum, sum of squares) of the stored outputs
     int hw;             // pixels per sample (stats only; hw % 64 == 0)
     int stats_slots;    // slot copies: wave tile t of a sample adds into slot t % stats_slots
@@ -623,6 +624,223 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 3x3 / stride-1 tap GEMM for K <= 64 input channels with the WEIGHTS IN REGISTERS (persistent blocks).
+//
+// The 64-channel 256 x 256 layers are the HBM-side layers of the bf16 step (3 FLOP per byte and tap): in
+// tapgemm_halo_kernel a block lives for 18 K-steps between a 2-3 us halo prologue and its store epilogue, with a
+// barrier and a weight DMA per tap.  Here the whole weight tensor of a 32-column slice -- 9 taps x K <= 64
+// channels = 144 VGPRs per lane -- is loaded ONCE per block and kept in registers; a block (4 waves: 2 (M) x 2 (N),
+// wave tile 64 pixels x 32 channels) then walks a contiguous range of 8 x 16-pixel patches:
+//   * the 10 x 18 halo of patch p+1 is DMA'd into the other LDS buffer right after the barrier that opens patch p,
+//     i.e. it lands under the 72 MFMAs and the epilogue of patch p;
+//   * ONE barrier per patch (halo landed for all waves = everybody is done reading the other buffer), no weight
+//     traffic, no per-tap synchronisation: the nine taps are nine shifted fragment addresses into the halo;
+//   * epilogue as in the halo kernel (bias, LeakyReLU, bf16 rounding, LDS-staged 16-byte stores); the InstanceNorm
+//     sums are kept in registers (f64) across the patches of one image and flushed with one atomic per column when the
+//     image changes: ~40x fewer atomics.
+// Two blocks per CU (64 KB of LDS, 256 VGPRs each): they run out of step, so one block's epilogue (VALU, stores)
+// overlaps the other's MFMAs on the same SIMDs.  Same LDS row format as the other kernels (64-byte rows, chunk ^=
+// (row >> 2) & 3 applied on the DMA source side, 0xffffffff offsets -> zeros for halo pixels outside the image).
+template <typename TO, int NCH>
+__global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs a, const int npatch) {
+    typedef bf16_t T;
+    constexpr int PH = 8, HC = 18, NIT = 12;            // halo (PH + 2) x 18 = 180 rows, padded to 12 DMA items of 16 rows
+    constexpr int ASTG = NIT * 256;                     // floats per 32-channel chunk
+    constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
+    static_assert(NIT * NCH % 4 == 0, "DMA items divide over the four waves");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * ABUF + 4 * 1024];       // + 4 KB store staging per wave
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const TapPhase& P = a.ph[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.y * 64;
+    const int ppr = a.wi >> 4, ppi = (a.hi / PH) * ppr;
+
+    // contiguous patch range of this block
+    const int per = (npatch + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * per, q1 = min(npatch, q0 + per);
+    if (q0 >= q1) return;
+
+    // ---- weights -> registers: lane (l31, h) holds W[tap][n][c*32 + kk*16 + 8h .. +7] for its column n
+    const int ncol = n0 + wn * 32 + l31;
+    bf16x8 bw[9][NCH][2];
+    {
+        const bf16_t* wp = (const bf16_t*)a.w;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 v = {};
+                    if (ncol < a.nout) v = *(const bf16x8*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * 32 + kk * 16 + h * 8);
+                    bw[t][c][kk] = v;
+                }
+    }
+    const float bias = (a.bias && ncol < a.nout) ? a.bias[ncol] : 0.f;
+
+    // ---- halo DMA: item it (0 .. NIT*NCH-1) = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w+4, ...
+    // NIT / 4 = 3 items per wave and chunk: item j of chunk c covers halo rows 16 (wave + 4 j) + drow, so the lane keeps
+    // three halo row numbers and derives the rest per patch (registers are what this kernel is short of).
+    const int drow = lane >> 2, dq = lane & 3;
+    static_assert(NIT == 12, "three DMA items per wave and chunk");
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const unsigned pixb = (unsigned)a.ldx * 2u;
+    auto dma = [&](int q, int buf) {
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        float* dst = smem + buf * ABUF + wave * 256;
+        int dr = drow;
+        asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int hrow = 16 * (wave + 4 * j) + dr;
+            const int hr = hrow / HC, hc = hrow - hr * HC;
+            const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+            const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+            const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)((dq ^ ((hrow >> 2) & 3)) << 4) : 0xffffffffu;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + c * ASTG + j * 4 * 256), 16,
+                                                         (int)(v ? off + 64u * c : 0xffffffffu), 0, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing (patch independent): byte address of the centre tap's halo row for the two 32-pixel tiles
+    const int hb0 = (4 * wm + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;      // second tile: + 2 * HC
+    int tsh[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tsh[t] = P.dh[t] * HC + P.dw[t];
+
+    // statistics carried over the patches of one image (fp32 per lane: at most a few thousand bf16-rounded terms; the
+    // cross-block sums are f64 atomics)
+    float S1 = 0.f, S2 = 0.f;
+    int simg = q0 / ppi;
+    auto flush = [&](int img) {
+        const float t1 = S1 + __shfl_xor(S1, 32, 64), t2 = S2 + __shfl_xor(S2, 32, 64);
+        if (h == 0 && ncol < a.nout) {
+            double* dst = a.stats + (size_t)(blockIdx.x % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
+            atomicAdd(dst, (double)t1);
+            atomicAdd(dst + 1, (double)t2);
+        }
+        S1 = S2 = 0.f;
+    };
+
+    unsigned short* const tile = (unsigned short*)(smem + 2 * ABUF) + wave * 2048;      // 64 rows x 32 bf16
+    // 16-byte stores need 2-byte outputs, aligned pitches and -- so that every epilogue issues the same number of store
+    // instructions, which the counted wait below relies on -- 32 valid columns in this wave
+    constexpr bool kWide = sizeof(TO) == 2;
+    const bool wide = kWide && (n0 + wn * 32 + 32 <= a.nout) && (a.n1 % 8 == 0) && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0) &&
+                      (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0)));
+
+    // outputs through buffer stores: one 32-bit offset register per store instead of a 64-bit address
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy2 = __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2bytes, 0x00020000);
+
+    dma(q0, 0);
+    for (int q = q0; q < q1; ++q) {
+        const int buf = (q - q0) & 1;
+        // halo(q) was issued one patch ago; the only younger operations of this wave are the stores of the previous
+        // epilogue (wide path: at least four 16-byte store instructions, plus the rare statistics flush), which stay in flight
+        if (wide && q != q0)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave; everyone is done with the other buffer
+        asm volatile("" ::: "memory");
+        if (q + 1 < q1) dma(q + 1, buf ^ 1);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float* Ab = smem + buf * ABUF;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hrow = hb0 + 2 * HC * i + tsh[t];
+                fa[i] = hrow * 16 + ((h ^ ((hrow >> 2) & 3)) << 2);          // floats; the kk = 1 group is this address ^ 8
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 av = *(const f32x4*)(Ab + c * ASTG + (fa[i] ^ (kk << 3)));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[t][c][kk], acc[i], 0, 0, 0);
+                    }
+        }
+
+        // ---- epilogue of patch q
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        if (a.stats && img != simg) {
+            flush(simg);
+            simg = img;
+        }
+        float s1 = 0.f, s2 = 0.f;
+        if (wide) {
+            // the wave's 64 x 32 tile through LDS (64-byte rows; a 16-lane group of the 16-byte reads below covers four
+            // whole rows = all 64 banks once)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bf16_t vo = (bf16_t)shm_lrelu(acc[i][r] + bias, a.slope);
+                    const float v = (float)vo;
+                    s1 += v;
+                    s2 += v * v;
+                    tile[row * 32 + l31] = __builtin_bit_cast(unsigned short, vo);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
+            const int rr = lane >> 2, ch = lane & 3;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + rr;
+                const u32x4 v = *(const u32x4*)(tile + row * 32 + (ch << 3));
+                const int py = 4 * wm + (row >> 4), px = row & 15;
+                const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
+                const int n = n0 + wn * 32 + ch * 8;
+                if (n < a.n1)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy, (opix * (unsigned)a.ldy + (unsigned)n) * 2u, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(n - a.n1)) * 2u, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 4 * wm + (row >> 4), px = row & 15;
+                    const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
+                    if (ncol < a.nout) {
+                        const TO vo = (TO)shm_lrelu(acc[i][r] + bias, a.slope);
+                        const float v = (float)vo;
+                        s1 += v;
+                        s2 += v * v;
+                        if (ncol < a.n1)
+                            ((TO*)a.y)[opix * a.ldy + ncol] = vo;
+                        else
+                            ((TO*)a.y2)[opix * a.ldy2 + (ncol - a.n1)] = vo;
+                    }
+                }
+        }
+        S1 += s1;
+        S2 += s2;
+    }
+    if (a.stats) flush(simg);
+}
+
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
@@ -640,6 +858,8 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         for (int t = 0; t < 9; ++t)             // every tap within the 1-pixel halo
             halo_ok = halo_ok && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
     const bool bk32_ok = a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0);
+    // weights-in-registers kernel: bf16, one source tensor with 32 or 64 channels
+    const bool wreg_ok = sizeof(T) == 2 && halo_ok && a.x2 == nullptr && (a.K == 32 || a.K == 64) && a.ybytes != 0 && (a.y2 == nullptr || a.y2bytes != 0);
     int v = forced;
     if (v == SHM_TG_AUTO) {
         // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
@@ -647,7 +867,9 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
         const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
         const long tiles128 = (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase;
-        if (halo_ok && a.nout <= 64 && sizeof(T) == 2)
+        if (wreg_ok)
+            v = SHM_TG_WREG;
+        else if (halo_ok && a.nout <= 64 && sizeof(T) == 2)
             v = SHM_TG_HALO64;                  // fp32: the 4-wave 64-channel halo block measures like the 128x64 DMA tile
         else if (halo_ok && a.nout > 64 && (sizeof(T) == 2 || nblk >= shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)))
             v = SHM_TG_HALO128;
@@ -680,6 +902,20 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 8>), dim3(batch * (a.hi / 8) * (a.wi / 16), shm_cdiv(a.nout, 128), 1), dim3(256), 0, st, a);
             shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
+        }
+        break;
+    case SHM_TG_WREG:
+        SHM_REQUIRE(wreg_ok, SHM_E_SHAPE, "%s: forced variant wreg is bf16, unit-stride 3x3, map multiple of 16, 32 or 64 input channels from one tensor", who);
+        if constexpr (sizeof(T) == 2) {
+            const int np8 = batch * (a.hi / 8) * (a.wi / 16), ny = shm_cdiv(a.nout, 64);
+            int gx = 512 / ny;                 // two 4-wave blocks per CU (LDS, VGPRs)
+            if (gx < 1) gx = 1;
+            if (gx > np8) gx = np8;
+            if (a.K == 64)
+                hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+            else
+                hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+            shm_set_last_kernel("tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
         }
         break;
     case SHM_TG_DMA_128x128:
@@ -745,6 +981,10 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
         a.xbytes = (unsigned)xb;
         a.x2bytes = (unsigned)x2b;
         a.wbytes = (unsigned)wb;
+        const int oesz = dtype == SHM_BF16 ? 2 : 4;
+        const size_t yb = (size_t)batch * a.ho * a.wo * a.ldy * oesz, y2b = a.y2 ? (size_t)batch * a.ho * a.wo * a.ldy2 * oesz : 0;
+        a.ybytes = yb < lim ? (unsigned)yb : 0u;
+        a.y2bytes = y2b < lim ? (unsigned)y2b : 0u;
     }
     int rc;
     if (dtype == SHM_BF16)

@@ -259,10 +259,43 @@ def test_golden_fixture_on_device(name):
             assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
     assert np.abs(host(m.gen_Y) - gold["gen_Y"]).max() < 1e-4
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
-    _check_grad_fixture(m, gold)
+    # un-pinned LeakyReLU kinks: 4 M pre-activations per 64-channel layer put a few elements of EVERY layer on the other side
+    # of zero, so the typical tensor sits at ~1.5e-3 here (measured) instead of the 3e-6 of a pinned comparison --
+    # test_train_step_parity_full_size below pins them and holds every tensor to 1e-3
+    _check_grad_fixture(m, gold, med_tol=5e-3)
 
 
-def _check_grad_fixture(m, gold):
+def test_train_step_parity_full_size():
+    """The whole step at BASELINE's layer widths and image size (S=256, F=64, B=1) against the float64 oracle evaluated
+    on the GPU box's host cores (~1 min, ~12 GB), with the device's LeakyReLU sign pattern pinned as in
+    test_train_step_parity: named losses 1e-4, gen_Y 1e-4, every weight-gradient tensor rel-L2 <= 1e-3 and cosine >= 0.9999."""
+    S, F, B, step = 256, 64, 1, 0
+    m, (g, d, gb, db) = _mk(S, F, B)
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(step, B, S, F)
+    sf = st.style_factor_intended(S)
+    m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
+    torch.cuda.synchronize()
+    masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    ref = st.train_step(g, d, gb, db, inp, dr, sf, F, masks=masks)
+    got = m.losses()
+    for k, v in ref["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    assert np.abs(host(m.gen_Y) - ref["outs"]["gen_Y"].numpy()).max() < 1e-4
+    worst = 0.0
+    for name, P, rg in (("D", m.D.P, ref["gD"]), ("G", m.G.P, ref["gG"])):
+        for i, (got_g, r) in enumerate(zip(P.grads, rg)):
+            r = r.numpy()
+            if np.linalg.norm(r) < 1e-12:
+                continue
+            e = rel_l2(host(got_g), r)
+            worst = max(worst, e)
+            assert e < 1e-3 and cosine(host(got_g), r) > 0.9999, (name, i, e)
+    print("full-size parity: worst per-tensor rel-L2", worst)
+
+
+def _check_grad_fixture(m, gold, med_tol=1e-3):
     """Per-tensor gradient norms and fixed random projections of the fixture (oracle/make_golden.py: one
     default_rng(99) stream over the G tensors, then the D tensors).  A LeakyReLU kink event (see
     test_train_step_parity: the fixture cannot pin the device's sign pattern) can move one layer by ~1e-2, so the
@@ -273,12 +306,12 @@ def _check_grad_fixture(m, gold):
         ref = gold[f"{nm}/norm"]
         ok = ref > 1e-12
         assert np.abs(n[ok] / ref[ok] - 1).max() < 5e-2, (nm, np.abs(n[ok] / ref[ok] - 1).max())
-        assert np.median(np.abs(n[ok] / ref[ok] - 1)) < 1e-3
+        assert np.median(np.abs(n[ok] / ref[ok] - 1)) < med_tol
         proj = np.array([float((t.detach().reshape(-1).double().cpu() * torch.from_numpy(rng.standard_normal(t.numel()))).sum())
                          for t in P.grads])
         err = np.abs(proj - gold[f"{nm}/proj"])[ok] / ref[ok]          # |<g - g_ref, r>| / |g_ref| ~ rel-L2 error
         assert err.max() < 5e-2, (nm, err.max(), int(err.argmax()))
-        assert np.median(err) < 1e-3, (nm, np.median(err))
+        assert np.median(err) < med_tol, (nm, np.median(err))
 
 
 @pytest.mark.parametrize("name", ["step_S256_F64_B1.npz", "step_S256_F64_B8.npz"])
@@ -305,7 +338,40 @@ def test_golden_fixture_full_size(name):
     assert np.abs((gy.reshape(B, -1) ** 2).sum(1) / gold["gen_Y_sq"] - 1).max() < 1e-5
     assert np.abs(host(m.specular_candidate)[:, ::sub, ::sub] - gold["specular_candidate_sub"]).max() < 1e-5
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
-    _check_grad_fixture(m, gold)
+    # un-pinned LeakyReLU kinks: 4 M pre-activations per 64-channel layer put a few elements of EVERY layer on the other side
+    # of zero, so the typical tensor sits at ~1.5e-3 here (measured) instead of the 3e-6 of a pinned comparison --
+    # test_train_step_parity_full_size below pins them and holds every tensor to 1e-3
+    _check_grad_fixture(m, gold, med_tol=5e-3)
+
+
+def test_train_step_parity_full_size():
+    """The whole step at BASELINE's layer widths and image size (S=256, F=64, B=1) against the float64 oracle evaluated
+    on the GPU box's host cores (~1 min, ~12 GB), with the device's LeakyReLU sign pattern pinned as in
+    test_train_step_parity: named losses 1e-4, gen_Y 1e-4, every weight-gradient tensor rel-L2 <= 1e-3 and cosine >= 0.9999."""
+    S, F, B, step = 256, 64, 1, 0
+    m, (g, d, gb, db) = _mk(S, F, B)
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(step, B, S, F)
+    sf = st.style_factor_intended(S)
+    m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
+    torch.cuda.synchronize()
+    masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    ref = st.train_step(g, d, gb, db, inp, dr, sf, F, masks=masks)
+    got = m.losses()
+    for k, v in ref["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    assert np.abs(host(m.gen_Y) - ref["outs"]["gen_Y"].numpy()).max() < 1e-4
+    worst = 0.0
+    for name, P, rg in (("D", m.D.P, ref["gD"]), ("G", m.G.P, ref["gG"])):
+        for i, (got_g, r) in enumerate(zip(P.grads, rg)):
+            r = r.numpy()
+            if np.linalg.norm(r) < 1e-12:
+                continue
+            e = rel_l2(host(got_g), r)
+            worst = max(worst, e)
+            assert e < 1e-3 and cosine(host(got_g), r) > 0.9999, (name, i, e)
+    print("full-size parity: worst per-tensor rel-L2", worst)
 
 
 def test_inference_path_matches_oracle(tmp_path):

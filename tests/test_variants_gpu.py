@@ -28,6 +28,7 @@ SYMBOL = {
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
+    "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
 }
 HALO = ["halo128", "halo64"]
 DMA = ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
@@ -44,8 +45,8 @@ def _reset_tuning():
     _ops().set_tuning("reset", 0)
 
 
-def _sym(variant, dt):
-    return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16")
+def _sym(variant, dt, nch=2):
+    return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch)
 
 
 def _dev(a, dt):
@@ -96,7 +97,7 @@ def _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=0):
     ops.conv2d_in_fwd(_dev(xa, dt), None if xb is None else _dev(xb, dt), c1 if c2 else 0, c1, c2, _wk(w, cin, dt),
                       torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout, k, s, 0.2, stats, 1e-6, scratch=scr)
     torch.cuda.synchronize()
-    assert ops.last_kernel() == _sym(variant, dt), ops.last_kernel()
+    assert ops.last_kernel() == _sym(variant, dt, cin // 32), ops.last_kernel()
     got = host(y.float())
     assert rel_l2(got, ref) < TOL[dt], (variant, dt, rel_l2(got, ref))
     if (ho * ho) % 64 == 0:                   # the fused path (smaller maps take a separate statistics pass)
@@ -115,6 +116,35 @@ def _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=0):
 ])
 def test_conv3x3_s1_forced_variant(variant, dt, n, h, c1, c2, cout):
     _fwd_case(variant, dt, n, h, c1, c2, cout, 3, 1)
+
+
+# ---- weights-in-registers kernel (bf16, <= 64 input channels from one tensor): persistent blocks over 8 x 16 patches
+@pytest.mark.parametrize("n,h,cin,cout", [
+    (3, 16, 64, 64),        # 6 patches per image
+    (2, 32, 64, 160),       # three N tiles, the last with one whole and one empty 32-column wave
+    (5, 16, 32, 48),        # K = 32 (the generator's first layer pitch), a 16-column wave (element stores)
+    (1, 64, 64, 64),        # 32 patches in one image: several patches per block when the grid is capped
+    (7, 48, 64, 32),        # 126 patches over 7 images: blocks that cross image boundaries (statistics flush)
+])
+def test_wreg_forced_variant(n, h, cin, cout):
+    _fwd_case("wreg", "bf16", n, h, cin, 0, cout, 3, 1, seed=3)
+
+
+def test_wreg_many_patches_per_block_and_refusals():
+    """n = 24 at 128 x 128 is 3072 patches on 512 blocks: six patches per block, most blocks inside one image, some across
+    two.  fp32 tensors and concatenated inputs are refused."""
+    from shmgan_amd._lib import ShmError
+    ops = _ops()
+    _fwd_case("wreg", "bf16", 24, 128, 64, 0, 64, 3, 1, seed=4)
+    ops.set_tuning("tapgemm.variant", "wreg")
+    x = torch.zeros((1, 16, 16, 64), device="cuda")
+    w = torch.zeros(9 * 64 * 64, device="cuda")
+    with pytest.raises(ShmError):
+        ops.conv2d_fwd(x, None, 0, 64, 0, w, None, x, 64, 1, 16, 16, 64, 64, 3, 1, 1.0)
+    xb = x.to(BF)
+    wb = torch.zeros(9 * 64 * 128, device="cuda", dtype=BF)
+    with pytest.raises(ShmError):             # two sources
+        ops.conv2d_fwd(xb, xb, 64, 64, 64, wb, None, xb, 64, 1, 16, 16, 128, 64, 3, 1, 1.0)
 
 
 @pytest.mark.parametrize("variant", HALO)
@@ -154,8 +184,10 @@ def test_dma_forced_variant_other_shapes(variant, dt, n, h, c1, c2, cout, k, s):
 
 # ---- input gradient (flipped taps / four stride-2 phases, split destination) under forced variants
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128"])
+@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "wreg"])
 def test_dgrad_s1_forced_variant(variant, dt):
+    if variant == "wreg" and dt == "f32":
+        pytest.skip("bf16 only")
     ops = _ops()
     rng = np.random.default_rng(7)
     n, h, c1, c2, cout = 2, 16, 64, 32, 64              # dx split into (upsampled, skip) parts: n1 = 64
@@ -171,6 +203,12 @@ def test_dgrad_s1_forced_variant(variant, dt):
     ops.set_tuning("tapgemm.variant", variant)
     ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), d1, d2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
     assert ops.last_kernel() == _sym(variant, dt)
+    if variant == "wreg":                     # the same product with the gradient signal leaving in fp32 (SHM_BF16_GF32)
+        f1 = torch.full((n, h, h, c1), 7.0, device="cuda")
+        f2 = torch.full((n, h, h, c2), 7.0, device="cuda")
+        ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), f1, f2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
+        assert ops.last_kernel() == "tapgemm_wreg_kernel<float, 2>"
+        assert rel_l2(host(f1), ref[..., :c1]) < 1e-4 and rel_l2(host(f2), ref[..., c1:]) < 1e-4
     assert rel_l2(host(d1.float()), ref[..., :c1]) < TOL[dt] and rel_l2(host(d2.float()), ref[..., c1:]) < TOL[dt]
 
 
