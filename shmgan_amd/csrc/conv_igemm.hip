@@ -887,6 +887,165 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     if (a.stats) flush(simg);
 }
 
+// ------------------------------------------------------------------------------------------
+// The fp32 counterpart of tapgemm_wreg_kernel: 3x3 / stride-1 tap GEMM for K <= 64 input channels with the weights in
+// registers, on v_mfma_f32_16x16x4_f32 (exact fp32, the same 64 FLOP/clk/SIMD as the 32x32x2 form).
+//
+// With 16-column MFMA tiles a wave's slice of the weight tensor is 9 taps x 64 channels x 16 columns = 144 VGPRs; one block
+// per CU (8 waves: 2 (M) x 4 (N), wave tile 64 pixels x 16 channels, 8 x 16-pixel patches) keeps it for its whole range of
+// patches.  A K step (one tap, 16 channels) is four 16-byte fragment reads and sixteen MFMAs per wave, there is no weight
+// traffic and ONE barrier per patch (576 MFMAs = 18 432 MFMA cycles per wave): the per-K-step barrier / DMA-issue /
+// first-ds_read bubble that holds the 128x64 DMA tile at 65-70 % of the fp32 peak on the Cout <= 64 layers does not exist.
+// Outputs are stored straight from the accumulators (lane = channel: 64-byte segments, four pixel rows per instruction);
+// InstanceNorm sums are carried in registers (f64) across the patches of an image.  LDS rows are 64 bytes (16 channels) with
+// the DMA source-side swizzle chunk' = (chunk + (R >> 1)) & 3 on the halo row R: conflict free for this instruction's lane
+// groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/halo_swizzle_check.py).
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
+    constexpr int PH = 8, HC = 18, NIT = 12;            // halo (PH + 2) x 18 = 180 rows, padded to 12 DMA items of 16 rows
+    constexpr int ASTG = NIT * 256;                     // floats per 16-channel chunk
+    constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
+    constexpr int NITEM = NIT * NCH;                    // DMA items per patch
+    constexpr int NA = (NITEM + 7) / 8;                 // per wave (the last ones may be idle)
+    extern __shared__ __attribute__((aligned(1024))) float smem[];      // two halo buffers
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const TapPhase& P = a.ph[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n0 = blockIdx.y * 64;
+    const int ppr = a.wi >> 4, ppi = (a.hi / PH) * ppr;
+
+    const int per = (npatch + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * per, q1 = min(npatch, q0 + per);
+    if (q0 >= q1) return;
+
+    // ---- weights -> registers: lane (l15, lq) holds W[tap][n][c*16 + 4 lq .. +3] for its column n; MFMA e of a K step
+    // contracts channel 4 k' + e of the chunk over k' = lane >> 4 (the same permutation on the A side)
+    const int ncol = n0 + wn * 16 + l15;
+    f32x4 bw[9][NCH];
+    {
+        const float* wp = (const float*)a.w;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) bw[t][c] = *(const f32x4*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * 16 + lq * 4);
+    }
+    const float bias = a.bias ? a.bias[ncol] : 0.f;
+
+    // ---- halo DMA: item it = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w + 8, ...
+    const int drow = lane >> 2, dq = lane & 3;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const unsigned pixb = (unsigned)a.ldx * 4u;
+    auto dma = [&](int q, int buf) {
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        float* dst = smem + buf * ABUF;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int it = wave + 8 * j;                 // wave-uniform
+            if (it < NITEM) {
+                const int c = it / NIT, ri = it - c * NIT;
+                const int hrow = 16 * ri + drow;
+                const int hr = hrow / HC, hc = hrow - hr * HC;
+                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+                const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+                // LDS chunk dq of row hrow holds channel chunk (dq - (hrow >> 1)) & 3
+                const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)(c * 64 + (((dq - (hrow >> 1)) & 3) << 4)) : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addressing: M tile m = patch row 4 wm + m, pixel = l15; halo row of the centre tap
+    const int hb0 = (4 * wm + 1) * HC + l15 + 1;
+    int tsh[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tsh[t] = P.dh[t] * HC + P.dw[t];
+
+    double S1 = 0.0, S2 = 0.0;
+    int simg = q0 / ppi;
+    auto flush = [&](int img) {
+        double t1 = S1 + __shfl_xor(S1, 16, 64), t2 = S2 + __shfl_xor(S2, 16, 64);
+        t1 += __shfl_xor(t1, 32, 64);
+        t2 += __shfl_xor(t2, 32, 64);
+        if (lane < 16) {
+            double* dst = a.stats + (size_t)((2 * blockIdx.x + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
+            atomicAdd(dst, t1);
+            atomicAdd(dst + 1, t2);
+        }
+        S1 = S2 = 0.0;
+    };
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy2 = __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2bytes, 0x00020000);
+
+    dma(q0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int q = q0; q < q1; ++q) {
+        const int buf = (q - q0) & 1;
+        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave; everyone is done with the other buffer
+        asm volatile("" ::: "memory");
+        if (q + 1 < q1) dma(q + 1, buf ^ 1);
+
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][r] = bias;
+        const float* Ab = smem + buf * ABUF;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // rows of the four M tiles are 18 halo rows apart; the swizzle term (R >> 1) grows by 9 per tile: per-tile addresses
+            int fa[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int hrow = hb0 + m * HC + tsh[t];
+                fa[m] = hrow * 16 + (((lq + (hrow >> 1)) & 3) << 2);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                f32x4 av[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = *(const f32x4*)(Ab + c * ASTG + fa[m]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][e], bw[t][c][e], acc[m], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue of patch q: accumulator register r of tile m = pixel (row 4 wm + m, column 4 lq + r), channel ncol
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        if (a.stats && img != simg) {
+            flush(simg);
+            simg = img;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc[m][r];
+                const float v = fmaxf(u, u * a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
+                s1 += v;
+                s2 += v * v;
+                const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
+                if (ncol < a.n1)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(ncol - a.n1)) * 4u, 0, 0);
+            }
+        S1 += (double)s1;
+        S2 += (double)s2;
+        // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+    if (a.stats) flush(simg);
+}
+
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
@@ -909,6 +1068,9 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                          a.slope >= 0.f && a.slope <= 1.f &&
                          (sizeof(TO) == 4 || (a.nout % 64 == 0 && a.n1 % 32 == 0 && a.ldy % 8 == 0 && ((size_t)a.y & 15) == 0 &&
                                               (a.y2 == nullptr || (a.ldy2 % 8 == 0 && ((size_t)a.y2 & 15) == 0))));
+    // ... and its fp32 form: 16 or 64 input channels
+    const bool wreg32_ok = sizeof(T) == 4 && sizeof(TO) == 4 && halo_ok && a.x2 == nullptr && (a.K == 16 || a.K == 64) && a.ybytes != 0 &&
+                           (a.y2 == nullptr || a.y2bytes != 0) && a.slope >= 0.f && a.slope <= 1.f && a.nout % 64 == 0 && a.n1 % 16 == 0;
     int v = forced;
     if (v == SHM_TG_AUTO) {
         // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
@@ -916,7 +1078,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
         const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
         const long tiles128 = (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase;
-        if (wreg_ok)
+        if (wreg_ok || wreg32_ok)
             v = SHM_TG_WREG;
         else if (halo_ok && a.nout <= 64 && sizeof(T) == 2)
             v = SHM_TG_HALO64;                  // fp32: the 4-wave 64-channel halo block measures like the 128x64 DMA tile
@@ -953,12 +1115,18 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
         }
         break;
-    case SHM_TG_WREG:
-        SHM_REQUIRE(wreg_ok, SHM_E_SHAPE,
-                    "%s: forced variant wreg is bf16, unit-stride 3x3, map multiple of 16, 32 or 64 input channels from one tensor, Cout %% 64 == 0, slope in [0,1]", who);
+    case SHM_TG_WREG: {
+        SHM_REQUIRE(wreg_ok || wreg32_ok, SHM_E_SHAPE,
+                    "%s: forced variant wreg needs a unit-stride 3x3 layer on a map that is a multiple of 16, one source tensor with 32/64 (bf16) or "
+                    "16/64 (fp32) channels, Cout %% 64 == 0, slope in [0,1]", who);
+        static const int ncu = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        const int np8 = batch * (a.hi / 8) * (a.wi / 16), ny = shm_cdiv(a.nout, 64);
         if constexpr (sizeof(T) == 2) {
-            const int np8 = batch * (a.hi / 8) * (a.wi / 16), ny = shm_cdiv(a.nout, 64);
-            int gx = 512 / ny;                 // two 4-wave blocks per CU (LDS, VGPRs)
+            int gx = 2 * ncu / ny;             // two 4-wave blocks per CU (LDS, VGPRs)
             if (gx < 1) gx = 1;
             if (gx > np8) gx = np8;
             if (a.K == 64)
@@ -966,8 +1134,21 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             else
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             shm_set_last_kernel("tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
+        } else if constexpr (sizeof(TO) == 4) {
+            int gx = ncu / ny;                 // one 8-wave block per CU
+            if (gx < 1) gx = 1;
+            if (gx > np8) gx = np8;
+            if (a.K == 64) {
+                static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+                SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve 96 KiB of LDS: %s", who, hipGetErrorString(attr));
+                hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<4>), dim3(gx, ny, 1), dim3(512), 98304, st, a, np8);
+            } else {
+                hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<1>), dim3(gx, ny, 1), dim3(512), 24576, st, a, np8);
+            }
+            shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d>", a.K / 16);
         }
         break;
+    }
     case SHM_TG_DMA_128x128:
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 128, 2, 2, 3, 16>), grid1d(128, 128), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 128, 2, 2, 3, 16>", tn, ton);

@@ -217,11 +217,28 @@ class Generator(_ModelBase):
         self.weights_dirty = True
         self.ctx = {}
         self.debug = None
+        self._on_wgrad = None
 
     # -- parameter plumbing ---------------------------------------------------------------
     def set_betas(self, arrays):
         for b, a in zip(self.betas, arrays):
             b.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+
+    def grad_buckets(self):
+        """Data-parallel exchange plan of the flat gradient: [(trigger_layer, [(lo, hi), ...]), ...] in the order the
+        backward pass completes them.  The kernels are stored in layer order, and a backward pass finishes the layers
+        last to first, so a bucket = the kernels of a run of layers, ready as soon as the weight gradient of its LOWEST
+        layer has been issued (`trigger_layer`); the last entry (trigger None) is what only the end of the pass completes:
+        the first encoder layers plus the f64-accumulated region (head kernel, every bias).  Stage cuts: decoder top
+        (3.7 MB at F=64), decoder bottom (49.6 MB), encoder bottom + 1x1 bottleneck (19.8 MB), the rest (1.1 MB)."""
+        off = [self.P.offsets[2 * i] for i in range(len(self.layers))]
+        cuts = [16, 10, 4]                                   # lowest layer of each early bucket
+        out, hi = [], self.acc_off
+        for c in cuts:
+            out.append((c, [(off[c], hi)]))
+            hi = off[c]
+        out.append((None, [(0, hi), (self.acc_off, self.P.n)]))
+        return out
 
     def _acc_slice(self, var_index):
         o = self.P.offsets[var_index] - self.acc_off
@@ -333,13 +350,17 @@ class Generator(_ModelBase):
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
         self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
                                                   self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
+        if self._on_wgrad is not None:
+            self._on_wgrad(li)
         if need_dx:
             lddx = rec["ldx"]
             ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
         return dz
 
-    def backward(self, dy, tag, need_dx=False):
+    def backward(self, dy, tag, need_dx=False, on_wgrad=None):
         """dy: gradient wrt gen_Y [N,S,S,1].  Accumulates into the flat gradient (+ f64 region).
+        on_wgrad(li): called right after the weight gradient of layer li has been issued on the wgrad lane (the
+        data-parallel trainer launches the gradient bucket that layer completes).
         need_dx=True: returns the gradient wrt the padded input (channels 0..9 valid).
         need_dx="dz": returns the first layer's pre-activation gradient dz [N,S,S,F] instead -- the caller only
         needs channel sums of the input gradient and forms them with ops.conv3x3_dgrad_sum1 (no 64->10 dgrad)."""
@@ -348,6 +369,13 @@ class Generator(_ModelBase):
         A = self.arena
         S, F = self.S, self.F
         nl = len(self.layers)
+        self._on_wgrad = on_wgrad
+        try:
+            return self._backward(dy, c, n, recs, ups, A, S, F, nl, tag, need_dx)
+        finally:
+            self._on_wgrad = None
+
+    def _backward(self, dy, c, n, recs, ups, A, S, F, nl, tag, need_dx):
         # head
         hx = c["head_x"]
         dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F), self.gdt)
@@ -380,6 +408,8 @@ class Generator(_ModelBase):
             ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, tcout, tcin, 3))
             self.lane.submit(lambda dzu=dzu, up=up, tli=tli, tcout=tcout, tcin=tcin, h=h, ws=ws: ops.conv2d_wgrad(
                 dzu, None, 0, tcout, 0, up["x"], up["ldx"], self.P.grads[2 * tli], n, h, h, tcout, tcout, tcin, 3, 2, 1, ws))
+            if self._on_wgrad is not None:
+                self._on_wgrad(tli)
             hin = up["h"]
             dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin), self.gdt)
             ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0)

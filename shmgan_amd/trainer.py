@@ -314,13 +314,28 @@ class ShmGANwithSSpecSeg:
         for k in range(5):                                       # G o G chain  SHM.py:576-580
             ops.sum_input_channels(G.P.vars[0], 10, F, sum(1 << j for j in range(5) if j != k and flags[j]), weff_g[k])
         ops.conv3x3_dgrad_sum1(dzg, F, weff_g, dgen_y, 5, B, S, S, F, 1, 1)
-        G.backward(dgen_y, "g1", need_dx=False)
-        G.finish_grads()
-        self._get_lane().join()                 # all weight gradients (both models) are complete
         update_g = self.epoch >= self.train_G_after
         # no collective for a gradient nobody applies (it would also still be in flight when the next step
         # zeroes the bucket)
-        ev_g = self._allreduce_async(G.P.grad) if (update_g or not apply) else None
+        reduce_g = world > 1 and (update_g or not apply)
+        # The G(1) backward is the last pass that touches the generator's weight gradients, and it finishes the layers last
+        # to first: each stage's slice of the flat gradient is all-reduced as soon as the weight gradient of its lowest
+        # layer has been issued on the wgrad lane (the collective waits for that lane event on the reducer stream), under
+        # the rest of the pass.  Only the small last bucket (first encoder layers + head kernel + biases) is exposed.
+        ev_g = None
+        on_wgrad = None
+        if reduce_g:
+            plan = {trig: slices for trig, slices in G.grad_buckets()}
+
+            def on_wgrad(li):
+                for lo, hi in plan.get(li, ()):
+                    self._allreduce_async(G.P.grad[lo:hi], after=lane.event())
+        G.backward(dgen_y, "g1", need_dx=False, on_wgrad=on_wgrad)
+        G.finish_grads()
+        lane.join()                             # all weight gradients (both models) are complete
+        if reduce_g:
+            for lo, hi in plan[None]:
+                ev_g = self._allreduce_async(G.P.grad[lo:hi])        # the reducer stream runs its collectives in order
 
         # ---- clip + Adam  SHM.py:859-872
         if apply:

@@ -85,3 +85,26 @@ def test_tuning_keys_roundtrip_without_gpu():
     for key, dflt in ((b"tapgemm.halo_min_blocks", 1024), (b"tapgemm.small_grid_blocks", 1024), (b"wgrad.variant", 0),
                       (b"wgrad.blocks", 0), (b"stats.fusion", 1)):
         assert L.shm_get_tuning(key, C.addressof(v)) == 0 and v.value == dflt, key
+
+
+def test_generator_gradient_buckets_partition_the_flat_buffer():
+    """The data-parallel bucket plan (G gradients in reverse-layer buckets) covers every element of the flat
+    gradient exactly once, and every bucket's trigger layer is the lowest layer stored in it."""
+    import torch
+    from shmgan_amd.model import Arena, Generator
+    dev = torch.device("cpu")
+    for F in (16, 64):
+        g = Generator(64, F, dev, Arena(dev), lambda n: None)
+        plan = g.grad_buckets()
+        seen = torch.zeros(g.P.n, dtype=torch.int32)
+        for trig, slices in plan:
+            for lo, hi in slices:
+                assert 0 <= lo < hi <= g.P.n
+                seen[lo:hi] += 1
+            if trig is not None:
+                assert slices[0][0] == g.P.offsets[2 * trig]
+        assert int(seen.min()) == 1 and int(seen.max()) == 1
+        assert [t for t, _ in plan] == [16, 10, 4, None]
+        if F == 64:
+            mb = [sum(hi - lo for lo, hi in sl) * 4 / 1e6 for _, sl in plan]
+            assert abs(sum(mb) - 74.1) < 0.1 and mb[1] > 45

@@ -46,6 +46,9 @@ def _reset_tuning():
 
 
 def _sym(variant, dt, nch=2):
+    if variant == "wreg" and dt == "f32":
+        return f"tapgemm_wreg_f32_kernel<{int(2 * nch)}>"          # 16-channel chunks
+    nch = int(nch)
     return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch)
 
 
@@ -97,7 +100,7 @@ def _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=0):
     ops.conv2d_in_fwd(_dev(xa, dt), None if xb is None else _dev(xb, dt), c1 if c2 else 0, c1, c2, _wk(w, cin, dt),
                       torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout, k, s, 0.2, stats, 1e-6, scratch=scr)
     torch.cuda.synchronize()
-    assert ops.last_kernel() == _sym(variant, dt, cin // 32), ops.last_kernel()
+    assert ops.last_kernel() == _sym(variant, dt, cin / 32), ops.last_kernel()
     got = host(y.float())
     assert rel_l2(got, ref) < TOL[dt], (variant, dt, rel_l2(got, ref))
     if (ho * ho) % 64 == 0:                   # the fused path (smaller maps take a separate statistics pass)
@@ -118,33 +121,42 @@ def test_conv3x3_s1_forced_variant(variant, dt, n, h, c1, c2, cout):
     _fwd_case(variant, dt, n, h, c1, c2, cout, 3, 1)
 
 
-# ---- weights-in-registers kernel (bf16, <= 64 input channels from one tensor): persistent blocks over 8 x 16 patches
+# ---- weights-in-registers kernels (<= 64 input channels from one tensor): persistent blocks over 8 x 16 patches
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("n,h,cin,cout", [
     (3, 16, 64, 64),        # 6 patches per image
     (2, 32, 64, 192),       # three N tiles
-    (5, 16, 32, 128),       # K = 32 (the generator's first-layer pitch)
+    (5, 16, 32, 128),       # the first-layer pitch: K = 32 in bf16 / 16 in fp32
     (1, 64, 64, 64),        # 32 patches in one image: several patches per block when the grid is capped
     (7, 48, 64, 64),        # 126 patches over 7 images: blocks that cross image boundaries (statistics flush)
 ])
-def test_wreg_forced_variant(n, h, cin, cout):
-    _fwd_case("wreg", "bf16", n, h, cin, 0, cout, 3, 1, seed=3)
+def test_wreg_forced_variant(dt, n, h, cin, cout):
+    if dt == "f32" and cin == 32:
+        cin = 16
+    _fwd_case("wreg", dt, n, h, cin, 0, cout, 3, 1, seed=3)
 
 
-def test_wreg_many_patches_per_block_and_refusals():
-    """n = 24 at 128 x 128 is 3072 patches on 512 blocks: six patches per block, most blocks inside one image, some across
-    two.  fp32 tensors and concatenated inputs are refused."""
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_wreg_many_patches_per_block_and_refusals(dt):
+    """n = 24 at 128 x 128 is 3072 patches on 512 (bf16) / 256 (fp32) blocks: 6 / 12 patches per block, most blocks inside
+    one image, some across two.  Channel counts the kernel has no instantiation for and concatenated inputs are refused."""
     from shmgan_amd._lib import ShmError
     ops = _ops()
-    _fwd_case("wreg", "bf16", 24, 128, 64, 0, 64, 3, 1, seed=4)
+    _fwd_case("wreg", dt, 24, 128, 64, 0, 64, 3, 1, seed=4)
     ops.set_tuning("tapgemm.variant", "wreg")
-    x = torch.zeros((1, 16, 16, 64), device="cuda")
-    w = torch.zeros(9 * 64 * 64, device="cuda")
+    adt = BF if dt == "bf16" else torch.float32
+    kbad = 96 if dt == "bf16" else 32
+    x = torch.zeros((1, 16, 16, kbad), device="cuda", dtype=adt)
+    w = torch.zeros(9 * 64 * kbad, device="cuda", dtype=adt)
+    y = torch.zeros((1, 16, 16, 64), device="cuda", dtype=adt)
     with pytest.raises(ShmError):
-        ops.conv2d_fwd(x, None, 0, 64, 0, w, None, x, 64, 1, 16, 16, 64, 64, 3, 1, 1.0)
-    xb = x.to(BF)
-    wb = torch.zeros(9 * 64 * 128, device="cuda", dtype=BF)
+        ops.conv2d_fwd(x, None, 0, kbad, 0, w, None, y, 64, 1, 16, 16, kbad, 64, 3, 1, 1.0)
+    x64 = torch.zeros((1, 16, 16, 64), device="cuda", dtype=adt)
+    wb = torch.zeros(9 * 64 * 128, device="cuda", dtype=adt)
     with pytest.raises(ShmError):             # two sources
-        ops.conv2d_fwd(xb, xb, 64, 64, 64, wb, None, xb, 64, 1, 16, 16, 128, 64, 3, 1, 1.0)
+        ops.conv2d_fwd(x64, x64, 64, 64, 64, wb, None, y, 64, 1, 16, 16, 128, 64, 3, 1, 1.0)
+    with pytest.raises(ShmError):             # Cout = 32
+        ops.conv2d_fwd(x64, None, 0, 64, 0, wb, None, y, 32, 1, 16, 16, 64, 32, 3, 1, 1.0)
 
 
 @pytest.mark.parametrize("variant", HALO)
@@ -186,8 +198,6 @@ def test_dma_forced_variant_other_shapes(variant, dt, n, h, c1, c2, cout, k, s):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "wreg"])
 def test_dgrad_s1_forced_variant(variant, dt):
-    if variant == "wreg" and dt == "f32":
-        pytest.skip("bf16 only")
     ops = _ops()
     rng = np.random.default_rng(7)
     n, h, c1, c2, cout = 2, 16, 64, 64, 64              # dx split into (upsampled, skip) parts: n1 = 64
@@ -203,7 +213,7 @@ def test_dgrad_s1_forced_variant(variant, dt):
     ops.set_tuning("tapgemm.variant", variant)
     ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), d1, d2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
     assert ops.last_kernel() == _sym(variant, dt)
-    if variant == "wreg":                     # the same product with the gradient signal leaving in fp32 (SHM_BF16_GF32)
+    if variant == "wreg" and dt == "bf16":    # the same product with the gradient signal leaving in fp32 (SHM_BF16_GF32)
         f1 = torch.full((n, h, h, c1), 7.0, device="cuda")
         f2 = torch.full((n, h, h, c2), 7.0, device="cuda")
         ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), f1, f2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
@@ -298,8 +308,9 @@ def test_default_dispatch_fp32_halo128_on_a_generator_layer():
 
 
 def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
-    """dgrad of generator conv2d_24's skip half at full resolution (n = 8, 256 x 256, 64 <- 64 ... the 128-channel concat
-    gradient: nout = 128 -> halo 128) and a discriminator block (64 -> 128, stride 2, n = 32: 1024 tiles -> DMA 128x128)."""
+    """dgrad of generator conv2d_24 at full resolution (n = 8, 256 x 256, 128 <- 64, the gradient split into its upsampled and
+    skip halves: K = 64 -> the weights-in-registers kernel, two N tiles), a 128 <- 128 dgrad at n = 16 (halo 128) and a
+    discriminator block (64 -> 128, stride 2, n = 32: 1024 tiles -> DMA 128x128)."""
     ops = _ops()
     rng = np.random.default_rng(22)
     n, h, cin, cout = 8, 256, 128, 64
@@ -310,9 +321,19 @@ def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     d1 = torch.empty((n, h, h, 64), device="cuda")
     d2 = torch.empty((n, h, h, 64), device="cuda")
     ops.conv2d_dgrad(_dev(dy, "f32"), cout, _dev(w, "f32"), d1, d2, 64, 64, 64, n, h, h, cin, cout, 3, 1)
-    assert ops.last_kernel() == _sym("halo128", "f32"), ops.last_kernel()
+    assert ops.last_kernel() == _sym("wreg", "f32"), ops.last_kernel()
     ref = nhwc(ref.detach())
     assert rel_l2(host(d1), ref[..., :64]) < 1e-5 and rel_l2(host(d2), ref[..., 64:]) < 1e-5
+    del ref, xt
+    n, h, c = 16, 128, 128                               # 128 <- 128 at 128 x 128: 1024 halo blocks
+    w = (rng.standard_normal((3, 3, c, c)) * 0.05).astype(np.float32)
+    dy = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    xt = torch.zeros(n, c, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(w), 1), xt, nchw(dy))
+    dx = torch.empty((n, h, h, c), device="cuda")
+    ops.conv2d_dgrad(_dev(dy, "f32"), c, _dev(w, "f32"), dx, None, c, c, 0, n, h, h, c, c, 3, 1)
+    assert ops.last_kernel() == _sym("halo128", "f32"), ops.last_kernel()
+    assert rel_l2(host(dx), nhwc(ref.detach())) < 1e-5
     del ref, xt
     n, h, cin, cout = 32, 128, 64, 128
     x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
@@ -326,7 +347,7 @@ def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
 
 
 def test_default_dispatch_fp32_cout64_at_256():
-    """The headline block: 64 -> 64 at 256 x 256, n = 8 (fp32 default = DMA 128x64 tile)."""
+    """The headline block: 64 -> 64 at 256 x 256, n = 8 (fp32 default = the weights-in-registers kernel)."""
     ops = _ops()
     rng = np.random.default_rng(23)
     n, h, c = 8, 256, 64
@@ -340,7 +361,7 @@ def test_default_dispatch_fp32_cout64_at_256():
     scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
     ops.conv2d_in_fwd(_dev(x, "f32"), None, 0, c, 0, _wk(w, c, "f32"), torch.from_numpy(b).cuda(), y, c, n, h, h, c, c, 3, 1, 0.2, stats,
                       1e-6, scratch=scr)
-    assert ops.last_kernel() == _sym("dma128x64", "f32"), ops.last_kernel()
+    assert ops.last_kernel() == _sym("wreg", "f32"), ops.last_kernel()
     got = host(y)
     assert rel_l2(got, ref) < 1e-5
     _check_stats(stats, got, n, c, "f32")

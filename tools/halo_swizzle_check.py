@@ -23,6 +23,26 @@ def conflicts(swz):
     return tot, n
 
 
+def conflicts_f32(fn):
+    """fp32 kernel on v_mfma_f32_16x16x4: lane l reads pixel l & 15 of one patch row, chunk fn(l >> 4, R)."""
+    g64 = groups + [[l + 32 for l in g] for g in groups]
+    tot = n = 0
+    for prow in range(8):
+        for dh in (-1, 0, 1):
+            for dw in (-1, 0, 1):
+                for g in g64:
+                    units = {}
+                    for l in g:
+                        R = (prow + 1 + dh) * 18 + (l & 15) + 1 + dw
+                        u = (R * 4 + fn(l >> 4, R)) % 16
+                        units[u] = units.get(u, 0) + 1
+                    tot += max(units.values()) - 1
+                    n += 1
+    return tot, n
+
+
 if __name__ == "__main__":
+    print("fp32 16x16x4, q ^ ((R >> 2) & 3)  : extra cycles / group reads =", conflicts_f32(lambda q, R: q ^ ((R >> 2) & 3)))
+    print("fp32 16x16x4, (q + (R >> 1)) & 3  : extra cycles / group reads =", conflicts_f32(lambda q, R: (q + (R >> 1)) & 3))
     print("(R >> 2) & 3             : extra cycles / group reads =", conflicts(lambda R: (R >> 2) & 3))
     print("((R >> 1) + R // 18) & 3 : extra cycles / group reads =", conflicts(lambda R: ((R >> 1) + R // 18) & 3))

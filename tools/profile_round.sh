@@ -1,0 +1,27 @@
+#!/bin/bash
+# rocprofv3 evidence for one bench configuration (run ON the GPU box, from the repo root):
+#   tools/profile_round.sh <tag> [bench.py arguments ...]
+# four passes of the same command (kernel-trace stats; PMC FETCH_SIZE; PMC WRITE_SIZE + L2 hit/miss; SQ counters), each in its
+# own run as the MI355X guide prescribes (no --pmc together with --stats), distilled into profiles/<tag>_*.{csv,json}.
+set -e -o pipefail
+tag=$1; shift
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+args="--serialize --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer $*"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" $args > "$out/stats.log" 2>&1
+echo "[$tag] stats pass done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 "$root/bench.py" $args > "$out/fetch.log" 2>&1
+echo "[$tag] FETCH_SIZE pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/write" -- python3 "$root/bench.py" $args > "$out/write.log" 2>&1
+echo "[$tag] WRITE_SIZE pass done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/sq" -- python3 "$root/bench.py" $args > "$out/sq.log" 2>&1
+echo "[$tag] SQ pass done"
+cd "$root"
+cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_kernel_stats_serialize.csv"
+python3 tools/pmc_traffic.py "$out/fetch" "$out/write" > "profiles/${tag}_traffic_pmc.json"
+(cd tools && python3 pmc_sq.py "$out/sq") > "profiles/${tag}_sq_pmc.json"
+# keep the merged-back scratch small: the raw counter CSVs are tens of MB
+find "$out" -name '*.csv' -size +2M -delete
+echo "[$tag] distilled into profiles/${tag}_*"
