@@ -179,7 +179,8 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic = None
             # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py, profiles/README.md)
-            tpath = ROOT / "profiles" / ("r01_v3_traffic_pmc.json" if args.dtype == "f32" else "r01_v3_traffic_pmc_bf16.json")
+            tag = "r02_f32" if args.dtype == "f32" else ("r02_s512_b4_bf16" if (S, B) == (512, 4) else "r02_bf16")
+            tpath = ROOT / "profiles" / f"{tag}_traffic_pmc.json"
             if tpath.exists():
                 tj = json.loads(tpath.read_text())
                 key = dom.split(" (+")[0].replace(" ", "")
