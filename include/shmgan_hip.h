@@ -305,6 +305,20 @@ int shm_head_sigmoid_fwd(const float* x, int ldx, const float* w, const float* b
 int shm_spec_loss(const float* cyc_y, const float* cbcr, const float* const* ds, const float* mask,
                   double* loss, int batch, size_t npix, void* stream);
 
+/* ---- live attention branch: attention_layer SHM.py:404-412, its use at SHM.py:248-275, 290-293, 358-359 ------------
+ * The reference evaluates attention_layer on a constant zero mask at model-build time (SURVEY finding 3), so the executed
+ * graph adds zeros; these entry points serve the "as-intended" mode (attention="live"): the SpecSeg mask of the step goes
+ * through MaxPooling2D -> Conv2D(1->C, 3x3, leaky_relu) -> Conv2D(C->C, 3x3, leaky_relu) (the two convolutions are
+ * shm_conv2d_fwd / _dgrad / _wgrad + shm_lrelu_bwd) and is added to the skip tensor. */
+/* MaxPooling2D(k x k) of mask [batch,s,s,1] (fp32) into channel 0 of dst [batch,s/k,s/k,lddst] (activation-typed, other
+ * channels zeroed); k = 1 copies (attention_layer(pool=False), SHM.py:248). */
+int shm_mask_pool_pack(const float* mask, void* dst, int lddst, int batch, int s, int k, int dtype, void* stream);
+/* out[i] = a[i] + b[(i0 + i) % nb] for nimg images of `per` elements (per % 4 == 0): skip + attention map of the image's
+ * sample (SHM.py:290-293, 359); in the batched plan image i0 + i of the batch is a copy of sample (i0 + i) % nb. */
+int shm_add_bcast(const void* a, const void* b, void* out, int nimg, size_t per, int nb, int i0, int dtype, void* stream);
+/* Its gradient wrt b: dst[j] (+)= sum of src[i] over the images with (i0 + i) % nb == j. */
+int shm_sum_groups(const void* src, void* dst, int nimg, size_t per, int nb, int i0, int accumulate, int dtype, void* stream);
+
 /* ---- input pipeline (datasetLoader.py:47-60: image_dataset_from_directory -> /255 -> flip_up_down) ----
  * tf.image.resize(bilinear, half-pixel centres, no antialias) of one decoded uint8 image [hin,win,c] to
  * float32 [ho,wo,c], times `scale` (1/255), optionally flipped top-to-bottom. */

@@ -106,6 +106,44 @@ def init_params(filter_size=64, image_size=128, seed=42, beta_seed=43):
 
 
 # ---------------------------------------------------------------------------
+# "as-intended" live attention branch.  The executed reference evaluates attention_layer on a
+# constant zero mask at build time (finding 3); attention="live" feeds the step's SpecSeg mask instead.
+# ---------------------------------------------------------------------------
+def attention_var_shapes_G(filter_size=64):
+    """Variables of the four generator attention_layer calls (SHM.py:248,257,266,275 -> :404-412), per level
+    [kernel 1->C, bias, kernel C->C, bias] (Keras Conv2D default use_bias=True), C = F, 2F, 4F, 8F."""
+    out = []
+    for c in (filter_size, 2 * filter_size, 4 * filter_size, 8 * filter_size):
+        out += [(3, 3, 1, c), (c,), (3, 3, c, c), (c,)]
+    return out
+
+
+def attention_var_shapes_D(filter_size=64):
+    """attention_layer(filter_size=8F, pool=True, poolsize=(16,16)) of the discriminator (SHM.py:358)."""
+    c = 8 * filter_size
+    return [(3, 3, 1, c), (c,), (3, 3, c, c), (c,)]
+
+
+def init_attention(filter_size=64, seed=45, bias_std=0.0):
+    """RandomNormal(0, 0.02) kernels (SHM.py:200), zero biases (bias_std > 0: non-trivial biases for tests)."""
+    rng = np.random.default_rng(seed)
+
+    def mk(shapes):
+        return [(rng.normal(0.0, 0.02, s) if len(s) == 4 else rng.normal(0.0, bias_std, s) if bias_std else np.zeros(s)).astype(np.float32)
+                for s in shapes]
+    return {"G": mk(attention_var_shapes_G(filter_size)), "D": mk(attention_var_shapes_D(filter_size))}
+
+
+def attention_layer(av, spec_nchw, pool, masks=None, mi=0):
+    """SHM.py:404-412: [MaxPooling2D(pool)] -> Conv2D(3x3, leaky_relu) -> Conv2D(3x3, leaky_relu).
+    av = [k1, b1, k2, b2]; returns (attention map, pooled mask)."""
+    pooled = F.max_pool2d(spec_nchw, pool) if pool else spec_nchw
+    s1 = _act(conv2d_same(pooled, av[0]) + av[1].view(1, -1, 1, 1), masks, mi)
+    s2 = _act(conv2d_same(s1, av[2]) + av[3].view(1, -1, 1, 1), masks, mi + 1)
+    return s2, pooled
+
+
+# ---------------------------------------------------------------------------
 # TF op semantics in torch (NHWC at the interface, NCHW inside)
 # ---------------------------------------------------------------------------
 def _same_pads(n, k, s):
@@ -156,9 +194,22 @@ def _act(z, masks, idx):
     return torch.where(m, z, LRELU * z)
 
 
-def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None, masks=None):
+def generator_attention(avars, mask_nhwc, masks=None):
+    """The four attention maps attn_1..4 of build_generator (SHM.py:248,257,266,275): the first on the mask itself
+    (pool=False), each next one on the 2x2 max-pool of the previous level's pooled mask."""
+    spec = mask_nhwc.permute(0, 3, 1, 2)
+    out = []
+    for lvl in range(4):
+        a, spec = attention_layer(avars[4 * lvl:4 * lvl + 4], spec, 2 if lvl else None, masks, 2 * lvl)
+        out.append(a)
+    return out
+
+
+def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None, masks=None, attn=None):
     """SHM.py:228-327.  x [B,S,S,10] -> [B,S,S,1].  record: optional list that receives, per
-    Conv->LReLU->IN block, (pre-activation z, IN output) with retain_grad (test diagnostics)."""
+    Conv->LReLU->IN block, (pre-activation z, IN output) with retain_grad (test diagnostics).
+    attn: optional [attn_1..attn_4] (NCHW, batch B or a divisor of it: tiled) added to the skips (SHM.py:290-293);
+    None = the executed graph (adds zeros)."""
     spec = generator_spec(filter_size)
     x = x_nhwc.permute(0, 3, 1, 2)
     vi = [0]
@@ -187,6 +238,8 @@ def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None, masks=
         downs.append(x)                       # + attn_k == + 0 (finding 3)
         x = F.avg_pool2d(x, 2)
     x = cnl(cnl(x))                           # the two 1x1 layers (SHM.py:280-282)
+    if attn is not None:                      # down_k = down_k + attn_k (SHM.py:290-293): only the skip, not the pooled path
+        downs = [d + a.repeat(d.shape[0] // a.shape[0], 1, 1, 1) for d, a in zip(downs, attn)]
     for lvl in range(4):
         w, b = nxt()
         x = _act(conv2d_transpose_same(x, w) + b.view(1, -1, 1, 1), masks, vi[0] // 2 - 1)
@@ -198,16 +251,19 @@ def generator_forward(gvars, gbetas, x_nhwc, filter_size=64, record=None, masks=
     return x.permute(0, 2, 3, 1)
 
 
-def discriminator_forward(dvars, dbetas, x_nhwc, noise=None, keep_mask=None, dropout=0.2, masks=None):
+def discriminator_forward(dvars, dbetas, x_nhwc, noise=None, keep_mask=None, dropout=0.2, masks=None, attn=None):
     """SHM.py:343-389.  x [B,S,S,3] -> ([B,s,s,1], [B,5]).  training=True <=> noise and
-    keep_mask given: GaussianNoise adds `noise`; Dropout multiplies by keep_mask/(1-rate)."""
+    keep_mask given: GaussianNoise adds `noise`; Dropout multiplies by keep_mask/(1-rate).
+    attn: optional attn_disc (NCHW, [B, 8F, S/16, S/16]) added after the fourth block (SHM.py:358-359)."""
     x = x_nhwc
     if noise is not None:
         x = x + noise
     x = x.permute(0, 3, 1, 2)
     for i in range(5):
         x = _act(conv2d_same(x, dvars[i], stride=2), masks, i)
-        x = instance_norm(x, dbetas[i])       # (+ attn_disc == + 0 after block 4)
+        x = instance_norm(x, dbetas[i])
+        if i == 3 and attn is not None:       # x = x + attn_disc (SHM.py:359); the executed graph adds zeros
+            x = x + attn
     if keep_mask is not None:
         x = x * keep_mask.permute(0, 3, 1, 2) / (1.0 - dropout)
     rf = _act(conv2d_same(x, dvars[5]), masks, 5).permute(0, 2, 3, 1)
@@ -352,7 +408,7 @@ def _mslice(masks, lo, hi):
 
 
 def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_factor,
-               filter_size=64, dtype=torch.float64, need_grads=True, masks=None, specseg=None):
+               filter_size=64, dtype=torch.float64, need_grads=True, masks=None, specseg=None, attention=None):
     """One SHM.py:467-875 forward + both tape.gradient calls (no optimizer apply).
 
     gvars/dvars/gbetas/dbetas: lists of numpy arrays or tensors (TF layouts).
@@ -361,6 +417,10 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     sign patterns taken from the device run (see _act); D batch order [D1][D3 x5][D2][D4 x5].
     specseg: optional SpecSeg weights (oracle.specseg_torch layout): adds the mask of SHM.py:492 to
     outs["specular_candidate"] and the logged-only losses["Spec_loss"] (SHM.py:792-806).
+    attention: optional {"G": [16 arrays], "D": [4 arrays]} (init_attention): the "as-intended" LIVE attention branch --
+    the step's SpecSeg mask (needs `specseg`; a constant, no gradient flows into SpecSeg) through attention_layer into
+    the four generator skips and the discriminator, for every G / D call of the step.  The result then carries gGa / gDa,
+    the gradients of the attention variables (G loss / D loss).  masks may hold "ga" (8) and "da" (2) sign patterns.
     """
     mk = masks or {}
     T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype)
@@ -386,17 +446,30 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     ones = torch.ones(B, S, S, 1, dtype=dtype)
     avgCbCr = (ds[0][..., 1:] + ds[1][..., 1:] + ds[2][..., 1:] + ds[3][..., 1:] + ds[4][..., 1:]) / 5.0
 
+    # specular mask (outside the tape, SHM.py:492) and, in live mode, the attention maps it produces
+    spec_mask = None
+    if specseg is not None:
+        from .specseg_torch import specseg_forward
+        spec_mask = specseg_forward(specseg, Ych[2], dtype).detach()
+    ga = da = attn_g = attn_d = None
+    if attention is not None:
+        assert spec_mask is not None, "attention='live' needs the SpecSeg weights"
+        ga = [T(a).clone().requires_grad_(need_grads) for a in attention["G"]]
+        da = [T(a).clone().requires_grad_(need_grads) for a in attention["D"]]
+        attn_g = generator_attention(ga, spec_mask, mk.get("ga"))
+        attn_d, _ = attention_layer(da, spec_mask.permute(0, 3, 1, 2), 16, mk.get("da"), 0)
+
     # G(1)  SHM.py:517-538
     rand_inp = [zeros if flags[k] else Ych[k] for k in range(5)]
     gen_input = torch.cat(rand_inp + [zeros, zeros, zeros, zeros, ones], dim=3)
-    gen_Y = generator_forward(gv, gb, gen_input, filter_size, masks=mk.get("g1"))
+    gen_Y = generator_forward(gv, gb, gen_input, filter_size, masks=mk.get("g1"), attn=attn_g)
     gen_yuv = torch.cat([gen_Y, avgCbCr], dim=3)
     gen_rgb = yuv_to_rgb(gen_yuv)
 
     # D(1), D(2): training=True  SHM.py:559-563
     md = mk.get("d")
-    rf_D1, cls_D1 = discriminator_forward(dv, db, gen_rgb, noise[:B], keep[:B], masks=_mslice(md, 0, B))
-    rf_D2, cls_D2 = discriminator_forward(dv, db, orig[4], noise[B:], keep[B:], masks=_mslice(md, 6 * B, 7 * B))
+    rf_D1, cls_D1 = discriminator_forward(dv, db, gen_rgb, noise[:B], keep[:B], masks=_mslice(md, 0, B), attn=attn_d)
+    rf_D2, cls_D2 = discriminator_forward(dv, db, orig[4], noise[B:], keep[B:], masks=_mslice(md, 6 * B, 7 * B), attn=attn_d)
 
     # G(2): cyclic inputs  SHM.py:576-607
     sub = [gen_Y if flags[k] else Ych[k] for k in range(5)]
@@ -405,13 +478,13 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
         chans = [zeros if j == k else sub[j] for j in range(5)]
         onehot = [ones if j == k else zeros for j in range(5)]
         cyc_Y.append(generator_forward(gv, gb, torch.cat(chans + onehot, dim=3), filter_size,
-                                       masks=_mslice(mk.get("cyc"), k * B, (k + 1) * B)))
+                                       masks=_mslice(mk.get("cyc"), k * B, (k + 1) * B), attn=attn_g))
     cyc_yuv = [torch.cat([cy, avgCbCr], dim=3) for cy in cyc_Y]
     cyc_rgb = [yuv_to_rgb(c) for c in cyc_yuv]
 
     # D(3), D(4): training=False  SHM.py:627-642
-    D3 = [discriminator_forward(dv, db, c, masks=_mslice(md, (1 + k) * B, (2 + k) * B)) for k, c in enumerate(cyc_rgb)]
-    D4 = [discriminator_forward(dv, db, o, masks=_mslice(md, (7 + k) * B, (8 + k) * B)) for k, o in enumerate(orig)]
+    D3 = [discriminator_forward(dv, db, c, masks=_mslice(md, (1 + k) * B, (2 + k) * B), attn=attn_d) for k, c in enumerate(cyc_rgb)]
+    D4 = [discriminator_forward(dv, db, o, masks=_mslice(md, (7 + k) * B, (8 + k) * B), attn=attn_d) for k, o in enumerate(orig)]
 
     def mse(a, t):      # per-sample mean -> [B]
         return ((a - t) ** 2).mean(dim=(1, 2, 3))
@@ -455,11 +528,9 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
         "L1_loss_Gen": L1_loss, "ssim_cyc_loss": ssim_loss, "content_loss": content,
         "style_loss": style, "total_NST_loss": nst,
     }
-    spec_mask = None
     if specseg is not None:
-        from .specseg_torch import spec_loss, specseg_forward
-        spec_mask = specseg_forward(specseg, Ych[2], dtype)                      # predict(I90_Ych)  SHM.py:492
-        losses["Spec_loss"] = spec_loss([c.detach() for c in cyc_yuv], ds, spec_mask)[0]
+        from .specseg_torch import spec_loss
+        losses["Spec_loss"] = spec_loss([c.detach() for c in cyc_yuv], ds, spec_mask)[0]      # mask = predict(I90_Ych)  SHM.py:492
     out = {"losses": {k: float(v.mean().detach()) for k, v in losses.items()},
            "outs": {"gen_Y": gen_Y.detach(), "gen_rgb": gen_rgb.detach(),
                     "cyc_rgb": [c.detach() for c in cyc_rgb],
@@ -467,12 +538,16 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
                     "ssim": [s_.detach() for s_ in ssims], "scales": [s_.detach() for s_ in scales],
                     "specular_candidate": spec_mask}}
     if need_grads:
-        gD = torch.autograd.grad((total_D + total_C).mean(), dv, retain_graph=True)
+        gD = torch.autograd.grad((total_D + total_C).mean(), dv + (da or []), retain_graph=True)
+        if da is not None:
+            gD, out["gDa"] = gD[:len(dv)], list(gD[len(dv):])
         # intermediate generator-loss gradients (test diagnostics): wrt the 5 cyclic outputs and
         # the total derivative wrt gen_Y (direct terms + the G o G chain through the cyclic inputs)
         mid = torch.autograd.grad(total_G.mean(), cyc_Y + [gen_Y], retain_graph=True)
         out["dcyc_Y"], out["dgen_Y"] = [m_.detach() for m_ in mid[:5]], mid[5].detach()
-        gG = torch.autograd.grad(total_G.mean(), gv)
+        gG = torch.autograd.grad(total_G.mean(), gv + (ga or []))
+        if ga is not None:
+            gG, out["gGa"] = gG[:len(gv)], list(gG[len(gv):])
         out["gD"], out["gG"] = list(gD), list(gG)
     return out
 

@@ -72,6 +72,9 @@ SIGNATURES = {
     "shm_conv2d_transpose2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, F, I, P]),
     "shm_head_sigmoid_fwd": (I, [P, I, P, P, P, Z, I, P]),
     "shm_spec_loss": (I, [P, P, P, P, P, I, Z, P]),
+    "shm_mask_pool_pack": (I, [P, P, I, I, I, I, I, P]),
+    "shm_add_bcast": (I, [P, P, P, I, Z, I, I, I, P]),
+    "shm_sum_groups": (I, [P, P, I, Z, I, I, I, I, P]),
     "shm_resize_bilinear_u8": (I, [P, I, I, I, P, I, I, F, I, P]),
     "shm_adam_clip": (I, [P, P, P, P, Z, F, F, F, F, F, P]),
 }

@@ -914,6 +914,82 @@ extern "C" int shm_mul_mask(const void* x, const float* mask, void* y, size_t n,
     return SHM_OK;
 }
 
+// ------------------------------------------------------ live attention branch (SHM.py:404-412, 290-293, 359)
+// MaxPooling2D(pool k x k, 'same' on sizes that are multiples of k) of the one-channel mask, written as channel 0 of an
+// activation tensor of pitch ld (the other channels zero): the 1 -> C convolution of attention_layer then runs on the
+// ordinary tap GEMM.  k = 1 copies (attention_layer(pool=False)).
+template <typename T>
+__global__ void mask_pool_pack_kernel(const float* __restrict__ m, T* __restrict__ dst, int ld, int s, int k, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // output pixel (b, y, x)
+    if (i >= total) return;
+    const int so = s / k;
+    const int x = (int)(i % so), y = (int)((i / so) % so);
+    const size_t b = i / ((size_t)so * so);
+    const float* src = m + (b * s + (size_t)y * k) * s + (size_t)x * k;
+    float v = src[0];
+    for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) v = fmaxf(v, src[(size_t)dy * s + dx]);
+    T* o = dst + i * ld;
+    o[0] = (T)v;
+    for (int c = 1; c < ld; ++c) o[c] = (T)0.f;
+}
+
+extern "C" int shm_mask_pool_pack(const float* mask, void* dst, int lddst, int batch, int s, int k, int dtype, void* stream) {
+    SHM_REQUIRE(mask && dst && k >= 1 && s % k == 0 && lddst >= 1, SHM_E_SHAPE, "shm_mask_pool_pack: bad shape (s %d, k %d)", s, k);
+    const size_t total = (size_t)batch * (s / k) * (s / k);
+    if (total == 0) return SHM_OK;
+    SHM_DISPATCH(dtype, "shm_mask_pool_pack",
+                 hipLaunchKernelGGL(mask_pool_pack_kernel<T>, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, mask, (T*)dst, lddst, s, k, total));
+    SHM_LAUNCH_CHECK("shm_mask_pool_pack");
+    return SHM_OK;
+}
+
+// out[i] = a[i] + b[(i0 + i) % nb]  over images of `per` elements each: the skip tensor plus the attention map of its sample
+// (`down_k + attn_k`, SHM.py:290-293; `x + attn_disc`, SHM.py:359), the attention map shared by every copy of a sample in the
+// batched plan (image i of the batch belongs to sample (i0 + i) % nb).
+template <typename T>
+__global__ void add_bcast_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t per4, int nb, int i0, size_t total4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const size_t img = i / per4, r = i - img * per4;
+    const size_t j = ((size_t)i0 + img) % (size_t)nb;
+    st4(out + i * 4, ld4(a + i * 4) + ld4(b + (j * per4 + r) * 4));
+}
+
+extern "C" int shm_add_bcast(const void* a, const void* b, void* out, int nimg, size_t per, int nb, int i0, int dtype, void* stream) {
+    SHM_REQUIRE(a && b && out && per % 4 == 0 && nb >= 1 && i0 >= 0, SHM_E_SHAPE, "shm_add_bcast: bad arguments");
+    const size_t total4 = (size_t)nimg * per / 4;
+    if (total4 == 0) return SHM_OK;
+    SHM_DISPATCH(dtype, "shm_add_bcast",
+                 hipLaunchKernelGGL(add_bcast_kernel<T>, dim3(shm_cdiv((long)total4, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out,
+                                    per / 4, nb, i0, total4));
+    SHM_LAUNCH_CHECK("shm_add_bcast");
+    return SHM_OK;
+}
+
+// dst[j] (+)= sum over the images i of src with (i0 + i) % nb == j: the gradient of the broadcast above (fp32 accumulation).
+template <typename T>
+__global__ void sum_groups_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t per4, int nimg, int nb, int i0, int accumulate, size_t total4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // (sample j, element r)
+    if (i >= total4) return;
+    const size_t j = i / per4, r = i - j * per4;
+    f32x4 s = accumulate ? ld4(dst + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    int first = (int)((j + (size_t)nb - (size_t)(i0 % nb)) % (size_t)nb);
+    for (int img = first; img < nimg; img += nb) s += ld4(src + ((size_t)img * per4 + r) * 4);
+    st4(dst + i * 4, s);
+}
+
+extern "C" int shm_sum_groups(const void* src, void* dst, int nimg, size_t per, int nb, int i0, int accumulate, int dtype, void* stream) {
+    SHM_REQUIRE(src && dst && per % 4 == 0 && nb >= 1 && i0 >= 0, SHM_E_SHAPE, "shm_sum_groups: bad arguments");
+    const size_t total4 = (size_t)nb * per / 4;
+    if (total4 == 0) return SHM_OK;
+    SHM_DISPATCH(dtype, "shm_sum_groups",
+                 hipLaunchKernelGGL(sum_groups_kernel<T>, dim3(shm_cdiv((long)total4, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, per / 4, nimg,
+                                    nb, i0, accumulate, total4));
+    SHM_LAUNCH_CHECK("shm_sum_groups");
+    return SHM_OK;
+}
+
 // ------------------------------------------------ input gradient of a first layer, summed over input channels
 // The step never needs the per-channel input gradient of the two first layers, only sums over input channels:
 //   generator (cyclic pass, SHM.py:576-580): d genY[b,p] = sum_k sum_{j != k, flags[j]} dX_k[b,p,j]

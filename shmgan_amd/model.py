@@ -159,23 +159,85 @@ class _Vars:
 class _ModelBase:
     trainable = True
 
-    @property
-    def trainable_variables(self):
-        return self.P.vars
-
-    @property
-    def gradients(self):
-        return self.P.grads
-
     def count_params(self):
         return self.P.n
 
+    # storage index of every variable in Keras creation order (identity unless the live attention branch adds variables,
+    # which Keras creates in the middle of the layer list)
+    keras_index = None
+
+    def _korder(self):
+        return self.keras_index if self.keras_index is not None else list(range(len(self.P.vars)))
+
+    @property
+    def trainable_variables(self):
+        return [self.P.vars[i] for i in self._korder()]
+
+    @property
+    def gradients(self):
+        return [self.P.grads[i] for i in self._korder()]
+
     def get_weights(self):
-        return self.P.numpy("vars")
+        w = self.P.numpy("vars")
+        return [w[i] for i in self._korder()]
 
     def set_weights(self, arrays):
-        self.P.load(arrays)
+        ko = self._korder()
+        assert len(arrays) == len(ko)
+        st = [None] * len(ko)
+        for a, i in zip(arrays, ko):
+            st[i] = a
+        self.P.load(st)
         self.weights_dirty = True
+
+
+class AttentionBranch:
+    """One `attention_layer` call (SHM.py:404-412) on the LIVE SpecSeg mask of the step (attention="live";
+    as executed the reference only ever evaluates it on a constant zero mask, SURVEY finding 3):
+    MaxPooling2D(k) -> Conv2D(1->C, 3x3, bias, LeakyReLU) -> Conv2D(C->C, 3x3, bias, LeakyReLU) on [B, S/k, S/k].
+    The variables (k1 [3,3,1,C], b1, k2 [3,3,C,C], b2) are views into the owning model's flat parameter buffer, so
+    clip+Adam and the gradient all-reduce cover them; forward and backward are C-ABI calls like every other layer."""
+
+    def __init__(self, owner, vi, c, pool, tag):
+        self.o, self.vi, self.c, self.pool, self.tag = owner, vi, c, pool, tag
+        self.wk1 = torch.zeros(9 * c * owner.pad, dtype=owner.adt, device=owner.dev)
+        self.wk2 = torch.zeros(9 * c * c, dtype=owner.adt, device=owner.dev)
+        self.ctx = None
+
+    def prepare_weights(self):
+        P, c = self.o.P, self.c
+        ops.transpose_taps(P.vars[self.vi], self.wk1, 9, 1, c, self.o.pad)
+        ops.transpose_taps(P.vars[self.vi + 2], self.wk2, 9, c, c, c)
+
+    def forward(self, mask, B, S):
+        """mask [B,S,S,1] fp32 -> attention map [B, S/pool, S/pool, C] (activation dtype)."""
+        o, c, A = self.o, self.c, self.o.arena
+        h = S // self.pool
+        m = A.get(f"{self.tag}/m", (B, h, h, o.pad), o.adt)
+        y1 = A.get(f"{self.tag}/y1", (B, h, h, c), o.adt)
+        y2 = A.get(f"{self.tag}/y2", (B, h, h, c), o.adt)
+        ops.mask_pool_pack(mask, m, B, S, self.pool)
+        ops.conv2d_fwd(m, None, 0, o.pad, 0, self.wk1, o.P.vars[self.vi + 1], y1, c, B, h, h, o.pad, c, 3, 1, LRELU, cin_real=1)
+        ops.conv2d_fwd(y1, None, 0, c, 0, self.wk2, o.P.vars[self.vi + 3], y2, c, B, h, h, c, c, 3, 1, LRELU)
+        self.ctx = dict(B=B, h=h, m=m, y1=y1, y2=y2)
+        return y2
+
+    def backward(self, dattn):
+        """dattn [B,h,h,C] ([G]-typed): gradient at the attention map, summed over every copy of the sample.  Fills the
+        weight gradients (kernels by the MFMA wgrad, biases through the owner's f64 accumulators)."""
+        o, c, A, x = self.o, self.c, self.o.arena, self.ctx
+        B, h = x["B"], x["h"]
+        dz2 = A.get(f"{self.tag}/dz2", (B, h, h, c), o.adt)
+        dz1 = A.get(f"{self.tag}/dz1", (B, h, h, c), o.adt)
+        dy1 = A.get(f"{self.tag}/dy1", (B, h, h, c), o.gdt)
+        red = A.get(f"attn/lred/{c}", (ops.LRELU_RED_SLOTS * c,), torch.float64)
+        ops.lrelu_bwd(dattn, c, x["y2"], c, dz2, c, o._acc_slice(self.vi + 3), B * h * h, c, LRELU, red)
+        ws = o.ws_provider(ops.conv2d_wgrad_workspace(B, h, h, c, c, 3))
+        o.lane.submit(lambda: ops.conv2d_wgrad(x["y1"], None, 0, c, 0, dz2, c, o.P.grads[self.vi + 2], B, h, h, c, c, c, 3, 1, 0, ws))
+        ops.conv2d_dgrad(dz2, c, o.P.op_vars[self.vi + 2], dy1, None, c, c, 0, B, h, h, c, c, 3, 1)
+        ops.lrelu_bwd(dy1, c, x["y1"], c, dz1, c, o._acc_slice(self.vi + 1), B * h * h, c, LRELU, red)
+        ws = o.ws_provider(ops.conv2d_wgrad_workspace(B, h, h, 1, c, 3))
+        o.lane.submit(lambda: ops.conv2d_wgrad(x["m"], None, 0, o.pad, 0, dz1, c, o.P.grads[self.vi], B, h, h, 1, o.pad, c, 3, 1, 0, ws))
 
 
 # =============================================================================== Generator
@@ -183,8 +245,9 @@ class Generator(_ModelBase):
     name = "SHM_Generator"
 
     def __init__(self, image_size, filter_size, device, arena, ws_provider, lane=None, dtype=torch.float32,
-                 grad_dtype=None):
+                 grad_dtype=None, attention=False):
         self.S, self.F, self.dev = image_size, filter_size, device
+        self.attention = bool(attention)
         self.arena, self.ws_provider = arena, ws_provider
         self.lane = lane or WgradLane(device, enabled=False)
         self.adt = dtype                                   # activation / MFMA operand dtype
@@ -198,11 +261,26 @@ class Generator(_ModelBase):
             shapes.append((k, k, cin, cout) if kind == "c" else (k, k, cout, cin))
             shapes.append((cout,))
         nl = len(self.layers)
-        # storage order: all MFMA-wgrad kernels, then [head kernel, every bias] (f64-accumulated grads)
-        order = [2 * i for i in range(nl - 1)] + [2 * (nl - 1)] + [2 * i + 1 for i in range(nl)]
+        nbase = 2 * nl
+        akern, abias = [], []
+        if self.attention:            # attention_layer variables of the four levels: [k 1->C, b, k C->C, b], C = F, 2F, 4F, 8F
+            for lvl in range(4):
+                c = filter_size << lvl
+                shapes += [(3, 3, 1, c), (c,), (3, 3, c, c), (c,)]
+                akern += [nbase + 4 * lvl, nbase + 4 * lvl + 2]
+                abias += [nbase + 4 * lvl + 1, nbase + 4 * lvl + 3]
+            # Keras creates an attention_layer right after the two convolutions of its encoder level (SHM.py:244-275)
+            ko = []
+            for lvl in range(4):
+                ko += [4 * lvl, 4 * lvl + 1, 4 * lvl + 2, 4 * lvl + 3] + [nbase + 4 * lvl + j for j in range(4)]
+            self.keras_index = ko + list(range(16, nbase))
+        # storage order: all MFMA-wgrad kernels (the layers', then the attention branch's), then [head kernel, every bias]
+        # (f64-accumulated grads)
+        order = [2 * i for i in range(nl - 1)] + akern + [2 * (nl - 1)] + [2 * i + 1 for i in range(nl)] + abias
         self.P = _Vars(shapes, order, device)
         self.P.operand_copy(dtype)
         self.acc_off = self.P.offsets[2 * (nl - 1)]            # start of the f64-accumulated region
+        self.attn_off = self.P.offsets[akern[0]] if akern else self.acc_off
         self.acc_n = self.P.n - self.acc_off
         self.acc = torch.zeros(self.acc_n, dtype=torch.float64, device=device)
         self.in_channels = [cout for n_, kind, k, cin, cout in self.layers if kind == "c" and n_ != "conv2d_26"]
@@ -214,6 +292,8 @@ class Generator(_ModelBase):
                 self.wk[i] = torch.zeros(k * k * cout * _padk(cin, self.pad), dtype=dtype, device=device)
             else:
                 self.wk[i] = torch.zeros(9 * cin * cout, dtype=dtype, device=device)
+        self.attn = [AttentionBranch(self, nbase + 4 * lvl, filter_size << lvl, 1 << lvl, f"g/attn{lvl}") for lvl in range(4)] \
+            if self.attention else []
         self.weights_dirty = True
         self.ctx = {}
         self.debug = None
@@ -233,11 +313,11 @@ class Generator(_ModelBase):
         (3.7 MB at F=64), decoder bottom (49.6 MB), encoder bottom + 1x1 bottleneck (19.8 MB), the rest (1.1 MB)."""
         off = [self.P.offsets[2 * i] for i in range(len(self.layers))]
         cuts = [16, 10, 4]                                   # lowest layer of each early bucket
-        out, hi = [], self.acc_off
+        out, hi = [], self.attn_off                          # (live attention kernels sit between the layers' and the head's)
         for c in cuts:
             out.append((c, [(off[c], hi)]))
             hi = off[c]
-        out.append((None, [(0, hi), (self.acc_off, self.P.n)]))
+        out.append((None, [(0, hi), (self.attn_off, self.P.n)]))
         return out
 
     def _acc_slice(self, var_index):
@@ -255,11 +335,30 @@ class Generator(_ModelBase):
                 ops.transpose_taps(w, self.wk[i], k * k, cin, cout, _padk(cin, self.pad))
             else:                # Keras convT [t][cout][cin] -> [t][cin][cout] (for its dgrad)
                 ops.transpose_taps(w, self.wk[i], 9, cout, cin, cout)
+        for br in self.attn:
+            br.prepare_weights()
         self.weights_dirty = False
 
     def zero_grad(self):
         ops.zero(self.P.grad)
         ops.zero(self.acc)
+
+    # -- live attention branch ---------------------------------------------------------------
+    def attention_forward(self, mask, B):
+        """attn_1..attn_4 (SHM.py:248,257,266,275) of the step's SpecSeg mask [B,S,S,1]; pass the result to forward(attn=)."""
+        self.prepare_weights()
+        self._attn_B = B
+        return [br.forward(mask, B, self.S) for br in self.attn]
+
+    def attention_masks(self):
+        """Sign patterns of the eight attention LeakyReLUs of the last attention_forward (test diagnostics, see lrelu_masks)."""
+        return [(br.ctx[k] > 0).cpu().numpy() for br in self.attn for k in ("y1", "y2")]
+
+    def attention_backward(self):
+        """Backward of the four attention branches from the skip gradients every backward() of this step accumulated."""
+        for lvl, br in enumerate(self.attn):
+            br.backward(self._dattn[lvl])
+        self._dattn_live = False
 
     def finish_grads(self):
         """Fold the f64-accumulated head-kernel / bias gradients into the flat fp32 gradient."""
@@ -281,8 +380,10 @@ class Generator(_ModelBase):
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
         return ahat, rec
 
-    def forward(self, x16, tag):
-        """x16: [N,S,S,pad] (10 real channels, zero padded to the 64-byte pitch).  Returns gen_Y [N,S,S,1]."""
+    def forward(self, x16, tag, attn=None):
+        """x16: [N,S,S,pad] (10 real channels, zero padded to the 64-byte pitch).  Returns gen_Y [N,S,S,1].
+        attn: attention_forward()'s maps ([B,...], N a multiple of B: image i is a copy of sample i % B): added to the four
+        skip tensors, `down_k + attn_k` (SHM.py:290-293); the pooled path keeps the un-augmented tensor."""
         n, S, F = x16.shape[0], self.S, self.F
         assert tuple(x16.shape) == (n, S, S, self.pad) and x16.dtype == self.adt
         self.prepare_weights()
@@ -298,7 +399,12 @@ class Generator(_ModelBase):
                 ld = self.layers[li][4]
                 li += 1
                 bi += 1
-            downs.append((cur, ld, h))
+            if attn is not None:
+                skip = A.get(f"{tag}/skip{lvl}", (n, h, h, ld), self.adt)
+                ops.add_bcast(cur, attn[lvl], skip, n, h * h * ld, self._attn_B)
+                downs.append((skip, ld, h))
+            else:
+                downs.append((cur, ld, h))
             pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, ld), self.adt)
             ops.avgpool2_fwd(cur, ld, pooled, ld, n, h, h, ld)
             cur, h = pooled, h // 2
@@ -329,7 +435,7 @@ class Generator(_ModelBase):
             bi += 1
         y = A.get(f"{tag}/y", (n, S, S, 1))
         ops.head_fwd(cur, ld, self.P.vars[2 * li], self.P.vars[2 * li + 1], y, n * S * S, ld, LRELU)
-        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, y=y, x16=x16)
+        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, y=y, x16=x16, attn=attn is not None)
         return y
 
     # -- backward -------------------------------------------------------------------------
@@ -399,6 +505,15 @@ class Generator(_ModelBase):
             dsk = A.get(f"bwd/dskip{3 - lvl}/{n}x{h}x{cs}", (n, h, h, cs), self.gdt)
             self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu)
             dskips[3 - lvl] = dsk
+            if c["attn"]:                       # d attn_k = sum of the skip gradient over every copy of the sample
+                B = self._attn_B
+                if lvl == 3 and not getattr(self, "_dattn_live", False):       # first backward pass of the step
+                    self._dattn = [None] * 4
+                da = A.get(f"bwd/dattn{3 - lvl}/{B}", (B, h, h, cs), self.gdt)
+                ops.sum_groups(dsk, da, n, h * h * cs, B, 0, accumulate=self._dattn[3 - lvl] is not None)
+                self._dattn[3 - lvl] = da
+                if lvl == 0:
+                    self._dattn_live = True
             # Conv2DTranspose: LeakyReLU', bias grad, wgrad (roles swapped), dgrad = stride-2 conv
             tli = up["li"]
             _, _, _, tcin, tcout = self.layers[tli]
@@ -478,8 +593,9 @@ class Discriminator(_ModelBase):
     name = "SHM_Discriminator"
 
     def __init__(self, image_size, filter_size, device, arena, ws_provider, dropout=0.2, lane=None, dtype=torch.float32,
-                 grad_dtype=None):
+                 grad_dtype=None, attention=False):
         self.S, self.F, self.dev = image_size, filter_size, device
+        self.attention = bool(attention)
         self.arena, self.ws_provider = arena, ws_provider
         self.lane = lane or WgradLane(device, enabled=False)
         self.adt = dtype
@@ -493,8 +609,18 @@ class Discriminator(_ModelBase):
         shapes = [(3, 3, self.chan[i], self.chan[i + 1]) for i in range(5)]
         shapes += [(3, 3, 16 * f, 1), (s * s * 16 * f, 5)]
         self.names = ["conv2d_27", "conv2d_28", "conv2d_29", "conv2d_30", "conv2d_33", "conv2d_34", "dense"]
-        self.P = _Vars(shapes, list(range(7)), device)
+        order = list(range(7))
+        if self.attention:            # attention_layer(8F, pool 16x16) (SHM.py:358): [k 1->8F, b, k 8F->8F, b], biases stored last
+            c = 8 * f
+            shapes += [(3, 3, 1, c), (c,), (3, 3, c, c), (c,)]
+            order += [7, 9, 8, 10]
+            self.names += ["conv2d_31", "conv2d_31/bias", "conv2d_32", "conv2d_32/bias"]
+            self.keras_index = [0, 1, 2, 3, 7, 8, 9, 10, 4, 5, 6]          # created between the 4th and 5th block
+        self.P = _Vars(shapes, order, device)
         self.P.operand_copy(dtype)
+        self.acc_off = self.P.offsets[8] if self.attention else self.P.n   # f64-accumulated region: the two attention biases
+        self.acc = torch.zeros(self.P.n - self.acc_off, dtype=torch.float64, device=device)
+        self.attn = AttentionBranch(self, 7, 8 * f, 16, "d/attn") if self.attention else None
         self.betas = [torch.zeros(c, dtype=torch.float32, device=device) for c in self.chan[1:]]
         self.wk = [torch.zeros(9 * self.chan[i + 1] * _padk(self.chan[i], self.pad), dtype=dtype, device=device)
                    for i in range(5)]
@@ -511,28 +637,43 @@ class Discriminator(_ModelBase):
         self.P.refresh_operands()
         for i in range(5):
             ops.transpose_taps(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _padk(self.chan[i], self.pad))
+        if self.attn is not None:
+            self.attn.prepare_weights()
         self.weights_dirty = False
 
     def zero_grad(self):
         ops.zero(self.P.grad)
+        if self.attn is not None:
+            ops.zero(self.acc)
 
-    def forward(self, xd16, keep_mask=None, mask_rows=(), parts=None):
+    def _acc_slice(self, var_index):
+        o = self.P.offsets[var_index] - self.acc_off
+        return self.acc[o:o + self.P.vars[var_index].numel()]
+
+    def attention_forward(self, mask, B):
+        """attn_disc (SHM.py:358) of the step's SpecSeg mask [B,S,S,1]; pass the result to forward(attn=)."""
+        self.prepare_weights()
+        self._attn_B = B
+        return self.attn.forward(mask, B, self.S)
+
+    def forward(self, xd16, keep_mask=None, mask_rows=(), parts=None, attn=None):
         """xd16 [N,S,S,16] (rgb + zeros).  keep_mask [len(mask_rows)...] is the Dropout keep mask of
         the `training=True` samples: mask_rows = list of (row_start, nrows, mask_row_start).
         parts: optional list of (row0, row1, run) -- the conv trunk is evaluated per row range (samples
         are independent: InstanceNorm) through `run(fn)`; the trainer uses it to push the real-image
         half onto the second stream while the generator is still producing the fake half."""
         n = xd16.shape[0]
-        self.start(xd16, keep_mask, mask_rows)
+        self.start(xd16, keep_mask, mask_rows, attn)
         if parts is None:
             parts = [(0, n, lambda fn: fn())]
         for r0, r1, run in parts:
             run(lambda r0=r0, r1=r1: self.trunk_rows(r0, r1))
         return self.heads()
 
-    def start(self, xd16, keep_mask=None, mask_rows=()):
+    def start(self, xd16, keep_mask=None, mask_rows=(), attn=None):
         """Declare the batch of the next forward (buffers only); follow with trunk_rows(...) over
-        every row and heads()."""
+        every row and heads().  attn: attention_forward()'s map [B,...] (batch a multiple of B, image i = a copy of sample
+        i % B): added after the fourth block, `x + attn_disc` (SHM.py:359)."""
         n, S = xd16.shape[0], self.S
         self.prepare_weights()
         A = self.arena
@@ -544,7 +685,8 @@ class Discriminator(_ModelBase):
             bufs.append((A.get(f"d/a{i}/{n}", (n, ho, ho, cout), self.adt), A.get(f"d/h{i}/{n}", (n, ho, ho, cout), self.adt),
                          A.get(f"d/s{i}/{n}", (n * cout * 2,), torch.float64)))
             h = ho
-        self._pending = dict(n=n, xd16=xd16, bufs=bufs, keep_mask=keep_mask, mask_rows=mask_rows)
+        x3p = A.get(f"d/x3p/{n}", (n, S // 16, S // 16, self.chan[4]), self.adt) if attn is not None else None
+        self._pending = dict(n=n, xd16=xd16, bufs=bufs, keep_mask=keep_mask, mask_rows=mask_rows, attn=attn, x3p=x3p)
 
     def trunk_rows(self, r0, r1):
         """The five Conv(3x3, s2) -> LeakyReLU -> InstanceNorm blocks on samples [r0, r1)."""
@@ -562,6 +704,10 @@ class Discriminator(_ModelBase):
                               LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
             ops.in_apply(a[r0:r1], cout, st, self.betas[i], ahat[r0:r1], cout, nb, ho * ho, cout)
             cur, ld, h = ahat[r0:r1], cout, ho
+            if i == 3 and self._pending["attn"] is not None:
+                x3p = self._pending["x3p"]
+                ops.add_bcast(cur, self._pending["attn"], x3p[r0:r1], nb, ho * ho * cout, self._attn_B, r0)
+                cur = x3p[r0:r1]
 
     def heads(self):
         """Dropout (training=True rows), PatchGAN logits and the Dense(5) classifier on the whole batch."""
@@ -575,6 +721,8 @@ class Discriminator(_ModelBase):
             a, ahat, stats = bufs[i]
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
             cur, ld, h = ahat, self.chan[i + 1], h // 2
+            if i == 3 and pd["x3p"] is not None:
+                cur = pd["x3p"]
         c5 = self.chan[5]
         per = h * h * c5
         scale = 1.0 / (1.0 - self.dropout)
@@ -584,7 +732,7 @@ class Discriminator(_ModelBase):
         cls = A.get(f"d/cls/{n}", (n, 5))
         ops.patch_fwd(cur, c5, self.P.vars[5], rf, n, h, h, c5, LRELU)
         ops.dense_fwd(cur, self.P.vars[6], cls, n, per, 5)
-        self.ctx = dict(n=n, recs=recs, x5=cur, rf=rf, cls=cls, keep_mask=keep_mask, mask_rows=mask_rows)
+        self.ctx = dict(n=n, recs=recs, x5=cur, rf=rf, cls=cls, keep_mask=keep_mask, mask_rows=mask_rows, attn=pd["attn"] is not None)
         return rf, cls
 
     def _backward(self, n, drf, dcls, params, need_dx):
@@ -625,11 +773,18 @@ class Discriminator(_ModelBase):
                 dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
                 ops.conv2d_dgrad(dz, cout, self.P.op_vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2)
                 dcur = dprev
+                if i == 4 and params and c["attn"]:          # d attn_disc = sum over the copies of each sample; then its branch
+                    B = self._attn_B
+                    da = A.get(f"d/bwd/dattn/{B}", (B, h, h, cin), self.gdt)
+                    ops.sum_groups(dprev, da, n, h * h * cin, B, 0)
+                    self.attn.backward(da)
         return dcur if need_dx else None
 
     def backward_params(self, drf, dcls):
         """D-loss backward over the whole D batch: fills the flat weight gradient."""
         self._backward(self.ctx["n"], drf, dcls, True, False)
+        if self.attn is not None:              # the attention biases were accumulated in f64
+            ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.P.n - self.acc_off, 0)
 
     def backward_input(self, n, drf):
         """G-loss backward (data gradient only) through the first n samples."""
@@ -639,6 +794,9 @@ class Discriminator(_ModelBase):
         """Same, but stops at the first layer's pre-activation gradient dz [n,S/2,S/2,F]: the step only needs the
         r+g+b sum of the image gradient, which ops.conv3x3_dgrad_sum1 forms from dz (no 64->3 dgrad)."""
         return self._backward(n, drf, None, False, "dz")
+
+    def attention_masks(self):
+        return [(self.attn.ctx[k] > 0).cpu().numpy() for k in ("y1", "y2")]
 
     def lrelu_masks(self):
         """Sign pattern of the 6 LeakyReLU outputs of the last forward (5 convs + patch logits)."""

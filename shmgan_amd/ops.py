@@ -349,6 +349,20 @@ def spec_loss(cyc_y, cbcr, ds_ptrs, mask, loss, batch, npix):
           "shm_spec_loss")
 
 
+# ---- live attention branch --------------------------------------------------------------------------
+def mask_pool_pack(mask, dst, batch, s, k):
+    """MaxPooling2D(k) of mask [batch,s,s,1] into channel 0 of the activation tensor dst [batch,s/k,s/k,ld]."""
+    check(lib().shm_mask_pool_pack(_p(mask), _p(dst), dst.shape[-1], batch, s, k, _dt(dst), _stream()), "shm_mask_pool_pack")
+
+
+def add_bcast(a, b, out, nimg, per, nb, i0=0):
+    check(lib().shm_add_bcast(_p(a), _p(b), _p(out), nimg, per, nb, i0, _dt(a), _stream()), "shm_add_bcast")
+
+
+def sum_groups(src, dst, nimg, per, nb, i0=0, accumulate=False):
+    check(lib().shm_sum_groups(_p(src), _p(dst), nimg, per, nb, i0, int(accumulate), _dt(src), _stream()), "shm_sum_groups")
+
+
 # ---- input pipeline ------------------------------------------------------------------------------
 def resize_bilinear_u8(src_u8, dst, scale=1.0 / 255.0, flip_ud=False):
     """src_u8 [hin,win,c] uint8 device tensor -> dst [ho,wo,c] float32 (tf.image.resize bilinear, then * scale)."""

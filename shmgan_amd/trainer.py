@@ -64,10 +64,16 @@ _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32
 
 
 class ShmGANwithSSpecSeg:
-    def __init__(self, args=None, device=None, compute_dtype="float32", grad_dtype=None, **overrides):
+    def __init__(self, args=None, device=None, compute_dtype="float32", grad_dtype=None, attention="executed", **overrides):
         """compute_dtype: "float32" (the reference's precision: exact-fp32 MFMA) or "bfloat16" (BASELINE
         configs 4-5: activations and MFMA operands in bf16, fp32 accumulation, fp32 master weights,
-        statistics, losses, weight gradients and Adam)."""
+        statistics, losses, weight gradients and Adam).
+        attention: "executed" (default) = the graph the reference runs: attention_layer is evaluated once on a constant zero
+        mask at build time, so the skips get + 0 (SURVEY finding 3); "live" = the architecture as intended: every step's
+        SpecSeg mask goes through attention_layer (MaxPool -> 2 x Conv3x3 + LeakyReLU, SHM.py:404-412) into the four
+        generator skips (SHM.py:290-293) and the discriminator (SHM.py:359), its 10 convolutions are trained."""
+        assert attention in ("executed", "live")
+        self.attention = attention
         self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
         # gradient-signal tensors between an input-gradient product and the next IN/LeakyReLU backward:
         # default = compute_dtype; "float32" with bf16 compute selects SHM_BF16_GF32 (include/shmgan_hip.h)
@@ -133,12 +139,13 @@ class ShmGANwithSSpecSeg:
     def build_generator(self):
         """SHM.py:228-327."""
         return Generator(self.image_size, self.filter_size, self.device, self.arena, self._workspace, self._get_lane(),
-                         dtype=self.compute_dtype, grad_dtype=self.grad_dtype)
+                         dtype=self.compute_dtype, grad_dtype=self.grad_dtype, attention=self.attention == "live")
 
     def build_discriminator(self):
         """SHM.py:343-380."""
         return Discriminator(self.image_size, self.filter_size, self.device, self.arena, self._workspace,
-                             self.dropout_amnt, self._get_lane(), dtype=self.compute_dtype, grad_dtype=self.grad_dtype)
+                             self.dropout_amnt, self._get_lane(), dtype=self.compute_dtype, grad_dtype=self.grad_dtype,
+                             attention=self.attention == "live")
 
     def build_specseg(self):
         """SHM.py:930-931: SpecSeg(image_size, image_size, 1) then load_model('specsegv3_chkpt.h5').  The
@@ -146,22 +153,33 @@ class ShmGANwithSSpecSeg:
         Keras weights with `self.SpecSeg.set_weights(keras_model.get_weights())`."""
         return SpecSeg(self.image_size, self.device, self.arena).init_random()
 
-    def build(self, seed=42, beta_seed=43):
+    def build(self, seed=42, beta_seed=43, attention_seed=45):
         """Build G, D and SpecSeg and give G/D the synthetic init of SURVEY 8(d): weights N(0,0.02) from
-        default_rng(seed) (RandomNormal(0,0.02), SHM.py:200), biases 0, IN beta N(0,0.02)."""
+        default_rng(seed) (RandomNormal(0,0.02), SHM.py:200), biases 0, IN beta N(0,0.02); the live attention branch's
+        kernels N(0,0.02) from default_rng(attention_seed), generator levels first, then the discriminator's."""
         self.G = self.build_generator()
         self.D = self.build_discriminator()
         if self.SpecSeg is None:
             self.SpecSeg = self.build_specseg()
         rng = np.random.default_rng(seed)
+        ng, nd = 2 * len(self.G.layers), 7
         gw = [np.zeros(s, np.float32) if len(s) == 1 else rng.normal(0.0, 0.02, s).astype(np.float32)
-              for s in self.G.P.shapes]
-        dw = [rng.normal(0.0, 0.02, s).astype(np.float32) for s in self.D.P.shapes]
+              for s in self.G.P.shapes[:ng]]
+        dw = [rng.normal(0.0, 0.02, s).astype(np.float32) for s in self.D.P.shapes[:nd]]
+        if self.attention == "live":
+            arng = np.random.default_rng(attention_seed)
+            ga = [(arng.normal(0.0, 0.02, s) if len(s) == 4 else np.zeros(s)).astype(np.float32) for s in self.G.P.shapes[ng:]]
+            da = [(arng.normal(0.0, 0.02, s) if len(s) == 4 else np.zeros(s)).astype(np.float32) for s in self.D.P.shapes[nd:]]
+            self.G.P.load(gw + ga)
+            self.D.P.load(dw + da)
+            self.G.weights_dirty = self.D.weights_dirty = True
+            gw = dw = None
         brng = np.random.default_rng(beta_seed)
         gb = [brng.normal(0.0, 0.02, (c,)).astype(np.float32) for c in self.G.in_channels]
         db = [brng.normal(0.0, 0.02, (c,)).astype(np.float32) for c in self.D.chan[1:]]
-        self.G.set_weights(gw)
-        self.D.set_weights(dw)
+        if gw is not None:
+            self.G.set_weights(gw)
+            self.D.set_weights(dw)
         self.G.set_betas(gb)
         self.D.set_betas(db)
         return self
@@ -255,11 +273,18 @@ class ShmGANwithSSpecSeg:
         lane.submit(lambda: box.__setitem__("mask", self.SpecSeg.forward_plane(ds[2], 3, 0, B, tag="specseg/step")))
         self.specular_candidate = box["mask"]
 
+        # ---- live attention branch: the maps of this step's mask, shared by the six G calls and the twelve D calls
+        attn_g = attn_d = None
+        if self.attention == "live":
+            lane.join()                                    # the mask comes from the second stream
+            attn_g = G.attention_forward(self.specular_candidate, B)
+            attn_d = D.attention_forward(self.specular_candidate, B)
+
         # ---- G(1)  SHM.py:517-538
         adt, PAD_C = self.compute_dtype, self.pad
         gen_in = A.get("g1/in", (B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, None, fmask, 0, gen_in, B, npix)
-        gen_Y = G.forward(gen_in, "g1")
+        gen_Y = G.forward(gen_in, "g1", attn=attn_g)
 
         # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
         xd = A.get("d/x16", (12 * B, S, S, PAD_C), adt)
@@ -269,7 +294,7 @@ class ShmGANwithSSpecSeg:
         # ---- G(2): cyclic  SHM.py:576-624
         cyc_in = A.get("cyc/in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, gen_Y, fmask, 1, cyc_in, B, npix)
-        cyc_Y = G.forward(cyc_in, "cyc")
+        cyc_Y = G.forward(cyc_in, "cyc", attn=attn_g)
         cyc_rgb = A.get("cyc/rgb", (5 * B, S, S, 3))
         ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, xd[B:6 * B], 5 * B, B, npix)
         ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
@@ -277,7 +302,7 @@ class ShmGANwithSSpecSeg:
             ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
 
         # ---- D on all 12B images (noise + dropout on the D1 and D2 slices only)
-        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)])
+        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)], attn=attn_d)
         np_ = (S // 32) ** 2
 
         # ---- losses  SHM.py:669-844
@@ -331,6 +356,8 @@ class ShmGANwithSSpecSeg:
                 for lo, hi in plan.get(li, ()):
                     self._allreduce_async(G.P.grad[lo:hi], after=lane.event())
         G.backward(dgen_y, "g1", need_dx=False, on_wgrad=on_wgrad)
+        if attn_g is not None:
+            G.attention_backward()                      # the skip gradients of both passes, summed per sample
         G.finish_grads()
         lane.join()                             # all weight gradients (both models) are complete
         if reduce_g:
@@ -472,13 +499,14 @@ class ShmGANwithSSpecSeg:
         adt, PAD_C = self.compute_dtype, self.pad
         gen_in = A.get("inf/in", (B, S, S, PAD_C), adt)
         ops.build_gen_input(ys, None, 0b11110, 0, gen_in, B, npix)          # views 1..4 zero, one-hot = ED
-        gen_Y = G.forward(gen_in, "inf1")
+        attn = G.attention_forward(self.specular_candidate, B) if self.attention == "live" else None
+        gen_Y = G.forward(gen_in, "inf1", attn=attn)
         gen_rgb = A.get("inf/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, None, gen_rgb, None, B, B, npix)
         orig_Ych = gen_rgb[..., 0:1].contiguous()              # test.py:252
         cyc_in = A.get("inf/cyc_in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ys, orig_Ych, 0b11111, 1, cyc_in, B, npix)      # view k zero, the others = orig_Ych
-        cyc_Y = G.forward(cyc_in, "inf5")
+        cyc_Y = G.forward(cyc_in, "inf5", attn=attn)
         cyc_rgb = A.get("inf/cyc_rgb", (5 * B, S, S, 3))
         ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, None, 5 * B, B, npix)
         self.gen_input, self.gen_Y, self.gen_rgb = gen_in, gen_Y, gen_rgb

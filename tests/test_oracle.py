@@ -282,3 +282,38 @@ def test_dataset_listing_is_sorted_and_filtered(tmp_path):
     for name in ("b_10.png", "a_2.PNG", "a_10.jpg", "notes.txt", "c.bmp"):
         (tmp_path / name).write_bytes(b"x")
     assert [p.split("/")[-1] for p in list_images(tmp_path)] == ["a_10.jpg", "a_2.PNG", "b_10.png", "c.bmp"]
+
+
+def test_live_attention_oracle_properties():
+    """oracle.step_torch.train_step(attention=...): zero attention variables reproduce the executed graph exactly; the
+    attention gradients agree with central finite differences of the generator / discriminator objectives."""
+    from oracle import specseg_torch as sp
+    S, F, B = 64, 8, 1
+    g, d, gb, db = st.init_params(F, S)
+    inp, dr, sf = st.make_inputs(B, S), st.make_draws(0, B, S, F), st.style_factor_intended(S)
+    sw = sp.init_specseg(seed=44)
+    att = st.init_attention(F, bias_std=0.05)
+    base = st.train_step(g, d, gb, db, inp, dr, sf, F, specseg=sw, need_grads=False)
+    zero = {k: [np.zeros_like(a) for a in v] for k, v in att.items()}
+    rz = st.train_step(g, d, gb, db, inp, dr, sf, F, specseg=sw, attention=zero, need_grads=False)
+    assert all(rz["losses"][k] == base["losses"][k] for k in base["losses"])
+    r = st.train_step(g, d, gb, db, inp, dr, sf, F, specseg=sw, attention=att)
+    assert len(r["gGa"]) == 16 and len(r["gDa"]) == 4
+
+    def objective(a, which):
+        out = st.train_step(g, d, gb, db, inp, dr, sf, F, specseg=sw, attention=a, need_grads=False)["losses"]
+        return out["total_Generator_loss"] if which == "G" else out["total_Discriminator_loss"] + out["total_Classification_loss"]
+
+    rng = np.random.default_rng(0)
+    eps = 1e-5
+    for which, key, grads in (("G", "G", r["gGa"]), ("D", "D", r["gDa"])):
+        dirs = [rng.standard_normal(v.shape) * (np.abs(v).max() + 1e-3) for v in att[key]]
+        ap = {k: [x.astype(np.float64).copy() for x in v] for k, v in att.items()}
+        am = {k: [x.astype(np.float64).copy() for x in v] for k, v in att.items()}
+        for i, u in enumerate(dirs):
+            ap[key][i] += eps * u
+            am[key][i] -= eps * u
+        fd = (objective(ap, which) - objective(am, which)) / (2 * eps)
+        an = sum(float((gr.numpy() * u).sum()) for gr, u in zip(grads, dirs))
+        # the loss has kinks (|.| in L1, LeakyReLU, min/max): a finite step crosses a few of them
+        assert abs(fd - an) <= 1e-2 * max(abs(an), 1e-6), (which, fd, an)
