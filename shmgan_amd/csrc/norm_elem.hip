@@ -46,6 +46,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"wgrad.variant", "SHM_WGRAD_VARIANT", 0, 0, 2},
     {"wgrad.blocks", "SHM_WGRAD_BLOCKS", 0, 0, 1 << 20},
     {"stats.fusion", "SHM_STATS_FUSION", 1, 0, 1},
+    {"elem.reverse", "SHM_ELEM_REVERSE", 1, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -261,13 +262,18 @@ extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, in
     return SHM_OK;
 }
 
+// rev: walk the tensor back to front.  The producing convolution wrote the samples in ascending order, so the LAST ones are
+// still in the 256 MiB Infinity Cache: reading them first turns up to 256 MiB of this pass's reads into cache hits (front to
+// back, an LRU cache smaller than the tensor yields none), and it leaves sample 0 written last -- where the
+// consuming convolution starts.
 template <typename T>
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
-                                                       T* __restrict__ out, int ldo, int hw, int c, int chunk) {
+                                                       T* __restrict__ out, int ldo, int hw, int c, int chunk, int rev) {
     PixMap pm(c);
     if (!pm.active) return;
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
+    const int n = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int p0 = bx * chunk, p1 = min(hw, p0 + chunk);
     float mean[4], inv[4], bt[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -310,7 +316,7 @@ extern "C" int shm_in_apply(const void* a, int lda, const double* stats, const f
     int chunk = shm_cdiv(hw, nch);
     SHM_DISPATCH(dtype, "shm_in_apply",
                  hipLaunchKernelGGL(in_apply_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats, beta,
-                                    (T*)out, ldo, hw, c, chunk));
+                                    (T*)out, ldo, hw, c, chunk, shm_tune(SHM_TUNE_ELEM_REVERSE)));
     SHM_LAUNCH_CHECK("shm_in_apply");
     return SHM_OK;
 }
@@ -327,6 +333,7 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     int ldg1, ldg2, lda, lddz;
     int h, w, c, chunk;
     float slope;
+    int rev;
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -345,11 +352,15 @@ __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, i
     return g;
 }
 
+// The reduce pass walks the tensor back to front when k.rev is set (the input-gradient product that wrote g1 went front to back:
+// its last samples are still in the Infinity Cache), the apply pass that follows front to back again (it starts where the
+// reduce pass ended).
 template <typename T, typename TG, bool G2>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
-    const int n = blockIdx.y, hw = k.h * k.w;
-    const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    const int n = k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, hw = k.h * k.w;
+    const int bx = k.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int p0 = bx * k.chunk, p1 = min(hw, p0 + k.chunk);
     double v[2][4] = {};
     if (pm.active) {
         float mean[4], inv[4];
@@ -489,7 +500,7 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
     // `red` is zero on entry by contract and zero again on return (no memset in front of every launch)
-    InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope};
+    InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, shm_tune(SHM_TUNE_ELEM_REVERSE)};
     int hw = h * w;
     int nch = pix_chunks(hw, batch, c);
     k.chunk = shm_cdiv(hw, nch);
