@@ -62,7 +62,8 @@ const char* shm_last_kernel(void);
  * process-wide integer knobs override that choice (parity tests force every variant; tools sweep them):
  *   "tapgemm.variant"           0 automatic (default), or one of SHM_TG_*: a forced variant the shape is not
  *                               eligible for makes the conv call return SHM_E_SHAPE (it never falls back silently)
- *   "tapgemm.halo_min_blocks"   fp32: smallest grid that takes the 16x16-patch halo kernel (default 1024)
+ *   "tapgemm.halo_min_blocks"   fp32: from this many 128-channel halo blocks on the 128-wide halo block is taken without comparing
+ *                               the fill of its last round with the 64-wide block's (default 1024)
  *   "tapgemm.small_grid_blocks" grids with fewer 128x128 tiles take the 64x128 tile (default 1024)
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 512 bf16)
@@ -84,6 +85,8 @@ const char* shm_last_kernel(void);
 #define SHM_TG_HALO128_PH8 8
 #define SHM_TG_DMA_128x128_BK32 9
 #define SHM_TG_DMA_128x128_NST4 10
+#define SHM_TG_HALO128_ST 12            /* halo kernels with the nine taps unrolled: static fragment addresses, conflict-free swizzle */
+#define SHM_TG_HALO64_ST 13
 #define SHM_TG_WREG 11                 /* bf16, 3x3 s1, <= 64 input channels: weights in registers, persistent blocks */
 int shm_set_tuning(const char* key, int value);
 int shm_get_tuning(const char* key, int* value);

@@ -20,7 +20,7 @@ void shm_set_last_kernel(const char* fmt, ...);        // symbol of the MFMA ker
 // norm_elem.hip (so tools/ablate_conv.py keeps working), -1/0 = the built-in choice.
 enum ShmTune {
     SHM_TUNE_TAPGEMM_VARIANT = 0,     // SHM_TG_* below; 0 = automatic
-    SHM_TUNE_TAPGEMM_HALO_MIN,        // fp32: smallest grid (blocks) that takes the 16x16-patch halo kernel
+    SHM_TUNE_TAPGEMM_HALO_MIN,        // fp32: 128-wide halo blocks from which the 128-wide block is taken unconditionally
     SHM_TUNE_TAPGEMM_SMALL_GRID,      // grids below this many 128x128 tiles take the 64x128 tile
     SHM_TUNE_WGRAD_VARIANT,           // 0 = automatic, 1 = generic kernel only, 2 = halo kernel but no thin-input packing
     SHM_TUNE_WGRAD_BLOCKS,            // split-K target (blocks), 0 = automatic
@@ -30,7 +30,7 @@ enum ShmTune {
 };
 int shm_tune(int id);
 
-#define SHM_TG_COUNT 12           // SHM_TG_* of include/shmgan_hip.h
+#define SHM_TG_COUNT 14           // SHM_TG_* of include/shmgan_hip.h
 
 // 4-channel vector access in either element type; arithmetic is always fp32.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }

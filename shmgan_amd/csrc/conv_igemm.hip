@@ -346,8 +346,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // applied on the DMA source side; halo pixels outside the image use offset 0xffffffff (zeros).
 // PH = patch height (16 or 8 pixel rows of 16): M = PH*16 rows, PH/4 row-waves.  PH = 8 halves the A stages
 // (3 four-wave blocks per CU instead of 2 eight-wave ones: smaller barrier groups) at 11 % more halo traffic.
-template <typename T, typename TO, int BN, int PH = 16>
-__global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemmArgs a) {
+// ST (round 2): the nine taps of a chunk are unrolled, which makes every fragment address a patch- and chunk-independent
+// register (one per (tap, tile); the second k group is an XOR, the B stage an immediate) -- no address arithmetic between the
+// barrier and the first ds_read of a K step -- and lets the halo use the conflict-free swizzle ((R >> 1) + R / 18) & 3 that
+// cost 3 % when its arithmetic sat on that path.
+template <typename T, typename TO, int BN, int PH = 16, bool ST = false>
+__global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
     constexpr int WGM = PH / 4, WGN = BN / 64, NW = WGM * WGN;          // waves: (PH/4) (M) x (BN/64) (N)
     constexpr int HC = 18, NIT = PH == 16 ? 24 : 12;  // halo (PH+2) x 18 rows, padded to NIT DMA items of 16 rows
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
         const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
         const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
         const int pix = (img * a.hi + iy) * a.wi + ix;
-        const int coff = (dq ^ ((hrow >> 2) & 3)) * CHE;
+        const int coff = (dq ^ (ST ? ((hrow >> 1) + hr) & 3 : (hrow >> 2) & 3)) * CHE;
         arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * (unsigned)ESZ : 0xffffffffu;
         arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * (unsigned)ESZ : 0xffffffffu;
     }
@@ -491,6 +495,50 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
     dma_a(0);
     dma_b();
     if (ksteps > 1) dma_b();
+    if constexpr (ST) {
+        // fragment addresses of the nine taps (floats, relative to the A stage): registers for the whole block
+        int fs[9][2];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hrow = hb[i] + P.dh[t] * HC + P.dw[t];
+                fs[t][i] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);        // k group 1: this address ^ 8
+            }
+        typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+        const unsigned sA_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)sA;
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            // LDS byte address of the A stage: the k-group-1 address is formed as (stage + offset) ^ 32 inside the chunk loop,
+            // so that the compiler keeps 18 address registers, not 36 (the stage base is a multiple of 64 bytes)
+            const unsigned Ab = sA_lds + (unsigned)((chunk & 1) * ASTG * 4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // B(s) (and, in order before it, the halo of this chunk) must have landed; issued after B(s): B(s+1),
+                // preceded by the A items of step s-1 if that step opened a chunk
+                if (tap == 8 && chunk + 1 == nch)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (tap == 1 && chunk + 1 < nch)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
+                if (tap < 7 || chunk + 1 < nch) dma_b();
+                const float* Bb = sB + (tap % 3) * BSTG + wn * 64 * 16;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    f32x4 av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[i] = *(lds_f4)(size_t)((Ab + (unsigned)(fs[tap][i] << 2)) ^ (unsigned)(kk << 5));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+                    tap_mfma<T, 2, 2>(av, bv, acc);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    } else {
     int tap = 0, chunk = 0, bst = 0;
     for (int s = 0; s < ksteps; ++s) {
         // B(s) (and, in order before it, the halo of this chunk) must have landed.  Issued after B(s):
@@ -518,6 +566,7 @@ __global__ __launch_bounds__(BN * PH / 4) void tapgemm_halo_kernel(const TapGemm
             tap = 0;
             ++chunk;
         }
+    }
     }
 
     // ---- epilogue: bias + LeakyReLU + store (+ InstanceNorm statistics)
@@ -1073,25 +1122,32 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                            (a.y2 == nullptr || a.y2bytes != 0) && a.slope >= 0.f && a.slope <= 1.f && a.nout % 64 == 0 && a.n1 % 16 == 0;
     int v = forced;
     if (v == SHM_TG_AUTO) {
-        // 2 blocks of 8 waves per CU = 512 slots: below ~2 rounds the coarser (256-row) tiles lose more to
-        // grid quantization than the halo reuse gains in fp32 (measured: 32x32 maps 113 vs 133 TFLOP/s).
-        // In bf16 the halo's 6.4x cut in A-operand traffic matters everywhere.
-        const long nblk = (long)batch * (a.hi / 16) * (a.wi / 16) * shm_cdiv(a.nout, 128);
         const long tiles128 = (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase;
-        if (wreg_ok || wreg32_ok)
+        if (wreg_ok || wreg32_ok) {
             v = SHM_TG_WREG;
-        else if (halo_ok && a.nout <= 64 && sizeof(T) == 2)
-            v = SHM_TG_HALO64;                  // fp32: the 4-wave 64-channel halo block measures like the 128x64 DMA tile
-        else if (halo_ok && a.nout > 64 && (sizeof(T) == 2 || nblk >= shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)))
-            v = SHM_TG_HALO128;
-        else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID))
-            // small grids (the n = 8 G(1) pass, 16x16 maps): 64-row tiles double the number of blocks, so a CU holds
-            // two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
+        } else if (halo_ok) {
+            // The static-tap halo kernels beat the DMA tiles on every unit-stride 3x3 layer they can take, small grids included
+            // (round-2 A/B, tools/bench_variants.py: fp32 n = 8 maps 120-134 vs 107-121 TFLOP/s).  128 or 64 output channels per
+            // block: the 128-wide block is ~3 % faster when both fill the chip, but it has half the blocks -- two 8-wave (or
+            // 4-wave) blocks fit a CU, i.e. 512 slots -- so below two rounds the choice goes by how full the last round is.
+            const long np16 = (long)batch * (a.hi / 16) * (a.wi / 16);
+            const long nb128 = np16 * shm_cdiv(a.nout, 128), nb64 = np16 * shm_cdiv(a.nout, 64);
+            auto fill = [](long nb) { return (double)nb / (double)(((nb + 511) / 512) * 512); };
+            if (a.nout <= 64)
+                v = SHM_TG_HALO64_ST;
+            else if (sizeof(T) == 2 || nb128 >= shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN) || fill(nb128) * 1.03 >= fill(nb64))
+                v = SHM_TG_HALO128_ST;
+            else
+                v = SHM_TG_HALO64_ST;
+        } else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID)) {
+            // small grids (16x16 maps, the n = 8 pass of the stride-2 / transposed layers): 64-row tiles double the number of
+            // blocks, so a CU holds two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
             v = SHM_TG_DMA_64x128;
-        else if (a.nout > 64)
+        } else if (a.nout > 64) {
             v = SHM_TG_DMA_128x128;
-        else
+        } else {
             v = SHM_TG_DMA_128x64;
+        }
     }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     const int npatch = batch * (a.hi / 16) * (a.wi / 16);
@@ -1105,6 +1161,16 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64 needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16>", tn, ton);
+        break;
+    case SHM_TG_HALO128_ST:
+        SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
+        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true>", tn, ton);
+        break;
+    case SHM_TG_HALO64_ST:
+        SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
+        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16, true>", tn, ton);
         break;
     case SHM_TG_HALO128_PH8:
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in

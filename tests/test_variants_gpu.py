@@ -29,8 +29,9 @@ SYMBOL = {
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
     "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
+    "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true>",
 }
-HALO = ["halo128", "halo64"]
+HALO = ["halo128", "halo64", "halo128_st", "halo64_st"]
 DMA = ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
 
 
@@ -284,15 +285,16 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
 # reference convolutions take a few seconds each on the GPU box's host cores.
 # ======================================================================================================
 def test_default_dispatch_fp32_halo128_on_a_generator_layer():
-    """Generator conv2d_5 (128 -> 128 at 128 x 128).  At the G(1) batch n = 8 the grid is 512 halo blocks / 1024 DMA tiles:
-    below the halo threshold, so the 128x128 DMA tile takes it; n = 16 reaches the halo kernel; n = 4 the 64x128 tile."""
+    """Generator conv2d_5 (128 -> 128 at 128 x 128) through the default dispatch: n = 4 is 256 128-wide halo blocks (half a
+    round of the chip) against 512 64-wide ones -> the 64-wide static-tap halo block; n = 8 (the G(1) batch, one full round)
+    and n = 16 -> the 128-wide one."""
     ops = _ops()
     rng = np.random.default_rng(21)
     h, cin, cout = 128, 128, 128
     w = rng.standard_normal((3, 3, cin, cout)) * 0.05
     b = rng.standard_normal(cout) * 0.1
     wk = _wk(w, cin, "f32")
-    for n, sym in ((4, "dma64x128"), (8, "dma128x128"), (16, "halo128")):
+    for n, sym in ((4, "halo64_st"), (8, "halo128_st"), (16, "halo128_st")):
         x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
         ref = conv_ref(x, w.astype(np.float32), 1) + b
         ref = np.where(ref > 0, ref, 0.2 * ref)
@@ -309,7 +311,7 @@ def test_default_dispatch_fp32_halo128_on_a_generator_layer():
 
 def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     """dgrad of generator conv2d_24 at full resolution (n = 8, 256 x 256, 128 <- 64, the gradient split into its upsampled and
-    skip halves: K = 64 -> the weights-in-registers kernel, two N tiles), a 128 <- 128 dgrad at n = 16 (halo 128) and a
+    skip halves: K = 64 -> the weights-in-registers kernel, two N tiles), a 128 <- 128 dgrad at n = 16 (static-tap halo 128) and a
     discriminator block (64 -> 128, stride 2, n = 32: 1024 tiles -> DMA 128x128)."""
     ops = _ops()
     rng = np.random.default_rng(22)
@@ -332,7 +334,7 @@ def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     ref, = torch.autograd.grad(st.conv2d_same(xt, t64(w), 1), xt, nchw(dy))
     dx = torch.empty((n, h, h, c), device="cuda")
     ops.conv2d_dgrad(_dev(dy, "f32"), c, _dev(w, "f32"), dx, None, c, c, 0, n, h, h, c, c, 3, 1)
-    assert ops.last_kernel() == _sym("halo128", "f32"), ops.last_kernel()
+    assert ops.last_kernel() == _sym("halo128_st", "f32"), ops.last_kernel()
     assert rel_l2(host(dx), nhwc(ref.detach())) < 1e-5
     del ref, xt
     n, h, cin, cout = 32, 128, 64, 128
