@@ -408,6 +408,109 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     block_reduce_atomic<2>(v, pm, k.red + (size_t)n * k.c * 2, k.c, true);
 }
 
+// bf16 form of the reduce pass with EIGHT channels (16 bytes) per thread: with four (8-byte loads) the pass reached 2.2-2.8 TB/s
+// where its fp32 twin, whose four channels are 16 bytes, reaches 4.0 (rocprofv3, profiles/r02_*): the loads per wave are what
+// limits a read-only stream.  Same sums, same scratch layout as in_bwd_reduce_kernel.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 ld8(const bf16_t* p) {
+    const uint4 u = *(const uint4*)p;
+    f32x8 r;
+    r[0] = __uint_as_float(u.x << 16);
+    r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16);
+    r[3] = __uint_as_float(u.y & 0xffff0000u);
+    r[4] = __uint_as_float(u.z << 16);
+    r[5] = __uint_as_float(u.z & 0xffff0000u);
+    r[6] = __uint_as_float(u.w << 16);
+    r[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ f32x8 ld8(const float* p) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <typename TG, bool G2>
+__global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) {
+    __shared__ double red[256 * 8];
+    const int lanes_c = k.c >> 3, PP = 256 / lanes_c;
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
+    const bool active = pp < PP;
+    const int n = k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, hw = k.h * k.w;
+    const int bx = k.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int p0 = bx * k.chunk, p1 = min(hw, p0 + k.chunk);
+    double v[2][8] = {};
+    if (active) {
+        float mean[8], inv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mean[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2];
+            inv[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2 + 1];
+        }
+        auto dout = [&](int p) {
+            f32x8 g = ld8((const TG*)k.g1 + ((size_t)n * hw + p) * k.ldg1 + cl * 8);
+            if constexpr (G2) {
+                const int y = p / k.w, x = p - y * k.w;
+                const size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
+                const f32x8 u = ld8((const TG*)k.g2 + q * k.ldg2 + cl * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += 0.25f * u[e];
+            }
+            return g;
+        };
+        constexpr int U = 4;
+        int p = p0 + pp;
+        for (; p + (U - 1) * PP < p1; p += U * PP) {
+            f32x8 g[U], x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                g[u] = dout(p + u * PP);
+                x[u] = ld8((const bf16_t*)k.a + ((size_t)n * hw + p + u * PP) * k.lda + cl * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sg = 0.f, sx = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float xh = (x[u][e] - mean[e]) * inv[e];
+                    sg += g[u][e];
+                    sx += g[u][e] * xh;
+                }
+                v[0][e] += (double)sg;
+                v[1][e] += (double)sx;
+            }
+        }
+        for (; p < p1; p += PP) {
+            const f32x8 g = dout(p);
+            const f32x8 x = ld8((const bf16_t*)k.a + ((size_t)n * hw + p) * k.lda + cl * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (x[e] - mean[e]) * inv[e];
+                v[0][e] += (double)g[e];
+                v[1][e] += (double)g[e] * (double)xh;
+            }
+        }
+    }
+    // combine over the PP pixel slots, then one atomic per (channel, value): red[(n*c + ch)*2 + q]
+    double* dst = k.red + (size_t)n * k.c * 2;
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(pp * lanes_c + cl) * 8 + e] = v[q][e];
+        }
+        __syncthreads();
+        if (active && pp == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double s = 0.0;
+                for (int t = 0; t < PP; ++t) s += red[(t * lanes_c + cl) * 8 + e];
+                atomicAdd(&dst[(cl * 8 + e) * 2 + q], s);
+            }
+        }
+    }
+}
+
 template <typename T, typename TG, bool G2>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
@@ -505,7 +608,23 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     int nch = pix_chunks(hw, batch, c);
     k.chunk = shm_cdiv(hw, nch);
     dim3 grid(shm_cdiv(hw, k.chunk), batch);
-    if (g2) {
+    // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
+    const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && (!g2 || ldg2 % 8 == 0) &&
+                       256 / (c / 8) >= 1;
+    if (wide8) {
+        if (dtype == SHM_BF16) {
+            if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, true>), grid, dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, false>), grid, dim3(256), 0, st, k);
+        } else {
+            if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, true>), grid, dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false>), grid, dim3(256), 0, st, k);
+        }
+        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+        if (g2)
+            SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+        else
+            SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+    } else if (g2) {
         SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
         SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
         SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
