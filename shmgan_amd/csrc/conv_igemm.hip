@@ -275,6 +275,62 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    // bf16 outputs (round 2): as in the halo kernels the wave's tile goes through LDS (free once every wave is past its last
+    // fragment read) and leaves as 16-byte stores -- the accumulator layout gives a lane one 2-byte element per row, i.e.
+    // TM*TN*16 two-byte store instructions per wave.  Works for the strided (four-phase) outputs too: a pixel's channels are
+    // contiguous whatever the pixel stride.
+    constexpr bool kWide = sizeof(TO) == 2 && WTM * WTN * 2 * NW <= NST * STAGE * 4;
+    const bool wide = kWide && (a.nout % 8 == 0) && (a.n1 % 8 == 0) && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0) &&
+                      (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0)));
+    if constexpr (kWide) if (wide) {
+        constexpr int CW = WTN / 8;                      // 16-byte chunks per tile row
+        constexpr int RPW = 64 / CW;                     // tile rows per store instruction
+        __syncthreads();
+        unsigned short* tile = (unsigned short*)smem + wave * (WTM * WTN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool mv = m0 + wm * WTM + row < a.M;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 32 + l31;
+                    float v = acc[i][j][r];
+                    if (a.bias && n < a.nout) v += a.bias[n];
+                    const TO vo = (TO)shm_lrelu(v, a.slope);
+                    v = (mv && n < a.nout) ? (float)vo : 0.f;          // statistics of the value as stored
+                    s1[j] += v;
+                    s2[j] += v * v;
+                    const int col = j * 32 + l31;
+                    tile[row * WTN + ((((col >> 3) ^ (row & (CW - 1))) << 3) | (col & 7))] = __builtin_bit_cast(unsigned short, vo);
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
+        const int rr = lane / CW, ch = lane % CW;
+#pragma unroll
+        for (int it = 0; it < WTM / RPW; ++it) {
+            const int row = it * RPW + rr;
+            const u32x4 v = *(const u32x4*)(tile + row * WTN + ((ch ^ (row & (CW - 1))) << 3));
+            const int m = m0 + wm * WTM + row;
+            const int n = n0 + wn * WTN + ch * 8;
+            if (m < a.M && n < a.nout) {
+                size_t opix;
+                if (direct) {
+                    opix = (size_t)m;
+                } else {
+                    const int ow = m % a.wg, t = m / a.wg;
+                    const int oh = t % a.hg, ni = t / a.hg;
+                    opix = ((size_t)ni * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
+                }
+                if (n < a.n1)
+                    *(u32x4*)((unsigned short*)a.y + opix * a.ldy + n) = v;
+                else
+                    *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
+            }
+        }
+    }
+    if (!wide) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -307,6 +363,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 }
             }
         }
+    }
     }
     // InstanceNorm statistics of the tile just written: the 64 rows of a wave belong to one sample
     // (hw % 64 == 0), so one f64 atomic per (wave, column, moment).
