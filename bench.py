@@ -89,19 +89,22 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     inputs = [torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).to(dev) for _ in range(5)]
     s = S // 32
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7 + rank)
 
     class Draws:
         pass
+
+    noise_buf = torch.empty((2 * B, S, S, 3), device=dev)
+    keep_buf = torch.empty((2 * B, s, s, 16 * F), device=dev)
 
     def draws_for(step):
         r = np.random.default_rng(7 + step)              # flags / TARGET_LABELS shared by all ranks
         d = Draws()
         d.flags = tuple(bool(u < 0.5) for u in r.random(5))
         d.target_label = float(r.uniform(0.8, 1.2))
-        d.noise = torch.randn((2 * B, S, S, 3), device=dev, generator=gen) * 0.1
-        d.keep_mask = (torch.rand((2 * B, s, s, 16 * F), device=dev, generator=gen) >= 0.2).float()
+        # GaussianNoise / Dropout draws: the library's Philox kernels, keyed by (step, rank) -- part of the timed step
+        ops.randn(noise_buf, 0.1, 7 + step, 2 * rank)
+        ops.keep_mask(keep_buf, 0.2, 7 + step, 2 * rank + 1)
+        d.noise, d.keep_mask = noise_buf, keep_buf
         return d
 
     def sync():

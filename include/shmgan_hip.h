@@ -263,6 +263,12 @@ int shm_pack_rgb16(const float* rgb, const float* noise, void* dpad, int ldp, si
 int shm_rgb16_to_dy(const void* d16, int ld, float* dy, size_t npix_total, int accumulate, int dtype,
                     void* stream);
 
+/* Step-level random draws (GaussianNoise(0.1) SHM.py:352, Dropout(0.2) SHM.py:363): counter-based Philox-4x32-10, reproducible
+ * from (seed, stream_id) whatever the launch geometry.  out[n] ~ N(0, stddev^2);  mask[n] = 1 with probability 1 - rate, else 0
+ * (the keep mask shm_mul_mask multiplies by, scaled 1/(1-rate)). */
+int shm_randn(float* out, size_t n, float stddev, unsigned long long seed, unsigned stream_id, void* stream);
+int shm_keep_mask(float* out, size_t n, float rate, unsigned long long seed, unsigned stream_id, void* stream);
+
 /* ---- losses (SHM.py:669-844) ------------------------------------------------------
  * Discriminator-head losses and their gradients.  Sample order in the D batch:
  * [D1: B][D3: 5B, k-major][D2: B][D4: 5B, k-major].  rf [12B, np], cls [12B,5].

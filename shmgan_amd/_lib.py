@@ -63,6 +63,8 @@ SIGNATURES = {
     "shm_yuv2rgb": (I, [P, P, P, P, P, I, I, I, Z, I, P]),
     "shm_pack_rgb16": (I, [P, P, P, I, Z, I, P]),
     "shm_rgb16_to_dy": (I, [P, I, P, Z, I, I, P]),
+    "shm_randn": (I, [P, Z, F, C.c_ulonglong, C.c_uint, P]),
+    "shm_keep_mask": (I, [P, Z, F, C.c_ulonglong, C.c_uint, P]),
     "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, P]),
     "shm_image_losses_workspace": (Z, [I, I]),
     "shm_image_losses": (I, [P, P, P, P, P, P, I, F, P, P, P, P, Z, I, I, P]),

@@ -342,3 +342,76 @@ extern "C" int shm_adam_clip(float* w, float* m, float* v, const float* g, size_
     SHM_LAUNCH_CHECK("shm_adam_clip");
     return SHM_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Step-level random draws on the device (SHM.py:352 GaussianNoise(0.1), SHM.py:363 Dropout(0.2)): counter-based
+// Philox-4x32-10 (Salmon et al. 2011), one counter per group of four outputs, key = (seed, stream).  The reference draws
+// these inside Keras layers from TF's global generator; the values differ from any TF run by construction (the parity tests
+// inject explicit draws), the distributions are what the layers specify.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__global__ void randn_kernel(float* __restrict__ out, size_t n, float stddev, unsigned seed_lo, unsigned seed_hi, unsigned stream_id) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // group of four outputs
+    if (i * 4 >= n) return;
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), stream_id, 0u, seed_lo, seed_hi, r);
+    float v[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {                                              // Box-Muller on two pairs of uniforms in (0, 1]
+        const float u1 = ((float)(r[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(r[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * logf(u1)) * stddev;
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        v[2 * p] = rad * cs;
+        v[2 * p + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i * 4 + e < n) out[i * 4 + e] = v[e];
+}
+
+__global__ void keep_mask_kernel(float* __restrict__ out, size_t n, float rate, unsigned seed_lo, unsigned seed_hi, unsigned stream_id) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i * 4 >= n) return;
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), stream_id, 1u, seed_lo, seed_hi, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i * 4 + e < n) out[i * 4 + e] = (float)(r[e] >> 8) * (1.0f / 16777216.0f) >= rate ? 1.f : 0.f;
+}
+
+extern "C" int shm_randn(float* out, size_t n, float stddev, unsigned long long seed, unsigned stream_id, void* stream) {
+    SHM_REQUIRE(out || n == 0, SHM_E_SHAPE, "shm_randn: null pointer");
+    if (n == 0) return SHM_OK;
+    hipLaunchKernelGGL(randn_kernel, dim3(shm_cdiv((long)((n + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, out, n, stddev, (unsigned)seed,
+                       (unsigned)(seed >> 32), stream_id);
+    SHM_LAUNCH_CHECK("shm_randn");
+    return SHM_OK;
+}
+
+extern "C" int shm_keep_mask(float* out, size_t n, float rate, unsigned long long seed, unsigned stream_id, void* stream) {
+    SHM_REQUIRE(out || n == 0, SHM_E_SHAPE, "shm_keep_mask: null pointer");
+    SHM_REQUIRE(rate >= 0.f && rate < 1.f, SHM_E_SHAPE, "shm_keep_mask: rate %g outside [0,1)", (double)rate);
+    if (n == 0) return SHM_OK;
+    hipLaunchKernelGGL(keep_mask_kernel, dim3(shm_cdiv((long)((n + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, out, n, rate, (unsigned)seed,
+                       (unsigned)(seed >> 32), stream_id);
+    SHM_LAUNCH_CHECK("shm_keep_mask");
+    return SHM_OK;
+}

@@ -296,6 +296,16 @@ def rgb16_to_dy(d16, dy, npix_total, accumulate):
           "shm_rgb16_to_dy")
 
 
+def randn(out, stddev, seed, stream_id=0):
+    """out ~ N(0, stddev^2), Philox-4x32-10 keyed by (seed, stream_id)."""
+    check(lib().shm_randn(_p(out), out.numel(), stddev, int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id), _stream()), "shm_randn")
+
+
+def keep_mask(out, rate, seed, stream_id=0):
+    """out = 1 with probability 1 - rate else 0 (Dropout keep mask)."""
+    check(lib().shm_keep_mask(_p(out), out.numel(), rate, int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id), _stream()), "shm_keep_mask")
+
+
 def dhead_losses(rf, cls, loss, drf_d, dcls_d, drf_g, batch, np_, target):
     check(lib().shm_dhead_losses(_p(rf), _p(cls), _p(loss), _p(drf_d), _p(dcls_d), _p(drf_g), batch, np_, target,
                                  _stream()), "shm_dhead_losses")

@@ -112,6 +112,7 @@ class ShmGANwithSSpecSeg:
         # train_step overwrites it with SpecSeg.predict(I90_Ych) (SHM.py:492), which feeds Spec_loss only
         self.specular_candidate = None
         self._rng = np.random.default_rng(self.seed)
+        self._draw_count = 0
         self._reducer = GradReducer(self.device)
         self._loss_cache = None
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
@@ -211,11 +212,23 @@ class ShmGANwithSSpecSeg:
 
     # ------------------------------------------------------------------ draws
     def _default_draws(self, B):
+        """Fresh draws of a step: the five RNG flags (SHM.py:509-513) on the host; GaussianNoise(0.1) for the D1 / D2 inputs
+        (SHM.py:352) and the Dropout keep mask (SHM.py:363) on the device (shm_randn / shm_keep_mask: Philox keyed by the
+        trainer's seed, the step counter and the rank, so replicas draw different noise and agree on the flags)."""
         S, s = self.image_size, self.image_size // 32
         flags = tuple(bool(u < self.randomness) for u in self._rng.random(5))
-        noise = torch.randn((2 * B, S, S, 3), device=self.device) * 0.1
-        keep = (torch.rand((2 * B, s, s, 16 * self.filter_size), device=self.device) >= self.dropout_amnt).float()
+        noise = self.arena.get("draws/noise", (2 * B, S, S, 3))
+        keep = self.arena.get("draws/keep", (2 * B, s, s, 16 * self.filter_size))
+        self._draw_count += 1
+        seed = (self.seed << 32) | (self._draw_count & 0xFFFFFFFF)
+        ops.randn(noise, 0.1, seed, 2 * self._rank())
+        ops.keep_mask(keep, self.dropout_amnt, seed, 2 * self._rank() + 1)
         return SimpleNamespace(flags=flags, target_label=float(self.TARGET_LABELS), noise=noise, keep_mask=keep)
+
+    @staticmethod
+    def _rank():
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
     def _dev(self, t):
         if isinstance(t, np.ndarray):

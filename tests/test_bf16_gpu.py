@@ -378,3 +378,24 @@ def test_bf16_training_reduces_the_loss_like_fp32():
     assert np.isfinite(curves["bfloat16"]).all()
     assert np.abs(curves["bfloat16"] / curves["float32"] - 1).max() < 5e-2
     assert curves["bfloat16"][-1] < curves["bfloat16"][0]
+
+
+def test_config4_image_size_512_runs_and_tracks_fp32():
+    """BASELINE configs[3] geometry (S=512, bf16) at B=1: finite named losses, and within 2e-2 of the fp32 run of the same step
+    (the batch of 4 is the bench's; rocprofv3 evidence for it: profiles/r02_s512_b4_bf16_*)."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 512, 64, 1
+    inp, dr = st.make_inputs(B, S), st.make_draws(6, B, S, F)
+    res = {}
+    for dt in ("bfloat16", "float32"):
+        m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+        m.train_step(*inp, draws=dr, apply=False)
+        torch.cuda.synchronize()
+        res[dt] = m.losses()
+        assert all(np.isfinite(v) for k, v in res[dt].items() if k != "ssim"), (dt, res[dt])
+        assert m.D.count_params() == 6359744 - 81920 + 5 * 16 * 16 * 1024          # Dense grows with S: 1 310 720 weights at 512
+        del m
+        torch.cuda.empty_cache()
+    for k, v in res["float32"].items():
+        if k != "ssim":
+            assert abs(res["bfloat16"][k] - v) <= 2e-2 * max(1.0, abs(v)), (k, v, res["bfloat16"][k])

@@ -467,3 +467,35 @@ def test_first_layer_dgrad_channel_sum(dt, nk, batch, h, cin, c, stride, mask):
     assert rel_l2(host(out)[..., 0] - 0.5, ref) < 1e-5
     ops.conv3x3_dgrad_sum1(dzd, c, weff, out, nk, batch, h, h, c, stride, 0)
     assert rel_l2(host(out)[..., 0], ref) < 1e-5
+
+
+def test_device_random_draws():
+    """shm_randn / shm_keep_mask (GaussianNoise(0.1) SHM.py:352, Dropout(0.2) SHM.py:363) against the NumPy restatement of the
+    same Philox-4x32-10 streams (oracle/rng_np.py, pinned by Random123's known answers): keep masks bit for bit, normals to
+    float rounding of log / sincos; plus moments, reproducibility and stream independence at 4 M draws."""
+    from oracle import rng_np
+    ops = _ops()
+    for n, seed, stream in ((4096, 1234, 0), (999, (25 << 32) | 3, 5)):
+        t = torch.full((n + 2,), 7.0, device="cuda")
+        ops.randn(t[:n], 0.1, seed, stream)
+        assert np.abs(host(t[:n]) - rng_np.randn(n, 0.1, seed, stream)).max() < 2e-6
+        assert float(t[n]) == 7.0 and float(t[n + 1]) == 7.0             # a length that is not a multiple of four stays in bounds
+        ops.keep_mask(t[:n], 0.2, seed, stream)
+        assert np.array_equal(host(t[:n]), rng_np.keep_mask(n, 0.2, seed, stream))
+    n = 1 << 22
+    a = torch.empty(n, device="cuda")
+    ops.randn(a, 0.1, 1234, 0)
+    x = host(a)
+    assert abs(x.mean()) < 3e-4 and abs(x.std() - 0.1) < 3e-4
+    assert abs(((x / 0.1) ** 4).mean() - 3.0) < 0.05 and np.abs(x).max() < 0.1 * 6.5          # normal kurtosis, bounded tails
+    b = torch.empty(n, device="cuda")
+    ops.randn(b, 0.1, 1234, 0)
+    assert torch.equal(a, b)
+    ops.randn(b, 0.1, 1234, 2)
+    assert abs(np.corrcoef(x, host(b))[0, 1]) < 3e-3
+    ops.randn(b, 0.1, 1235, 0)
+    assert abs(np.corrcoef(x, host(b))[0, 1]) < 3e-3
+    m = torch.empty(n, device="cuda")
+    ops.keep_mask(m, 0.2, 99, 1)
+    k = host(m)
+    assert set(np.unique(k)) == {0.0, 1.0} and abs(k.mean() - 0.8) < 1e-3

@@ -317,3 +317,15 @@ def test_live_attention_oracle_properties():
         an = sum(float((gr.numpy() * u).sum()) for gr, u in zip(grads, dirs))
         # the loss has kinks (|.| in L1, LeakyReLU, min/max): a finite step crosses a few of them
         assert abs(fd - an) <= 1e-2 * max(abs(an), 1e-6), (which, fd, an)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors, philox4x32 10 rounds: zero counter / key and all-ones counter / key."""
+    from oracle import rng_np
+    z = rng_np.philox4x32_10([0, 0, 0, 0], [0, 0])
+    assert [int(v) for v in z] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = rng_np.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)
+    assert [int(v) for v in f] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    x = rng_np.randn(1 << 16, 0.1, 7, 0)
+    assert abs(x.mean()) < 2e-3 and abs(x.std() - 0.1) < 2e-3
+    assert abs(rng_np.keep_mask(1 << 16, 0.2, 7, 1).mean() - 0.8) < 6e-3
