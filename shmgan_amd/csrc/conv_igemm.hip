@@ -1186,13 +1186,14 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             // The static-tap halo kernels beat the DMA tiles on every unit-stride 3x3 layer they can take, small grids included
             // (round-2 A/B, tools/bench_variants.py: fp32 n = 8 maps 120-134 vs 107-121 TFLOP/s).  128 or 64 output channels per
             // block: the 128-wide block is ~3 % faster when both fill the chip, but it has half the blocks -- two 8-wave (or
-            // 4-wave) blocks fit a CU, i.e. 512 slots -- so below two rounds the choice goes by how full the last round is.
+            // 4-wave) blocks fit a CU, i.e. 512 slots -- so below two rounds (bf16: below one) the choice goes by how full the last
+            // round is (bf16 n = 8 at 32 x 32: 62 us on the 64-wide block against 76).
             const long np16 = (long)batch * (a.hi / 16) * (a.wi / 16);
             const long nb128 = np16 * shm_cdiv(a.nout, 128), nb64 = np16 * shm_cdiv(a.nout, 64);
             auto fill = [](long nb) { return (double)nb / (double)(((nb + 511) / 512) * 512); };
             if (a.nout <= 64)
                 v = SHM_TG_HALO64_ST;
-            else if (sizeof(T) == 2 || nb128 >= shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN) || fill(nb128) * 1.03 >= fill(nb64))
+            else if (nb128 >= (sizeof(T) == 2 ? 512 : shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)) || fill(nb128) * 1.03 >= fill(nb64))
                 v = SHM_TG_HALO128_ST;
             else
                 v = SHM_TG_HALO64_ST;
