@@ -1182,6 +1182,81 @@ __global__ __launch_bounds__(256) void dgrad_sum1_kernel(const T* __restrict__ d
     if (live && cl == 0) out[q] = accumulate ? out[q] + s : s;
 }
 
+// Tiled form (round 2): the pixel-per-thread-group kernel above reads every dz pixel nine times (once per output pixel it
+// contributes to: 0.6 TB/s HBM-side, 290-560 us per launch in the r02 profiles).  Here a block owns a 16 x 16 tile of OUTPUT
+// pixels: phase A turns every dz pixel the tile touches into its nine per-tap dot products P[t] = sum_k sum_c dz_k[.., c] *
+// weff_k[t][c] (each dz pixel read once per block; weights staged in LDS), phase B gathers out[y, x] = sum of the valid taps'
+// P entries from LDS.  Same sums, different order (fp32 accumulation; the parity tests hold it to 1e-5).
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_sum1_tiled_kernel(const T* __restrict__ dz, int lddz, const float* __restrict__ weff, float* __restrict__ out,
+                                                               int nk, int batch, int hi, int wi, int ho, int wo, int c, int stride, int pt, int pl,
+                                                               int accumulate) {
+    constexpr int TO = 16, RMAX = TO + 2;
+    __shared__ float P[9][RMAX * RMAX];
+    __shared__ __attribute__((aligned(16))) float wl[5 * 9 * 64];
+    const int lanes_c = c >> 2, PP = 256 / lanes_c;
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
+    const int tiles_x = (wi + TO - 1) / TO, tiles_y = (hi + TO - 1) / TO;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TO, x0 = (tr % tiles_x) * TO;
+    // dz region the tile's outputs touch: oy = (y + pt - kh) / stride for kh in 0..2
+    auto fdiv = [](int a, int d) { return a >= 0 ? a / d : -((-a + d - 1) / d); };
+    const int oy_lo = fdiv(y0 + pt - 2, stride), oy_hi = fdiv(y0 + TO - 1 + pt, stride);
+    const int ox_lo = fdiv(x0 + pl - 2, stride), ox_hi = fdiv(x0 + TO - 1 + pl, stride);
+    const int R = oy_hi - oy_lo + 1, Cn = ox_hi - ox_lo + 1;             // <= 18 each
+    for (int i = threadIdx.x; i < nk * 9 * c; i += 256) wl[i] = weff[i];
+    __syncthreads();
+    // ---- phase A
+    if (pp < PP) {
+        for (int j = pp; j < R * Cn; j += PP) {
+            const int r = j / Cn, q = j - r * Cn;
+            const int oy = oy_lo + r, ox = ox_lo + q;
+            float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)oy < (unsigned)ho && (unsigned)ox < (unsigned)wo) {
+                for (int k = 0; k < nk; ++k) {
+                    const f32x4 g = ld4(dz + (((size_t)(k * batch + b) * ho + oy) * wo + ox) * lddz + cl * 4);
+                    const float* wk = wl + k * 9 * c + cl * 4;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const f32x4 wv = *(const f32x4*)(wk + t * c);
+                        s[t] += g[0] * wv[0] + g[1] * wv[1] + g[2] * wv[2] + g[3] * wv[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = s[t];
+                for (int o = lanes_c >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (cl == 0) P[t][r * RMAX + q] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: one output pixel per thread
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < hi && x < wi) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ny = y + pt - kh;
+            if (ny < 0 || (stride == 2 && (ny & 1))) continue;
+            const int oy = stride == 2 ? ny >> 1 : ny;
+            if (oy >= ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int nx = x + pl - kw;
+                if (nx < 0 || (stride == 2 && (nx & 1))) continue;
+                const int ox = stride == 2 ? nx >> 1 : nx;
+                if (ox >= wo) continue;
+                v += P[kh * 3 + kw][(oy - oy_lo) * RMAX + (ox - ox_lo)];
+            }
+        }
+        const size_t qo = ((size_t)b * hi + y) * wi + x;
+        out[qo] = accumulate ? out[qo] + v : v;
+    }
+}
+
 extern "C" int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* weff, float* out, int nk, int batch, int hi, int wi, int c, int stride,
                                       int accumulate, int dtype, void* stream) {
     SHM_REQUIRE(dz && weff && out, SHM_E_SHAPE, "shm_conv3x3_dgrad_sum1: null pointer");
@@ -1193,6 +1268,14 @@ extern "C" int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* wef
     const size_t npx = (size_t)batch * hi * wi;
     if (npx == 0 || nk == 0) return SHM_OK;
     const int PP = 256 / (c / 4);
+    if (nk * c <= 5 * 64) {              // weights fit the tiled kernel's LDS staging
+        const int tiles = shm_cdiv(hi, 16) * shm_cdiv(wi, 16);
+        SHM_DISPATCH(dtype, "shm_conv3x3_dgrad_sum1",
+                     hipLaunchKernelGGL(dgrad_sum1_tiled_kernel<T>, dim3(batch * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)dz, lddz, weff, out, nk,
+                                        batch, hi, wi, ho, wo, c, stride, pt, pl, accumulate));
+        SHM_LAUNCH_CHECK("shm_conv3x3_dgrad_sum1");
+        return SHM_OK;
+    }
     SHM_DISPATCH(dtype, "shm_conv3x3_dgrad_sum1",
                  hipLaunchKernelGGL(dgrad_sum1_kernel<T>, dim3(shm_cdiv((long)npx, PP)), dim3(256), 0, (hipStream_t)stream, (const T*)dz, lddz, weff, out, nk,
                                     batch, hi, wi, ho, wo, c, stride, pt, pl, accumulate));
