@@ -580,17 +580,29 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifndef SHM_ABL_NODMA
                 if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
                 if (tap < 7 || chunk + 1 < nch) dma_b();
+#endif
                 const float* Bb = sB + (tap % 3) * BSTG + wn * 64 * 16;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     f32x4 av[2], bv[2];
+#ifdef SHM_ABL_NOLDS
+                    for (int i = 0; i < 2; ++i) av[i] = abl_frag;
+                    for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
+                    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+#else
 #pragma unroll
                     for (int i = 0; i < 2; ++i) av[i] = *(lds_f4)(size_t)((Ab + (unsigned)(fs[tap][i] << 2)) ^ (unsigned)(kk << 5));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+#endif
+#ifndef SHM_ABL_NOMFMA
                     tap_mfma<T, 2, 2>(av, bv, acc);
+#else
+                    asm volatile("" :: "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
+#endif
                 }
                 asm volatile("" ::: "memory");
             }
