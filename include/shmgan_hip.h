@@ -65,13 +65,15 @@ const char* shm_last_kernel(void);
  *   "tapgemm.halo_min_blocks"   fp32: from this many 128-channel halo blocks on the 128-wide halo block is taken without comparing
  *                               the fill of its last round with the 64-wide block's (default 1024)
  *   "tapgemm.small_grid_blocks" grids with fewer 128x128 tiles take the 64x128 tile (default 1024)
+ *   "tapgemm.phase4_min_blocks" stride-2 transposed 3x3 products with at least this many fused (16x16 input pixels x 64 channels) blocks
+ *                               take the four-phases-in-one-block kernel (default 256)
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 512 bf16)
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
  *                               producer just wrote is still in the Infinity Cache), 0 front to back
  * value < 0 restores the knob's default; key "reset" restores all.  Initial values may be given in the
- * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_WGRAD_VARIANT,
+ * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_TAPGEMM_PHASE4_MIN, SHM_WGRAD_VARIANT,
  * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE), read once.  Knobs change scheduling only, never results beyond the
  * summation order of a tile shape. */
 #define SHM_TG_AUTO 0
@@ -87,6 +89,8 @@ const char* shm_last_kernel(void);
 #define SHM_TG_DMA_128x128_NST4 10
 #define SHM_TG_HALO128_ST 12            /* halo kernels with the nine taps unrolled: static fragment addresses, conflict-free swizzle */
 #define SHM_TG_HALO64_ST 13
+#define SHM_TG_PHASE4 14               /* 3x3 stride-2 transposed products (Conv2DTranspose forward, stride-2 input gradient): four phases fused in one block */
+#define SHM_TG_DMA_64x64 15             /* DMA tap GEMM, 64 x 64 tile (four waves of 32 x 32): grids too small to fill the chip with larger tiles */
 #define SHM_TG_WREG 11                 /* bf16, 3x3 s1, <= 64 input channels: weights in registers, persistent blocks */
 int shm_set_tuning(const char* key, int value);
 int shm_get_tuning(const char* key, int* value);

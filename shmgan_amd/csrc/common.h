@@ -22,6 +22,7 @@ enum ShmTune {
     SHM_TUNE_TAPGEMM_VARIANT = 0,     // SHM_TG_* below; 0 = automatic
     SHM_TUNE_TAPGEMM_HALO_MIN,        // fp32: 128-wide halo blocks from which the 128-wide block is taken unconditionally
     SHM_TUNE_TAPGEMM_SMALL_GRID,      // grids below this many 128x128 tiles take the 64x128 tile
+    SHM_TUNE_TAPGEMM_PHASE4_MIN,      // four-phase (stride-2 transposed) launches with at least this many fused blocks take tapgemm_phase4_kernel
     SHM_TUNE_WGRAD_VARIANT,           // 0 = automatic, 1 = generic kernel only, 2 = halo kernel but no thin-input packing
     SHM_TUNE_WGRAD_BLOCKS,            // split-K target (blocks), 0 = automatic
     SHM_TUNE_STATS_FUSION,            // 1 = InstanceNorm statistics in the conv epilogue (default), 0 = separate pass
@@ -30,7 +31,7 @@ enum ShmTune {
 };
 int shm_tune(int id);
 
-#define SHM_TG_COUNT 14           // SHM_TG_* of include/shmgan_hip.h
+#define SHM_TG_COUNT 16           // SHM_TG_* of include/shmgan_hip.h
 
 // 4-channel vector access in either element type; arithmetic is always fp32.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }

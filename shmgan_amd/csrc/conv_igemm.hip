@@ -1164,6 +1164,184 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     if (a.stats) flush(simg);
 }
 
+// ------------------------------------------------------------------------------------------
+// The four output phases of a 3x3 / stride-2 transposed product in ONE block (Conv2DTranspose forward, input gradient of
+// the stride-2 convolution): tapgemm_dma_kernel runs them as four grid slices with 4 + 2 + 2 + 1 taps, i.e. K loops of one
+// to four taps -- at 128 input channels a block lives for 8..32 K steps between its prologue and its epilogue, and every
+// phase fetches the same input rows again (fp32 89-119, bf16 200-460 TFLOP/s).  Here a block owns 16 x 16 INPUT pixels
+// (-> 32 x 32 output pixels) x 64 output channels: per 64-byte channel chunk the 18 x 18 halo (17 x 17 used) and the NINE
+// weight slices are DMA'd once, two stages deep, ONE barrier per chunk; the nine (phase, tap) steps are unrolled with static
+// fragment addresses (conflict-free halo swizzle of the static-tap halo kernel) and accumulate into the accumulators of
+// their phase: 8 waves = 4 (M: 64 pixels) x 2 (N: 32 channels), 4 phases x 2 tiles = 128 accumulator registers.
+// Phases arrive sorted by tap count 4, 2, 2, 1 (fill_s2_phases with pad_before = 0).  LDS: 2 x 24 KiB halo + 2 x 36 KiB weights.
+template <typename T, typename TO>
+__global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArgs a) {
+    constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;
+    constexpr int HC = 18, NIT = 24, NHR = NIT * 16;
+    constexpr int ASTG = NHR * 16, BTAP = 64 * 16, BSTG = 9 * BTAP;      // floats per stage
+    extern __shared__ __attribute__((aligned(1024))) float psm[];
+    float* const sA = psm;
+    float* const sB = psm + 2 * ASTG;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ppr = a.wi >> 4, ppi = (a.hi >> 4) * ppr;
+    const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
+    const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
+    const int n0 = blockIdx.y * 64;
+
+    // ---- DMA lane constants: halo items wave, wave + 8, wave + 16 (16 halo rows each); weight items wave + 8 j < 36
+    // (item = 4 * step + row group: 16 of the 64 weight rows of (phase, tap) step `item >> 2`)
+    const int drow = lane >> 2, dq = lane & 3;
+    unsigned arow[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int hrow = 16 * (wave + 8 * j) + drow;
+        const int hr = hrow / HC, hc = hrow - hr * HC;
+        const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const int pix = (img * a.hi + iy) * a.wi + ix;
+        arow[j] = v ? (unsigned)(pix * a.ldx + (dq ^ (((hrow >> 1) + hr) & 3)) * CHE) * (unsigned)ESZ : 0xffffffffu;
+    }
+    unsigned wrow[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int item = wave + 8 * j;
+        const int step = item >> 2;                           // 0..3 phase 0, 4..5 phase 1, 6..7 phase 2, 8 phase 3
+        const int ph = step < 4 ? 0 : step < 6 ? 1 : step < 8 ? 2 : 3;
+        const int tp = step < 4 ? step : step < 6 ? step - 4 : step < 8 ? step - 6 : 0;
+        const int row = (item & 3) * 16 + drow;
+        const int nn = n0 + row;
+        const bool v = item < 36 && nn < a.nout;
+        const int wi_ = item < 36 ? a.ph[ph].widx[tp] : 0;
+        wrow[j] = v ? (unsigned)((wi_ * a.nout + nn) * a.K + (dq ^ ((row >> 2) & 3)) * CHE) * (unsigned)ESZ : 0xffffffffu;
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    const int nch = a.K / BKE;
+
+    auto dma = [&](int chunk) {
+        const unsigned cb = (unsigned)(chunk * BKE) * (unsigned)ESZ;
+        float* da = sA + (chunk & 1) * ASTG + wave * 256;
+        float* db = sB + (chunk & 1) * BSTG + wave * 256;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned off = arow[j] == 0xffffffffu ? arow[j] : arow[j] + cb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(da + j * 8 * 256), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j < 4 || wave < 4) {                           // wave-uniform: items 32..35 belong to waves 0..3
+                const unsigned off = wrow[j] == 0xffffffffu ? wrow[j] : wrow[j] + cb;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(db + j * 8 * 256), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[4][2][1];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][i][0][r] = 0.f;
+
+    // fragment addresses (floats, relative to the stage): A per (step, tile); k group 1 = address ^ 8.  B: rows wn*32 + l31
+    int fs[9][2];
+    {
+        int hb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hb[i] = (4 * wm + 2 * i + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            const int ph = st < 4 ? 0 : st < 6 ? 1 : st < 8 ? 2 : 3;
+            const int tp = st < 4 ? st : st < 6 ? st - 4 : st < 8 ? st - 6 : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hrow = hb[i] + a.ph[ph].dh[tp] * HC + a.ph[ph].dw[tp];
+                fs[st][i] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);
+            }
+        }
+    }
+    const int swb = (l31 >> 2) & 3;
+    const int fb0 = (wn * 32 + l31) * 16 + ((0 + h) ^ swb) * 4, fb1 = (wn * 32 + l31) * 16 + ((2 + h) ^ swb) * 4;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    const unsigned sA_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)sA;
+
+    dma(0);
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (chunk + 1 < nch) dma(chunk + 1);                   // the other stage: last read before this barrier
+        const unsigned Ab = sA_lds + (unsigned)((chunk & 1) * ASTG * 4);
+        const float* Bb = sB + (chunk & 1) * BSTG;
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            constexpr int kPhase[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 av[2], bv[1];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[i] = *(lds_f4)(size_t)((Ab + (unsigned)(fs[st][i] << 2)) ^ (unsigned)(kk << 5));
+                bv[0] = *(const f32x4*)(Bb + st * BTAP + (kk ? fb1 : fb0));
+                tap_mfma<T, 2, 1>(av, bv, acc[kPhase[st]]);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue: bias + LeakyReLU, phase p of input pixel (y, x) -> output pixel (2y + oph, 2x + opw)
+    constexpr bool kWide = sizeof(TO) == 2;
+    const bool wide = kWide && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0);
+    const int ncol = n0 + wn * 32 + l31;
+    const float bcol = (a.bias && ncol < a.nout) ? a.bias[ncol] : 0.f;
+    if constexpr (kWide) if (wide) {
+        __syncthreads();                                         // every wave is past its last fragment read
+        unsigned short* tile = (unsigned short*)psm + wave * (64 * 32);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const TO vo = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
+                    // 16-byte chunk c of row `row` lives at chunk c ^ ((row >> 1) & 3)
+                    tile[row * 32 + ((((l31 >> 3) ^ ((row >> 1) & 3)) << 3) | (l31 & 7))] = __builtin_bit_cast(unsigned short, vo);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave hand-off (ds ops of a wave complete in order)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + lane, row = q >> 2, ch = q & 3;
+                const u32x4 v = *(const u32x4*)(tile + row * 32 + ((ch ^ ((row >> 1) & 3)) << 3));
+                const int i = row >> 5, r32 = row & 31;
+                const int py = 4 * wm + 2 * i + (r32 >> 4), px = r32 & 15;
+                const size_t opix = ((size_t)img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw);
+                const int n = n0 + wn * 32 + ch * 8;
+                if (n < a.nout) *(u32x4*)((unsigned short*)a.y + opix * a.ldy + n) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    if (!wide) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
+                    const size_t opix = ((size_t)img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw);
+                    if (ncol < a.nout) ((TO*)a.y)[opix * a.ldy + ncol] = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
+                }
+    }
+}
+
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
@@ -1189,11 +1367,26 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
     // ... and its fp32 form: 16 or 64 input channels
     const bool wreg32_ok = sizeof(T) == 4 && sizeof(TO) == 4 && halo_ok && a.x2 == nullptr && (a.K == 16 || a.K == 64) && a.ybytes != 0 &&
                            (a.y2 == nullptr || a.y2bytes != 0) && a.slope >= 0.f && a.slope <= 1.f && a.nout % 64 == 0 && a.n1 % 16 == 0;
+    // the four phases of a stride-2 transposed product fused in one block: 16 x 16 input patches, 64-channel output slices
+    bool phase4_ok = nphase == 4 && a.is == 1 && a.os == 2 && a.x2 == nullptr && a.y2 == nullptr && a.stats == nullptr && a.hi % 16 == 0 &&
+                     a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi && a.ho == 2 * a.hi && a.wo == 2 * a.wi && a.nout % 64 == 0 &&
+                     a.ph[0].ntaps == 4 && a.ph[1].ntaps == 2 && a.ph[2].ntaps == 2 && a.ph[3].ntaps == 1;
+    if (phase4_ok)
+        for (int p = 0; p < 4; ++p)
+            for (int t = 0; t < a.ph[p].ntaps; ++t)
+                phase4_ok = phase4_ok && a.ph[p].dh[t] >= -1 && a.ph[p].dh[t] <= 1 && a.ph[p].dw[t] >= -1 && a.ph[p].dw[t] <= 1;
     int v = forced;
     if (v == SHM_TG_AUTO) {
         const long tiles128 = (long)shm_cdiv(a.M, 128) * shm_cdiv(a.nout, 128) * nphase;
         if (wreg_ok || wreg32_ok) {
             v = SHM_TG_WREG;
+        } else if (phase4_ok && (long)batch * (a.hi / 16) * (a.wi / 16) * (a.nout / 64) >= shm_tune(SHM_TUNE_TAPGEMM_PHASE4_MIN) &&
+                   (sizeof(T) == 2 || a.K <= 256)) {
+            // tools/bench_phase4.py, n = 40 / 8: Conv2DTranspose 128 -> 64 fp32 832 vs 1153 us (bf16 184 vs 304), 256 -> 128 751 vs 863
+            // (135 vs 229); stride-2 input gradient 64 <- 128, n = 96: 498 vs 645 (113 vs 148).  One 8-wave block per CU (120 KiB of
+            // LDS), so from 512 input channels on the fp32 DMA tiles (two blocks per CU, long K loops) are level or ahead
+            // (512 -> 256: 850 vs 820 us); bf16 stays ahead (129 vs 176) down to one round of blocks.
+            v = SHM_TG_PHASE4;
         } else if (halo_ok) {
             // The static-tap halo kernels beat the DMA tiles on every unit-stride 3x3 layer they can take, small grids included
             // (round-2 A/B, tools/bench_variants.py: fp32 n = 8 maps 120-134 vs 107-121 TFLOP/s).  128 or 64 output channels per
@@ -1203,12 +1396,19 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             const long np16 = (long)batch * (a.hi / 16) * (a.wi / 16);
             const long nb128 = np16 * shm_cdiv(a.nout, 128), nb64 = np16 * shm_cdiv(a.nout, 64);
             auto fill = [](long nb) { return (double)nb / (double)(((nb + 511) / 512) * 512); };
-            if (a.nout <= 64)
+            if (sizeof(T) == 4 && nb64 < 256)
+                // fewer 64-wide halo blocks than CUs (SpecSeg's deep layers at n = 8, any model at batch 1): the 64 x 64 DMA tile
+                // has four times the blocks -- fp32 n = 8: 128 -> 128 @32x32 99 -> 50 us, 256 -> 256 @16x16 165 -> 77,
+                // 128 -> 64 @64x64 100 -> 70; level with the halo block in bf16, where it is not taken
+                v = SHM_TG_DMA_64x64;
+            else if (a.nout <= 64)
                 v = SHM_TG_HALO64_ST;
             else if (nb128 >= (sizeof(T) == 2 ? 512 : shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)) || fill(nb128) * 1.03 >= fill(nb64))
                 v = SHM_TG_HALO128_ST;
             else
                 v = SHM_TG_HALO64_ST;
+        } else if ((long)shm_cdiv(a.M, 64) * shm_cdiv(a.nout, 128) * nphase < 256) {
+            v = SHM_TG_DMA_64x64;           // not even one 64x128 tile per CU
         } else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID)) {
             // small grids (16x16 maps, the n = 8 pass of the stride-2 / transposed layers): 64-row tiles double the number of
             // blocks, so a CU holds two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs
@@ -1251,6 +1451,17 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
         }
         break;
+    case SHM_TG_PHASE4: {
+        SHM_REQUIRE(phase4_ok, SHM_E_SHAPE,
+                    "%s: forced variant phase4 needs a four-phase stride-2 transposed 3x3 product on a 16-aligned input map, one source and one "
+                    "destination tensor, Cout %% 64 == 0, no fused statistics", who);
+        constexpr unsigned kLds = (2 * 24 * 16 * 16 + 2 * 9 * 64 * 16) * sizeof(float);       // 120 KiB
+        static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_phase4_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve 120 KiB of LDS: %s", who, hipGetErrorString(attr));
+        hipLaunchKernelGGL((tapgemm_phase4_kernel<T, TO>), dim3(npatch, a.nout / 64, 1), dim3(512), kLds, st, a);
+        shm_set_last_kernel("tapgemm_phase4_kernel<%s, %s>", tn, ton);
+        break;
+    }
     case SHM_TG_WREG: {
         SHM_REQUIRE(wreg_ok || wreg32_ok, SHM_E_SHAPE,
                     "%s: forced variant wreg needs a unit-stride 3x3 layer on a map that is a multiple of 16, one source tensor with 32/64 (bf16) or "
@@ -1296,6 +1507,10 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
     case SHM_TG_DMA_128x64:
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 128, 64, 2, 2, 3, 16>), grid1d(128, 64), dim3(256), 0, st, a);
         shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 128, 64, 2, 2, 3, 16>", tn, ton);
+        break;
+    case SHM_TG_DMA_64x64:
+        hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 64, 64, 2, 2, 3, 16>), grid1d(64, 64), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_dma_kernel<%s, %s, 64, 64, 2, 2, 3, 16>", tn, ton);
         break;
     case SHM_TG_DMA_256x64:
         hipLaunchKernelGGL((tapgemm_dma_kernel<T, TO, 256, 64, 4, 1, 3, 16>), grid1d(256, 64), dim3(256), 0, st, a);

@@ -43,6 +43,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"tapgemm.variant", "SHM_TAPGEMM_VARIANT", 0, 0, SHM_TG_COUNT - 1},
     {"tapgemm.halo_min_blocks", "SHM_TAPGEMM_HALO_MIN", 1024, 0, 1 << 30},
     {"tapgemm.small_grid_blocks", "SHM_TAPGEMM_SMALLM", 1024, 0, 1 << 30},
+    {"tapgemm.phase4_min_blocks", "SHM_TAPGEMM_PHASE4_MIN", 256, 0, 1 << 30},
     {"wgrad.variant", "SHM_WGRAD_VARIANT", 0, 0, 2},
     {"wgrad.blocks", "SHM_WGRAD_BLOCKS", 0, 0, 1 << 20},
     {"stats.fusion", "SHM_STATS_FUSION", 1, 0, 1},

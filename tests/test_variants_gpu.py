@@ -24,15 +24,16 @@ SYMBOL = {
     "halo128": "tapgemm_halo_kernel<{t}, {t}, 128, 16>", "halo64": "tapgemm_halo_kernel<{t}, {t}, 64, 16>",
     "halo128_ph8": "tapgemm_halo_kernel<{t}, {t}, 128, 8>",
     "dma128x128": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 3, 16>", "dma64x128": "tapgemm_dma_kernel<{t}, {t}, 64, 128, 2, 2, 3, 16>",
-    "dma128x64": "tapgemm_dma_kernel<{t}, {t}, 128, 64, 2, 2, 3, 16>", "dma256x64": "tapgemm_dma_kernel<{t}, {t}, 256, 64, 4, 1, 3, 16>",
+    "dma128x64": "tapgemm_dma_kernel<{t}, {t}, 128, 64, 2, 2, 3, 16>", "dma64x64": "tapgemm_dma_kernel<{t}, {t}, 64, 64, 2, 2, 3, 16>", "dma256x64": "tapgemm_dma_kernel<{t}, {t}, 256, 64, 4, 1, 3, 16>",
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
     "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
     "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true>",
+    "phase4": "tapgemm_phase4_kernel<{t}, {t}>",
 }
 HALO = ["halo128", "halo64", "halo128_st", "halo64_st"]
-DMA = ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
+DMA = ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
 
 
 def _ops():
@@ -197,7 +198,7 @@ def test_dma_forced_variant_other_shapes(variant, dt, n, h, c1, c2, cout, k, s):
 
 # ---- input gradient (flipped taps / four stride-2 phases, split destination) under forced variants
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "wreg"])
+@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "wreg"])
 def test_dgrad_s1_forced_variant(variant, dt):
     ops = _ops()
     rng = np.random.default_rng(7)
@@ -224,7 +225,7 @@ def test_dgrad_s1_forced_variant(variant, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", ["dma128x128", "dma64x128", "dma128x64", "dma256x64", "dma256x128", "dma128x128_bk32"])
+@pytest.mark.parametrize("variant", ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "dma128x128_bk32"])
 def test_dgrad_s2_and_transpose_forced_variant(variant, dt):
     """Stride-2 input gradient and Conv2DTranspose forward: the four-phase launches (blockIdx.z = output phase)."""
     ops = _ops()
@@ -250,6 +251,76 @@ def test_dgrad_s2_and_transpose_forced_variant(variant, dt):
     y = torch.empty((n, 2 * hi, 2 * hi, co), device="cuda", dtype=adt)
     ops.conv2d_transpose_fwd(_dev(x, dt), ci, _dev(wt, dt), torch.from_numpy(b.astype(np.float32)).cuda(), y, co, n, hi, hi, ci, co, 0.2)
     assert ops.last_kernel() == _sym(variant, dt)
+    assert rel_l2(host(y.float()), r) < TOL[dt]
+
+
+# ---- the four phases fused in one block (tapgemm_phase4_kernel): 16 x 16 input patches, 64-channel output slices
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,h,cin,cout", [
+    (2, 32, 64, 128),        # dy 16 x 16: one patch per image, K = 128
+    (3, 64, 128, 64),        # four patches per image, two 64-channel output slices
+    (1, 96, 192, 64),        # 3 x 3 patches (interior patch with all four neighbours), three output slices, one K chunk in bf16
+])
+def test_dgrad_s2_phase4(dt, n, h, cin, cout):
+    ops = _ops()
+    rng = np.random.default_rng(18)
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    dy = rng.standard_normal((n, h // 2, h // 2, cout))
+    xt = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(_rnd(w, dt)), 2), xt, nchw(_rnd(dy, dt)))
+    adt = BF if dt == "bf16" else torch.float32
+    dx = torch.full((n, h, h, cin), 7.0, device="cuda", dtype=adt)
+    ops.set_tuning("tapgemm.variant", "phase4")
+    ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), dx, None, cin, cin, 0, n, h, h, cin, cout, 3, 2)
+    assert ops.last_kernel() == _sym("phase4", dt)
+    assert rel_l2(host(dx.float()), nhwc(ref)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,hi,ci,co", [(2, 16, 64, 64), (3, 32, 128, 192), (1, 48, 64, 128)])
+def test_conv2d_transpose_phase4(dt, n, hi, ci, co):
+    """Conv2DTranspose(3x3, s2) + bias + LeakyReLU through the fused four-phase kernel; shapes it cannot take are refused."""
+    from shmgan_amd._lib import ShmError
+    ops = _ops()
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((n, hi, hi, ci))
+    wt = rng.standard_normal((3, 3, co, ci)) * 0.1
+    b = rng.standard_normal(co)
+    r = nhwc(st.conv2d_transpose_same(nchw(_rnd(x, dt)), t64(_rnd(wt, dt)))) + b
+    r = np.where(r > 0, r, 0.2 * r)
+    adt = BF if dt == "bf16" else torch.float32
+    y = torch.full((n, 2 * hi, 2 * hi, co), 5.0, device="cuda", dtype=adt)
+    ops.set_tuning("tapgemm.variant", "phase4")
+    ops.conv2d_transpose_fwd(_dev(x, dt), ci, _dev(wt, dt), torch.from_numpy(b.astype(np.float32)).cuda(), y, co, n, hi, hi, ci, co, 0.2)
+    assert ops.last_kernel() == _sym("phase4", dt)
+    assert rel_l2(host(y.float()), r) < TOL[dt]
+    y8 = torch.empty((1, 16, 16, 64), device="cuda", dtype=adt)
+    with pytest.raises(ShmError):             # 8 x 8 input map: not a whole 16 x 16 patch
+        ops.conv2d_transpose_fwd(torch.zeros((1, 8, 8, 64), device="cuda", dtype=adt), 64, torch.zeros((3, 3, 64, 64), device="cuda", dtype=adt), None,
+                                 y8, 64, 1, 8, 8, 64, 64, 0.2)
+    with pytest.raises(ShmError):             # Cout = 96 is not a whole number of 64-channel slices
+        ops.conv2d_transpose_fwd(torch.zeros((1, 16, 16, 64), device="cuda", dtype=adt), 64, torch.zeros((3, 3, 96, 64), device="cuda", dtype=adt), None,
+                                 torch.empty((1, 32, 32, 96), device="cuda", dtype=adt), 96, 1, 16, 16, 64, 96, 0.2)
+    with pytest.raises(ShmError):             # a unit-stride layer has one phase
+        ops.conv2d_fwd(torch.zeros((1, 16, 16, 64), device="cuda", dtype=adt), None, 0, 64, 0, torch.zeros(9 * 64 * 64, device="cuda", dtype=adt), None,
+                       y8, 64, 1, 16, 16, 64, 64, 3, 1, 1.0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_default_dispatch_transpose_at_real_shape(dt):
+    """Generator conv2d_transpose_3 (128 -> 64, 128 x 128 -> 256 x 256) at n = 8 through the default dispatch: 512 fused blocks."""
+    ops = _ops()
+    rng = np.random.default_rng(24)
+    n, hi, ci, co = 8, 128, 128, 64
+    x = rng.standard_normal((n, hi, hi, ci)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, co, ci)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    r = nhwc(st.conv2d_transpose_same(nchw(_rnd(x, dt)), t64(_rnd(wt, dt)))) + b
+    r = np.where(r > 0, r, 0.2 * r)
+    adt = BF if dt == "bf16" else torch.float32
+    y = torch.empty((n, 2 * hi, 2 * hi, co), device="cuda", dtype=adt)
+    ops.conv2d_transpose_fwd(_dev(x, dt), ci, _dev(wt, dt), torch.from_numpy(b).cuda(), y, co, n, hi, hi, ci, co, 0.2)
+    assert ops.last_kernel() == _sym("phase4", dt), ops.last_kernel()
     assert rel_l2(host(y.float()), r) < TOL[dt]
 
 
