@@ -230,12 +230,13 @@ def test_train_step_properties_full_size():
     m2.train_step(*inp2, draws=dr2, apply=False)
     torch.cuda.synchronize()
     l2 = m2.losses()
+    # The two runs dispatch different tap-GEMM variants (the tile choice depends on the grid size: at B = 1 the deep layers
+    # take the 64 x 64 DMA tile), whose K orders differ in the last bit; a handful of pre-activations then sit on the other
+    # side of a LeakyReLU kink (see test_train_step_parity), which moves a loss by ~1e-5 (bound: the 1e-4 of SURVEY 8(c)'s
+    # named-loss tolerance) and the gradient by up to ~1e-3 in rel-L2.
     for k in l1:
         if k != "ssim":
-            assert abs(l1[k] - l2[k]) <= 1e-5 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
-    # The two runs may dispatch different tap-GEMM variants (tile choice depends on the grid size), whose K orders
-    # differ in the last bit; a handful of pre-activations then sit on the other side of a LeakyReLU kink (see
-    # test_train_step_parity), which moves the gradient by up to ~1e-3 in rel-L2.
+            assert abs(l1[k] - l2[k]) <= 1e-4 * max(1.0, abs(l1[k])), (k, l1[k], l2[k])
     assert rel_l2(host(m2.G.P.grad), host(g1)) < 3e-3 and cosine(host(m2.G.P.grad), host(g1)) > 0.99999
     assert rel_l2(host(m2.D.P.grad), host(d1)) < 3e-3 and cosine(host(m2.D.P.grad), host(d1)) > 0.99999
 
