@@ -1018,9 +1018,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // InstanceNorm sums are carried in registers (f64) across the patches of an image.  LDS rows are 64 bytes (16 channels) with
 // the DMA source-side swizzle chunk' = (chunk + (R >> 1)) & 3 on the halo row R: conflict free for this instruction's lane
 // groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/halo_swizzle_check.py).
-template <int NCH>
+template <int NCH, int WN = 4, bool TWO = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
-    constexpr int PH = 8, HC = 18, NIT = 12;            // halo (PH + 2) x 18 = 180 rows, padded to 12 DMA items of 16 rows
+    // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
+    // patches of 8 / 16 / 32 rows -- the narrow forms serve SpecSeg's 16- and 32-channel layers without idle N waves
+    constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, NIT = ((PH + 2) * HC + 15) / 16;     // halo (PH + 2) x 18 rows in DMA items of 16 rows
     constexpr int ASTG = NIT * 256;                     // floats per 16-channel chunk
     constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
     constexpr int NITEM = NIT * NCH;                    // DMA items per patch
@@ -1032,8 +1034,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int n0 = blockIdx.y * 64;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * (16 * WN);
     const int ppr = a.wi >> 4, ppi = (a.hi / PH) * ppr;
 
     const int per = (npatch + gridDim.x - 1) / gridDim.x;
@@ -1056,7 +1058,9 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     // ---- halo DMA: item it = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w + 8, ...
     const int drow = lane >> 2, dq = lane & 3;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    const unsigned pixb = (unsigned)a.ldx * 4u;
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    const unsigned pixb = (unsigned)a.ldx * 4u, pixb2 = (unsigned)a.ldx2 * 4u;
+    const int nc1 = a.c1 >> 4;                           // TWO: chunks [0, nc1) come from x, the rest from x2 (Concatenate)
     auto dma = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
@@ -1071,8 +1075,15 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
                 const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
                 // LDS chunk dq of row hrow holds channel chunk (dq - (hrow >> 1)) & 3
-                const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)(c * 64 + (((dq - (hrow >> 1)) & 3) << 4)) : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+                const unsigned sw = (unsigned)(((dq - (hrow >> 1)) & 3) << 4);
+                const unsigned pix = (unsigned)((img * a.hi + iy) * a.wi + ix);
+                if (!TWO || c < nc1) {
+                    const unsigned off = v ? pix * pixb + (unsigned)(c * 64) + sw : 0xffffffffu;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+                } else {
+                    const unsigned off = v ? pix * pixb2 + (unsigned)((c - nc1) * 64) + sw : 0xffffffffu;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+                }
             }
         }
     };
@@ -1090,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         t1 += __shfl_xor(t1, 32, 64);
         t2 += __shfl_xor(t2, 32, 64);
         if (lane < 16) {
-            double* dst = a.stats + (size_t)((2 * blockIdx.x + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
+            double* dst = a.stats + (size_t)((WM * blockIdx.x + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
             atomicAdd(dst, t1);
             atomicAdd(dst + 1, t2);
         }
@@ -1365,8 +1376,12 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                          (sizeof(TO) == 4 || (a.nout % 64 == 0 && a.n1 % 32 == 0 && a.ldy % 8 == 0 && ((size_t)a.y & 15) == 0 &&
                                               (a.y2 == nullptr || (a.ldy2 % 8 == 0 && ((size_t)a.y2 & 15) == 0))));
     // ... and its fp32 form: 16 or 64 input channels
-    const bool wreg32_ok = sizeof(T) == 4 && sizeof(TO) == 4 && halo_ok && a.x2 == nullptr && (a.K == 16 || a.K == 64) && a.ybytes != 0 &&
-                           (a.y2 == nullptr || a.y2bytes != 0) && a.slope >= 0.f && a.slope <= 1.f && a.nout % 64 == 0 && a.n1 % 16 == 0;
+    // (also 16 / 32 output channels on 32- / 16-row patches, K = 32, and SpecSeg's Concatenate of two 16-channel tensors into 16)
+    const int wreg32_wn = a.nout % 64 == 0 ? 4 : a.nout == 32 ? 2 : a.nout == 16 ? 1 : 0;
+    const bool wreg32_ok = sizeof(T) == 4 && sizeof(TO) == 4 && halo_ok && (a.x2 == nullptr || (a.c1 == 16 && a.K == 32 && a.nout == 16)) && a.ybytes != 0 &&
+                           (a.y2 == nullptr || a.y2bytes != 0) && a.slope >= 0.f && a.slope <= 1.f && a.n1 % 16 == 0 &&
+                           ((wreg32_wn == 4 && (a.K == 16 || a.K == 32 || a.K == 64)) || (wreg32_wn == 2 && a.hi % 16 == 0 && (a.K == 16 || a.K == 32)) ||
+                            (wreg32_wn == 1 && a.hi % 32 == 0 && (a.K == 16 || a.K == 32)));
     // the four phases of a stride-2 transposed product fused in one block: 16 x 16 input patches, 64-channel output slices
     bool phase4_ok = nphase == 4 && a.is == 1 && a.os == 2 && a.x2 == nullptr && a.y2 == nullptr && a.stats == nullptr && a.hi % 16 == 0 &&
                      a.wi % 16 == 0 && a.hg == a.hi && a.wg == a.wi && a.ho == 2 * a.hi && a.wo == 2 * a.wi && a.nout % 64 == 0 &&
@@ -1464,8 +1479,9 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
     }
     case SHM_TG_WREG: {
         SHM_REQUIRE(wreg_ok || wreg32_ok, SHM_E_SHAPE,
-                    "%s: forced variant wreg needs a unit-stride 3x3 layer on a map that is a multiple of 16, one source tensor with 32/64 (bf16) or "
-                    "16/64 (fp32) channels, Cout %% 64 == 0, slope in [0,1]", who);
+                    "%s: forced variant wreg needs a unit-stride 3x3 layer on a map that is a multiple of 16, slope in [0,1] and: bf16 -- one source "
+                    "tensor with 32/64 channels, Cout %% 64 == 0; fp32 -- one source with 16/32/64 input channels and "
+                    "Cout %% 64 == 0, or 16/32 input channels with Cout = 32 (map a multiple of 16) or 16 (map a multiple of 32; also 16 + 16 from two tensors)", who);
         static const int ncu = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -1482,17 +1498,41 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             shm_set_last_kernel("tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
         } else if constexpr (sizeof(TO) == 4) {
-            int gx = ncu / ny;                 // one 8-wave block per CU
+            // one 8-wave block per CU; patches of 8 (64 channels per block), 16 (32) or 32 (16) rows
+            const int ph = 32 / wreg32_wn, npw = batch * (a.hi / ph) * (a.wi / 16), nyw = a.nout / (16 * wreg32_wn);
+            int gx = ncu / nyw;
             if (gx < 1) gx = 1;
-            if (gx > np8) gx = np8;
-            if (a.K == 64) {
-                static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-                SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve 96 KiB of LDS: %s", who, hipGetErrorString(attr));
-                hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<4>), dim3(gx, ny, 1), dim3(512), 98304, st, a, np8);
-            } else {
-                hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<1>), dim3(gx, ny, 1), dim3(512), 24576, st, a, np8);
-            }
-            shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d>", a.K / 16);
+            if (gx > npw) gx = npw;
+            const int nch = a.K / 16;
+            const unsigned lds = 2u * (unsigned)nch * (unsigned)(((ph + 2) * 18 + 15) / 16) * 1024u;      // two halo buffers
+            hipError_t attr = hipSuccess;
+#define SHM_WREG32_LAUNCH2(NCH_, WN_, TWO_)                                                                                              \
+    do {                                                                                                                                 \
+        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, WN_, TWO_>,                         \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize,                                    \
+                                                          2 * NCH_ * ((((32 / WN_) + 2) * 18 + 15) / 16) * 1024);                        \
+        attr = at_;                                                                                                                      \
+        if (attr == hipSuccess)                                                                                                          \
+            hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, WN_, TWO_>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);                \
+    } while (0)
+#define SHM_WREG32_LAUNCH(NCH_, WN_) SHM_WREG32_LAUNCH2(NCH_, WN_, false)
+            if (wreg32_wn == 4 && nch == 4) SHM_WREG32_LAUNCH(4, 4);
+            else if (wreg32_wn == 4 && nch == 2) SHM_WREG32_LAUNCH(2, 4);
+            else if (wreg32_wn == 4) SHM_WREG32_LAUNCH(1, 4);
+            else if (wreg32_wn == 2 && nch == 2) SHM_WREG32_LAUNCH(2, 2);
+            else if (wreg32_wn == 2) SHM_WREG32_LAUNCH(1, 2);
+            else if (nch == 2 && a.x2) SHM_WREG32_LAUNCH2(2, 1, true);
+            else if (nch == 2) SHM_WREG32_LAUNCH(2, 1);
+            else SHM_WREG32_LAUNCH(1, 1);
+#undef SHM_WREG32_LAUNCH2
+#undef SHM_WREG32_LAUNCH
+            SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, lds, hipGetErrorString(attr));
+            if (wreg32_wn == 4)
+                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d>", nch);
+            else if (a.x2)
+                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d, true>", nch, wreg32_wn);
+            else
+                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d>", nch, wreg32_wn);
         }
         break;
     }

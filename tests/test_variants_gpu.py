@@ -138,6 +138,35 @@ def test_wreg_forced_variant(dt, n, h, cin, cout):
     _fwd_case("wreg", dt, n, h, cin, 0, cout, 3, 1, seed=3)
 
 
+@pytest.mark.parametrize("n,h,c1,c2,cout,sym", [
+    (2, 32, 16, 0, 16, "tapgemm_wreg_f32_kernel<1, 1>"),      # SpecSeg 256-level layers: 16 output channels, 32-row patches
+    (3, 64, 16, 16, 16, "tapgemm_wreg_f32_kernel<2, 1, true>"),     # Concatenate([up, skip]) of two 16-channel tensors, several patches per image
+    (1, 32, 32, 0, 16, "tapgemm_wreg_f32_kernel<2, 1>"),
+    (2, 32, 16, 0, 32, "tapgemm_wreg_f32_kernel<1, 2>"),      # 32 output channels, 16-row patches
+    (5, 16, 32, 0, 32, "tapgemm_wreg_f32_kernel<2, 2>"),
+    (2, 32, 32, 0, 64, "tapgemm_wreg_f32_kernel<2>"),         # K = 32, 64-channel blocks
+])
+def test_wreg_f32_narrow_and_concat(n, h, c1, c2, cout, sym):
+    """The fp32 weights-in-registers kernel on 16 / 32 output channels (WN = 1 / 2 waves along N), K = 32, and SpecSeg's two-source form."""
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    cin = c1 + c2
+    xa = rng.standard_normal((n, h, h, c1))
+    xb = rng.standard_normal((n, h, h, c2)) if c2 else None
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    xr = xa if xb is None else np.concatenate([xa, xb], -1)
+    ref = np.maximum(conv_ref(xr.astype(np.float32), w.astype(np.float32), 1) + b, 0.0)       # ReLU (slope 0), as SpecSeg uses it
+    y = torch.full((n, h, h, cout), 9.0, device="cuda")
+    for variant in ("wreg", "auto"):
+        ops.set_tuning("tapgemm.variant", variant)
+        ops.conv2d_fwd(_dev(xa, "f32"), None if xb is None else _dev(xb, "f32"), c1 if c2 else 0, c1, c2, _wk(w, cin, "f32"),
+                       torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout, 3, 1, 0.0)
+        assert ops.last_kernel() == sym, ops.last_kernel()
+        assert rel_l2(host(y), ref) < 1e-5
+        y.fill_(9.0)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_wreg_many_patches_per_block_and_refusals(dt):
     """n = 24 at 128 x 128 is 3072 patches on 512 (bf16) / 256 (fp32) blocks: 6 / 12 patches per block, most blocks inside
@@ -147,7 +176,7 @@ def test_wreg_many_patches_per_block_and_refusals(dt):
     _fwd_case("wreg", dt, 24, 128, 64, 0, 64, 3, 1, seed=4)
     ops.set_tuning("tapgemm.variant", "wreg")
     adt = BF if dt == "bf16" else torch.float32
-    kbad = 96 if dt == "bf16" else 32
+    kbad = 96 if dt == "bf16" else 48
     x = torch.zeros((1, 16, 16, kbad), device="cuda", dtype=adt)
     w = torch.zeros(9 * 64 * kbad, device="cuda", dtype=adt)
     y = torch.zeros((1, 16, 16, 64), device="cuda", dtype=adt)
