@@ -1418,6 +1418,11 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                 v = SHM_TG_DMA_64x64;
             else if (a.nout <= 64)
                 v = SHM_TG_HALO64_ST;
+            else if (sizeof(T) == 4 && nb128 < shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN))
+                // fp32 is MFMA bound, so what counts is the busiest CU: blocks are dealt out over 256 CUs, a 64-wide block is half
+                // the work at ~4 % less efficiency.  Matches every A/B point of tools/bench_variants.py (n = 2..40 on the 128-, 256-
+                // and 512-channel layers), e.g. 320 blocks (n = 40, 32 x 32, 256 <- 512): 2 units against 3 x 0.52 -- 1085 vs 865 us
+                v = (double)((nb128 + 255) / 256) <= (double)((nb64 + 255) / 256) * 0.52 ? SHM_TG_HALO128_ST : SHM_TG_HALO64_ST;
             else if (nb128 >= (sizeof(T) == 2 ? 512 : shm_tune(SHM_TUNE_TAPGEMM_HALO_MIN)) || fill(nb128) * 1.03 >= fill(nb64))
                 v = SHM_TG_HALO128_ST;
             else

@@ -385,16 +385,16 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
 # reference convolutions take a few seconds each on the GPU box's host cores.
 # ======================================================================================================
 def test_default_dispatch_fp32_halo128_on_a_generator_layer():
-    """Generator conv2d_5 (128 -> 128 at 128 x 128) through the default dispatch: n = 4 is 256 128-wide halo blocks (half a
-    round of the chip) against 512 64-wide ones -> the 64-wide static-tap halo block; n = 8 (the G(1) batch, one full round)
-    and n = 16 -> the 128-wide one."""
+    """Generator conv2d_5 (128 -> 128 at 128 x 128) through the default dispatch: n = 6 is 384 128-wide halo blocks on 256 CUs
+    (the busiest CU gets two) against 768 64-wide ones (three halves) -> the 64-wide static-tap halo block; n = 8 (the G(1) batch,
+    two per CU) and n = 16 -> the 128-wide one."""
     ops = _ops()
     rng = np.random.default_rng(21)
     h, cin, cout = 128, 128, 128
     w = rng.standard_normal((3, 3, cin, cout)) * 0.05
     b = rng.standard_normal(cout) * 0.1
     wk = _wk(w, cin, "f32")
-    for n, sym in ((4, "halo64_st"), (8, "halo128_st"), (16, "halo128_st")):
+    for n, sym in ((6, "halo64_st"), (8, "halo128_st"), (16, "halo128_st")):
         x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
         ref = conv_ref(x, w.astype(np.float32), 1) + b
         ref = np.where(ref > 0, ref, 0.2 * ref)
