@@ -69,11 +69,12 @@ const char* shm_last_kernel(void);
  *                               take the four-phases-in-one-block kernel (default 256)
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 512 bf16)
+ *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
  *                               producer just wrote is still in the Infinity Cache), 0 front to back
  * value < 0 restores the knob's default; key "reset" restores all.  Initial values may be given in the
- * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_TAPGEMM_PHASE4_MIN, SHM_WGRAD_VARIANT,
+ * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_TAPGEMM_PHASE4_MIN, SHM_WGRAD_VARIANT, SHM_WGRAD_BF16_ROWS,
  * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE), read once.  Knobs change scheduling only, never results beyond the
  * summation order of a tile shape. */
 #define SHM_TG_AUTO 0

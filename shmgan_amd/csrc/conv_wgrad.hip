@@ -759,13 +759,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
 // swizzled address per kw serves all taps through immediates) of 128-byte rows (64 channels) and 32 dY
 // rows, brought in by LDS-DMA with the half-swap swizzle applied on the source side; two K steps of 16
 // pixels, nine v_mfma_f32_32x32x16_bf16 each, operands via ds_read_b64_tr_b16.
+// R = pixel rows per stage (2 or 4).  The x fragment of tap row kh at K step (pixel row) q is the fragment of tap row 0 at
+// q + kh, so a stage of R rows needs (R + 2) x 3 fragment reads for 9 R MFMAs (hipcc keeps the shared ones in registers):
+// R = 4 reads 22 fragments per 36 MFMAs where two R = 2 stages read 28, with half the barriers and 3/4 of the halo bytes.
+template <int R>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
-    constexpr int PW = 16, HP = 20;                     // patch 2 x 16; halo 4 rows, LDS pitch 20 (18 valid)
-    constexpr int NHR = 4 * HP, NPX = 2 * PW;           // 80 halo rows, 32 dY rows
-    constexpr int STAGE = (NHR + NPX) * 64;             // bf16 elements per stage (14 KiB)
+    constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
+    constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows (14 KiB); R = 4: 120 + 64 (23 KiB)
+    constexpr int STAGE = (NHR + NPX) * 64;             // bf16 elements per stage
     constexpr int NST = 3;
-    constexpr int NXI = NHR / 8, NDI = NPX / 8;         // DMA items (8 rows of 128 B each): 10 + 4
-    __shared__ __attribute__((aligned(1024))) unsigned short smem[NST * STAGE];
+    constexpr int NXI = NHR / 8, NDI = NPX / 8;         // DMA items (8 rows of 128 B each): 10 + 4 / 15 + 8
+    constexpr int NIT = NXI + NDI, NJ = (NIT + 3) / 4;  // items per wave: waves below NIT % 4 (or all) take NJ, the others NJ - 1
+    constexpr int NXJ = (NXI + 3) / 4;                  // halo items per wave (at most)
+    extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -793,9 +799,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
                                               : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     // items 0..9: halo rows [8i, 8i+8); items 10..13: dY rows.  Wave w takes items w, w+4, w+8, w+12.
-    int hr[3], hc[3];
+    int hr[NXJ], hc[NXJ];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NXJ; ++j) {
         const int hp = 8 * (wave + 4 * j) + drow;
         hr[j] = hp / HP;
         hc[j] = hp - hr[j] * HP;
@@ -803,11 +809,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
 
     int n, pr, pc;
     {
-        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int ppr = a.w / PW, ppi = (a.h / R) * ppr;
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
-        pr = (r / ppr) * 2;
+        pr = (r / ppr) * R;
         pc = (r % ppr) * PW;
     }
     auto dma = [&](int stage) {
@@ -815,10 +821,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         unsigned short* sd = sx + NHR * 64;
         const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int item = wave + 4 * j;
             if (item < NXI) {
-                const int r_ = hr[j < 3 ? j : 0], c_ = hc[j < 3 ? j : 0];
+                const int r_ = hr[j < NXJ ? j : 0], c_ = hc[j < NXJ ? j : 0];
                 const int iy = pr - 1 + r_, ix = pc - 1 + c_;
                 const bool v = xvalid && c_ < PW + 2 && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
                 const unsigned off = v ? (unsigned)((org + r_ * a.w + c_) * ldX + ccX) * 2u : 0xffffffffu;
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         pc += PW;
         if (pc == a.w) {
             pc = 0;
-            pr += 2;
+            pr += R;
             if (pr == a.h) {
                 pr = 0;
                 ++n;
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         const unsigned short* X = smem + stage * STAGE;
         const unsigned short* D = X + NHR * 64;
 #pragma unroll
-        for (int qr = 0; qr < 2; ++qr) {
+        for (int qr = 0; qr < R; ++qr) {
             const bf16x8 bv = tr_frag(D + fb + qr * PW * 64);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -878,11 +884,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         if (nstages > 1) dma(1);
         int cur = 0, nxt2 = 2;
         for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {                 // one younger stage in flight: 4 (waves 0,1) or 3 DMA instructions
-                if (wave < 2)
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (s + 1 < nstages) {                 // one younger stage in flight: NJ or NJ - 1 DMA instructions of this wave
+                if (NIT % 4 == 0 || wave < NIT % 4)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
                 else
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1056,7 +1062,8 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.cin_ld = cin_ld;
         hgs.cin = cin;
         hgs.cout = cout;
-        hgs.npatch = batch * (hi / 2) * (wi / 16);
+        const int rows = (hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2) ? 4 : 2;      // pixel rows per stage
+        hgs.npatch = batch * (hi / rows) * (wi / 16);
         int nsh = ns < hgs.npatch ? ns : hgs.npatch;
         hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
         nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
@@ -1064,8 +1071,15 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
         ns = nsh;
-        hipLaunchKernelGGL(wgrad_halo_bf16_kernel, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
-        shm_set_last_kernel("wgrad_halo_bf16_kernel");
+        if (rows == 4) {
+            constexpr unsigned kLds = 3u * (6 * 20 + 4 * 16) * 128u;      // 69 KiB
+            static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s", hipGetErrorString(attr));
+            hipLaunchKernelGGL(wgrad_halo_bf16_kernel<4>, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
+        } else {
+            hipLaunchKernelGGL(wgrad_halo_bf16_kernel<2>, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
+        }
+        shm_set_last_kernel("wgrad_halo_bf16_kernel<%d>", rows);
     } else if (dtype == SHM_BF16) {
         dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
         if (ksize == 3) {

@@ -370,14 +370,16 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
     ops.set_tuning("wgrad.variant", wv)
     ops.set_tuning("wgrad.blocks", blocks)
     ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 1024, device="cuda")
-    dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
-    ops.conv2d_wgrad(_dev(x, dt), None, 0, ld, 0, _dev(dy, dt), cout, dw, n, h, h, cin, ld, cout, 3, 1, 0, ws)
-    k = ops.last_kernel()
-    if wv == 1:
-        assert k.startswith("wgrad_kernel<") or k.startswith("wgrad_bf16_kernel<"), k
-    elif wv == 2:
-        assert k in ("wgrad_halo_kernel", "wgrad_halo_bf16_kernel"), k
-    assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
+    for rows in ((0, 2) if dt == "bf16" and wv != 1 else (0,)):        # bf16 halo kernel: 4 (automatic here) and 2 pixel rows per stage
+        ops.set_tuning("wgrad.bf16_rows", rows)
+        dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+        ops.conv2d_wgrad(_dev(x, dt), None, 0, ld, 0, _dev(dy, dt), cout, dw, n, h, h, cin, ld, cout, 3, 1, 0, ws)
+        k = ops.last_kernel()
+        if wv == 1:
+            assert k.startswith("wgrad_kernel<") or k.startswith("wgrad_bf16_kernel<"), k
+        elif wv == 2:
+            assert k in ("wgrad_halo_kernel", f"wgrad_halo_bf16_kernel<{rows or 4}>"), k
+        assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
 
 
 # ======================================================================================================
