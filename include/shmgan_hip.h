@@ -92,6 +92,7 @@ const char* shm_last_kernel(void);
 #define SHM_TG_HALO64_ST 13
 #define SHM_TG_PHASE4 14               /* 3x3 stride-2 transposed products (Conv2DTranspose forward, stride-2 input gradient): four phases fused in one block */
 #define SHM_TG_DMA_64x64 15             /* DMA tap GEMM, 64 x 64 tile (four waves of 32 x 32): grids too small to fill the chip with larger tiles */
+#define SHM_TG_HALO128_ST_W4 16         /* static-tap halo block of four waves, wave tile 128 pixels x 64 channels */
 #define SHM_TG_WREG 11                 /* bf16, 3x3 s1, <= 64 input channels: weights in registers, persistent blocks */
 int shm_set_tuning(const char* key, int value);
 int shm_get_tuning(const char* key, int* value);

@@ -32,7 +32,7 @@ enum ShmTune {
 };
 int shm_tune(int id);
 
-#define SHM_TG_COUNT 16           // SHM_TG_* of include/shmgan_hip.h
+#define SHM_TG_COUNT 17           // SHM_TG_* of include/shmgan_hip.h
 
 // 4-channel vector access in either element type; arithmetic is always fp32.
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }

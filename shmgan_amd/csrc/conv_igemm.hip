@@ -407,10 +407,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // register (one per (tap, tile); the second k group is an XOR, the B stage an immediate) -- no address arithmetic between the
 // barrier and the first ds_read of a K step -- and lets the halo use the conflict-free swizzle ((R >> 1) + R / 18) & 3 that
 // cost 3 % when its arithmetic sat on that path.
-template <typename T, typename TO, int BN, int PH = 16, bool ST = false>
-__global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
+// TM = 32-row MFMA tiles per wave along M (2: wave tile 64 pixels x 64 channels; 4, static taps only: 128 x 64 -- half the waves,
+// six fragment reads per eight MFMAs instead of four per four, twice the MFMAs per barrier: the bf16 form, whose K step is 8x shorter).
+template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2>
+__global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
+    static_assert(TM == 2 || (TM == 4 && ST), "four M tiles per wave: static-tap form only");
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
-    constexpr int WGM = PH / 4, WGN = BN / 64, NW = WGM * WGN;          // waves: (PH/4) (M) x (BN/64) (N)
+    constexpr int WGM = PH / (2 * TM), WGN = BN / 64, NW = WGM * WGN;   // waves: PH / (2 TM) (M) x (BN/64) (N)
     constexpr int HC = 18, NIT = PH == 16 ? 24 : 12;  // halo (PH+2) x 18 rows, padded to NIT DMA items of 16 rows
     constexpr int NHR = NIT * 16;
     constexpr int ASTG = NHR * 16, BSTG = BN * 16;    // floats per stage
@@ -495,9 +498,9 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
         ld_stage = ld_stage == 2 ? 0 : ld_stage + 1;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -509,9 +512,9 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
     // fragment reads see a 2-way bank conflict (SQ_LDS_BANK_CONFLICT).  The conflict-free function for this access
     // pattern is ((R >> 1) + R / 18) & 3 (exhaustive check over taps and lane groups); it was measured 3 % SLOWER in
     // both dtypes -- its per-tap address work sits on the barrier -> first ds_read critical path, the conflicts do not.
-    int hb[2];
+    int hb[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) hb[i] = (4 * wm + 2 * i + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
+    for (int i = 0; i < TM; ++i) hb[i] = (2 * TM * wm + 2 * i + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
     const int swb = (l31 >> 2) & 3;
     const int fb0 = l31 * 16 + ((0 + h) ^ swb) * 4, fb1 = l31 * 16 + ((2 + h) ^ swb) * 4;
 
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
 #endif
-            tap_mfma<T, 2, 2>(av, bv, acc);
+            if constexpr (TM == 2) tap_mfma<T, 2, 2>(av, bv, acc);
         }
     };
 
@@ -554,14 +557,14 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
     if (ksteps > 1) dma_b();
     if constexpr (ST) {
         // fragment addresses of the nine taps (floats, relative to the A stage): registers for the whole block
-        int fs[9][2];
+        // (tile i sits 2 i patch rows = 36 i halo rows further on: (R >> 1) + R / 18 grows by 20 i, the swizzle does not change, and
+        // the tile offset 2304 i bytes leaves bit 5 alone -- one register per tap, tiles and k groups as immediates / one XOR)
+        int fs[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int hrow = hb[i] + P.dh[t] * HC + P.dw[t];
-                fs[t][i] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);        // k group 1: this address ^ 8
-            }
+        for (int t = 0; t < 9; ++t) {
+            const int hrow = hb[0] + P.dh[t] * HC + P.dw[t];
+            fs[t] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);        // k group 1: this address ^ 8
+        }
         typedef const __attribute__((address_space(3))) f32x4* lds_f4;
         const unsigned sA_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)sA;
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -587,19 +590,20 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
                 const float* Bb = sB + (tap % 3) * BSTG + wn * 64 * 16;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    f32x4 av[2], bv[2];
+                    f32x4 av[TM], bv[2];
 #ifdef SHM_ABL_NOLDS
-                    for (int i = 0; i < 2; ++i) av[i] = abl_frag;
+                    for (int i = 0; i < TM; ++i) av[i] = abl_frag;
                     for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
                     asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
 #else
+                    const lds_f4 ap = (lds_f4)(size_t)((Ab + (unsigned)(fs[tap] << 2)) ^ (unsigned)(kk << 5));
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) av[i] = *(lds_f4)(size_t)((Ab + (unsigned)(fs[tap][i] << 2)) ^ (unsigned)(kk << 5));
+                    for (int i = 0; i < TM; ++i) av[i] = ap[i * (2 * HC * 4)];               // 36 halo rows of 64 bytes per tile
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
 #endif
 #ifndef SHM_ABL_NOMFMA
-                    tap_mfma<T, 2, 2>(av, bv, acc);
+                    tap_mfma<T, TM, 2>(av, bv, acc);
 #else
                     asm volatile("" :: "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
 #endif
@@ -651,9 +655,9 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
                       (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0)));
     if constexpr (kWide) if (wide) {
         __syncthreads();
-        unsigned short* tile = (unsigned short*)smem + wave * (64 * 64);
+        unsigned short* tile = (unsigned short*)smem + wave * (TM * 32 * 64);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -677,11 +681,11 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rr = lane >> 3, ch = lane & 7;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4 * TM; ++it) {
             const int row = it * 8 + rr;
             const u32x4 v = *(const u32x4*)(tile + row * 64 + ((ch ^ (row & 7)) << 3));
             const int i = row >> 5, r32 = row & 31;
-            const int py = 4 * wm + 2 * i + (r32 >> 4), px = r32 & 15;
+            const int py = 2 * TM * wm + 2 * i + (r32 >> 4), px = r32 & 15;
             const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
             const int n = n0 + wn * 64 + ch * 8;
 #ifndef SHM_ABL_NOSTORE
@@ -696,11 +700,11 @@ __global__ __launch_bounds__(BN * PH / 4, ST ? BN * PH / 512 : 1) void tapgemm_h
     }
     if (!wide) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
+            const int py = 2 * TM * wm + 2 * i + (row >> 4), px = row & 15;
             const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -1456,6 +1460,11 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
         shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true>", tn, ton);
+        break;
+    case SHM_TG_HALO128_ST_W4:
+        SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps/4 waves needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
+        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 4>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(256), 0, st, a);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true, 4>", tn, ton);
         break;
     case SHM_TG_HALO64_ST:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);

@@ -92,7 +92,7 @@ def _dtg(act, grad):
 
 # SHM_TG_* of include/shmgan_hip.h
 TAPGEMM_VARIANTS = {"auto": 0, "halo128": 1, "halo64": 2, "dma128x128": 3, "dma64x128": 4, "dma128x64": 5, "dma256x64": 6,
-                    "dma256x128": 7, "halo128_ph8": 8, "dma128x128_bk32": 9, "dma128x128_nst4": 10, "wreg": 11, "halo128_st": 12, "halo64_st": 13, "phase4": 14, "dma64x64": 15}
+                    "dma256x128": 7, "halo128_ph8": 8, "dma128x128_bk32": 9, "dma128x128_nst4": 10, "wreg": 11, "halo128_st": 12, "halo64_st": 13, "phase4": 14, "dma64x64": 15, "halo128_st_w4": 16}
 
 
 def set_tuning(key, value):

@@ -30,9 +30,9 @@ SYMBOL = {
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
     "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
     "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true>",
-    "phase4": "tapgemm_phase4_kernel<{t}, {t}>",
+    "phase4": "tapgemm_phase4_kernel<{t}, {t}>", "halo128_st_w4": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 4>",
 }
-HALO = ["halo128", "halo64", "halo128_st", "halo64_st"]
+HALO = ["halo128", "halo64", "halo128_st", "halo64_st", "halo128_st_w4"]
 DMA = ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "dma128x128_bk32", "dma128x128_nst4"]
 
 
