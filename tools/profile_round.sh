@@ -22,6 +22,8 @@ cd "$root"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "profiles/${tag}_kernel_stats_serialize.csv"
 python3 tools/pmc_traffic.py "$out/fetch" "$out/write" > "profiles/${tag}_traffic_pmc.json"
 (cd tools && python3 pmc_sq.py "$out/sq") > "profiles/${tag}_sq_pmc.json"
+# gpurun merges only gpurun_out/ back: carry the distilled files there too (copy them into profiles/ afterwards)
+mkdir -p "$out/distilled" && cp profiles/${tag}_kernel_stats_serialize.csv profiles/${tag}_traffic_pmc.json profiles/${tag}_sq_pmc.json "$out/distilled/"
 # keep the merged-back scratch small: the raw counter CSVs are tens of MB
 find "$out" -name '*.csv' -size +2M -delete
 echo "[$tag] distilled into profiles/${tag}_*"
