@@ -1449,17 +1449,17 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
     case SHM_TG_HALO128:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128 needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16>", tn, ton);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, false, 2>", tn, ton);
         break;
     case SHM_TG_HALO64:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64 needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16>", tn, ton);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16, false, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_ST:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true>", tn, ton);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_ST_W4:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps/4 waves needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
@@ -1469,7 +1469,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
     case SHM_TG_HALO64_ST:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16, true>", tn, ton);
+        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_PH8:
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
@@ -1477,7 +1477,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
         SHM_REQUIRE(halo_ok && sizeof(T) == 2, SHM_E_SHAPE, "%s: forced variant halo128/ph8 is bf16, unit-stride 3x3, map multiple of 16", who);
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 8>), dim3(batch * (a.hi / 8) * (a.wi / 16), shm_cdiv(a.nout, 128), 1), dim3(256), 0, st, a);
-            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8>", tn, ton);
+            shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 8, false, 2>", tn, ton);
         }
         break;
     case SHM_TG_PHASE4: {
@@ -1541,12 +1541,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
 #undef SHM_WREG32_LAUNCH2
 #undef SHM_WREG32_LAUNCH
             SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, lds, hipGetErrorString(attr));
-            if (wreg32_wn == 4)
-                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d>", nch);
-            else if (a.x2)
-                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d, true>", nch, wreg32_wn);
-            else
-                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d>", nch, wreg32_wn);
+            shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn, a.x2 ? "true" : "false");
         }
         break;
     }

@@ -21,15 +21,15 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 TOL = {"f32": 1e-5, "bf16": 4e-3}
 SYMBOL = {
-    "halo128": "tapgemm_halo_kernel<{t}, {t}, 128, 16>", "halo64": "tapgemm_halo_kernel<{t}, {t}, 64, 16>",
-    "halo128_ph8": "tapgemm_halo_kernel<{t}, {t}, 128, 8>",
+    "halo128": "tapgemm_halo_kernel<{t}, {t}, 128, 16, false, 2>", "halo64": "tapgemm_halo_kernel<{t}, {t}, 64, 16, false, 2>",
+    "halo128_ph8": "tapgemm_halo_kernel<{t}, {t}, 128, 8, false, 2>",
     "dma128x128": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 3, 16>", "dma64x128": "tapgemm_dma_kernel<{t}, {t}, 64, 128, 2, 2, 3, 16>",
     "dma128x64": "tapgemm_dma_kernel<{t}, {t}, 128, 64, 2, 2, 3, 16>", "dma64x64": "tapgemm_dma_kernel<{t}, {t}, 64, 64, 2, 2, 3, 16>", "dma256x64": "tapgemm_dma_kernel<{t}, {t}, 256, 64, 4, 1, 3, 16>",
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
     "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
-    "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true>",
+    "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 2>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true, 2>",
     "phase4": "tapgemm_phase4_kernel<{t}, {t}>", "halo128_st_w4": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 4>",
 }
 HALO = ["halo128", "halo64", "halo128_st", "halo64_st", "halo128_st_w4"]
@@ -49,7 +49,7 @@ def _reset_tuning():
 
 def _sym(variant, dt, nch=2):
     if variant == "wreg" and dt == "f32":
-        return f"tapgemm_wreg_f32_kernel<{int(2 * nch)}>"          # 16-channel chunks
+        return f"tapgemm_wreg_f32_kernel<{int(2 * nch)}, 4, false>"          # 16-channel chunks, four N waves, one source
     nch = int(nch)
     return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch)
 
@@ -139,12 +139,12 @@ def test_wreg_forced_variant(dt, n, h, cin, cout):
 
 
 @pytest.mark.parametrize("n,h,c1,c2,cout,sym", [
-    (2, 32, 16, 0, 16, "tapgemm_wreg_f32_kernel<1, 1>"),      # SpecSeg 256-level layers: 16 output channels, 32-row patches
+    (2, 32, 16, 0, 16, "tapgemm_wreg_f32_kernel<1, 1, false>"),      # SpecSeg 256-level layers: 16 output channels, 32-row patches
     (3, 64, 16, 16, 16, "tapgemm_wreg_f32_kernel<2, 1, true>"),     # Concatenate([up, skip]) of two 16-channel tensors, several patches per image
-    (1, 32, 32, 0, 16, "tapgemm_wreg_f32_kernel<2, 1>"),
-    (2, 32, 16, 0, 32, "tapgemm_wreg_f32_kernel<1, 2>"),      # 32 output channels, 16-row patches
-    (5, 16, 32, 0, 32, "tapgemm_wreg_f32_kernel<2, 2>"),
-    (2, 32, 32, 0, 64, "tapgemm_wreg_f32_kernel<2>"),         # K = 32, 64-channel blocks
+    (1, 32, 32, 0, 16, "tapgemm_wreg_f32_kernel<2, 1, false>"),
+    (2, 32, 16, 0, 32, "tapgemm_wreg_f32_kernel<1, 2, false>"),      # 32 output channels, 16-row patches
+    (5, 16, 32, 0, 32, "tapgemm_wreg_f32_kernel<2, 2, false>"),
+    (2, 32, 32, 0, 64, "tapgemm_wreg_f32_kernel<2, 4, false>"),         # K = 32, 64-channel blocks
 ])
 def test_wreg_f32_narrow_and_concat(n, h, c1, c2, cout, sym):
     """The fp32 weights-in-registers kernel on 16 / 32 output channels (WN = 1 / 2 waves along N), K = 32, and SpecSeg's two-source form."""
