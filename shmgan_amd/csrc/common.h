@@ -28,6 +28,7 @@ enum ShmTune {
     SHM_TUNE_WGRAD_BF16_ROWS,         // wgrad_halo_bf16_kernel: pixel rows per stage, 0 = automatic (4 when the map allows), 2 or 4
     SHM_TUNE_STATS_FUSION,            // 1 = InstanceNorm statistics in the conv epilogue (default), 0 = separate pass
     SHM_TUNE_ELEM_REVERSE,            // 1 = in_apply / in_bwd_reduce walk the tensor back to front (Infinity-Cache reuse), 0 = front to back
+    SHM_TUNE_ELEM_REDUCE_BLOCKS,      // block target of the InstanceNorm-backward reduce pass
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);

@@ -83,7 +83,8 @@ def test_tuning_keys_roundtrip_without_gpu():
     assert L.shm_set_tuning(b"reset", 0) == 0
     assert L.shm_get_tuning(b"tapgemm.variant", C.addressof(v)) == 0 and v.value == 0
     for key, dflt in ((b"tapgemm.halo_min_blocks", 1024), (b"tapgemm.small_grid_blocks", 1024), (b"wgrad.variant", 0),
-                      (b"wgrad.blocks", 0), (b"stats.fusion", 1), (b"elem.reverse", 1)):
+                      (b"wgrad.blocks", 0), (b"stats.fusion", 1), (b"elem.reverse", 1), (b"tapgemm.phase4_min_blocks", 256),
+                      (b"wgrad.bf16_rows", 0), (b"elem.reduce_blocks", 0)):
         assert L.shm_get_tuning(key, C.addressof(v)) == 0 and v.value == dflt, key
 
 
