@@ -930,31 +930,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// The same sums in the same order (bit-identical results) with 16 bytes per lane and four slabs in flight per chain: the
-// 4-byte form ran at 2.7 TB/s (profiles/r02_f32: 147 launches, 2.7 ms per fp32 step of slab traffic).  n % 4 == 0.
+// 16 bytes per lane and SIXTEEN interleaved chains per element group (slab k goes to chain k % 16, four loads in flight per
+// chain, chains combined as a fixed tree): a reduce is a chain of dependent slab loads -- with four chains and up to 1024 slabs
+// every launch took 13 (bf16) to 26 us (fp32) whatever its size, 49 launches per step.  Deterministic (fixed order); the order
+// differs from wgrad_reduce_kernel's, which keeps serving element counts that are not a multiple of four.  n % 4 == 0.
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4, int nsplit, int accumulate) {
-    __shared__ f32x4 red[4][64];
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + e;               // group of four elements
+    __shared__ f32x4 red[16][16];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + e;               // group of four elements
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         const f32x4* p = (const f32x4*)part + i;
         int k = g;
-        for (; k + 12 < nsplit; k += 16) {
-            const f32x4 a = p[(size_t)k * n4], b = p[(size_t)(k + 4) * n4], c = p[(size_t)(k + 8) * n4], d = p[(size_t)(k + 12) * n4];
+        for (; k + 48 < nsplit; k += 64) {
+            const f32x4 a = p[(size_t)k * n4], b = p[(size_t)(k + 16) * n4], c = p[(size_t)(k + 32) * n4], d = p[(size_t)(k + 48) * n4];
             s += a;
             s += b;
             s += c;
             s += d;
         }
-        for (; k < nsplit; k += 4) s += p[(size_t)k * n4];
+        for (; k < nsplit; k += 16) s += p[(size_t)k * n4];
     }
     red[g][e] = s;
     __syncthreads();
     if (g == 0 && i < n4) {
-        f32x4 t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        f32x4 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = red[2 * q][e] + red[2 * q + 1][e];
+        const f32x4 r = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         f32x4* o = (f32x4*)dw + i;
-        *o = accumulate ? *o + t : t;
+        *o = accumulate ? *o + r : r;
     }
 }
 
@@ -1181,7 +1186,7 @@ extern "C" int shm_conv2d_wgrad_reduce(const void* workspace, float* dw, size_t 
     SHM_REQUIRE(workspace && dw && nsplit >= 1, SHM_E_SHAPE, "shm_conv2d_wgrad_reduce: bad arguments");
     if (n == 0) return SHM_OK;
     if (n % 4 == 0 && ((size_t)workspace & 15) == 0 && ((size_t)dw & 15) == 0)
-        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(shm_cdiv((long)(n / 4), 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, n / 4,
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(shm_cdiv((long)(n / 4), 16)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, n / 4,
                            nsplit, accumulate);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shm_cdiv((long)n, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, n, nsplit,
