@@ -2,6 +2,8 @@
 // discriminator-head losses and the clip+Adam update.  All HBM-bound, one pass each.
 #include "common.h"
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // tf.image.rgb_to_yuv kernel (column j of yuv = sum_i rgb[i] * K[i][j])
 #define R2Y_00 0.299f
 #define R2Y_01 -0.14714119f
@@ -187,29 +189,63 @@ __device__ __forceinline__ void store_rgb_pad(T* o, int ld, float r, float g, fl
     for (int q = 1; q < (ld >> 2); ++q) st4(o + 4 * q, (f32x4){0.f, 0.f, 0.f, 0.f});
 }
 
+// The same rows when they are 64 bytes (the MFMA staging pitch: 16 floats / 32 bf16), written by the whole wave: lane l of
+// store j covers bytes [1024 j + 16 l, +16) of the wave's 64 consecutive rows, i.e. row 16 j + l / 4, chunk l % 4 -- four fully
+// coalesced 1 KiB stores instead of 4 (fp32) or 8 (bf16) per lane that each touch 64 different lines.  Every lane of the wave
+// must call it (idx = this lane's row, live = idx < n); r, g, b of dead lanes are ignored.
+template <typename T>
+__device__ __forceinline__ void store_rgb_rows64(T* base, size_t idx, size_t n, float r, float g, float b) {
+    const int lane = threadIdx.x & 63;
+    const size_t row0 = idx - lane;                        // the wave's first row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int src = 16 * j + (lane >> 2);
+        const float rr = __shfl(r, src, 64), gg = __shfl(g, src, 64), bb = __shfl(b, src, 64);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((lane & 3) == 0) {
+            if constexpr (sizeof(T) == 4) {
+                v = (u32x4){__builtin_bit_cast(unsigned, rr), __builtin_bit_cast(unsigned, gg), __builtin_bit_cast(unsigned, bb), 0u};
+            } else {
+                const unsigned short hr = __builtin_bit_cast(unsigned short, (T)rr), hg = __builtin_bit_cast(unsigned short, (T)gg),
+                                     hb = __builtin_bit_cast(unsigned short, (T)bb);
+                v = (u32x4){(unsigned)hr | ((unsigned)hg << 16), (unsigned)hb, 0u, 0u};
+            }
+        }
+        if (row0 + src < n) *(u32x4*)((char*)base + (row0 + src) * 64 + (lane & 3) * 16) = v;
+    }
+}
+
 template <typename T>
 __global__ void yuv2rgb_kernel(const float* __restrict__ ych, const float* __restrict__ cbcr, const float* __restrict__ noise, float* __restrict__ rgb,
                                T* __restrict__ dpad, int ldp, int nimg, int batch, size_t npix) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)nimg * npix) return;
-    size_t p = idx % npix;
-    int b = (int)((idx / npix) % batch);
-    float y = ych[idx];
-    float u = cbcr[((size_t)b * npix + p) * 2], v = cbcr[((size_t)b * npix + p) * 2 + 1];
-    float r = y + Y2R_V_R * v;
-    float g = y + Y2R_U_G * u + Y2R_V_G * v;
-    float bl = y + Y2R_U_B * u;
-    rgb[idx * 3] = r;
-    rgb[idx * 3 + 1] = g;
-    rgb[idx * 3 + 2] = bl;
-    if (dpad) {
-        if (noise) {
+    const size_t total = (size_t)nimg * npix;
+    const bool rows64 = dpad && (size_t)ldp * sizeof(T) == 64 && (((size_t)dpad & 15) == 0);
+    const bool live = idx < total;
+    if (!live && !rows64) return;
+    float r = 0.f, g = 0.f, bl = 0.f;
+    if (live) {
+        size_t p = idx % npix;
+        int b = (int)((idx / npix) % batch);
+        float y = ych[idx];
+        float u = cbcr[((size_t)b * npix + p) * 2], v = cbcr[((size_t)b * npix + p) * 2 + 1];
+        r = y + Y2R_V_R * v;
+        g = y + Y2R_U_G * u + Y2R_V_G * v;
+        bl = y + Y2R_U_B * u;
+        rgb[idx * 3] = r;
+        rgb[idx * 3 + 1] = g;
+        rgb[idx * 3 + 2] = bl;
+        if (dpad && noise) {
             r += noise[idx * 3];
             g += noise[idx * 3 + 1];
             bl += noise[idx * 3 + 2];
         }
-        store_rgb_pad(dpad + idx * ldp, ldp, r, g, bl);
     }
+    if (rows64) {
+        store_rgb_rows64(dpad, idx, total, r, g, bl);
+        return;
+    }
+    if (dpad) store_rgb_pad(dpad + idx * ldp, ldp, r, g, bl);
 }
 
 extern "C" int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noise, float* rgb, void* dpad, int ldp, int nimg, int batch, size_t npix,
@@ -228,14 +264,22 @@ extern "C" int shm_yuv2rgb(const float* ych, const float* cbcr, const float* noi
 template <typename T>
 __global__ void pack_rgb16_kernel(const float* __restrict__ rgb, const float* __restrict__ noise, T* __restrict__ dpad, int ldp, size_t n) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    float r = rgb[idx * 3], g = rgb[idx * 3 + 1], b = rgb[idx * 3 + 2];
-    if (noise) {
-        r += noise[idx * 3];
-        g += noise[idx * 3 + 1];
-        b += noise[idx * 3 + 2];
+    const bool rows64 = (size_t)ldp * sizeof(T) == 64 && (((size_t)dpad & 15) == 0);
+    const bool live = idx < n;
+    if (!live && !rows64) return;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (live) {
+        r = rgb[idx * 3], g = rgb[idx * 3 + 1], b = rgb[idx * 3 + 2];
+        if (noise) {
+            r += noise[idx * 3];
+            g += noise[idx * 3 + 1];
+            b += noise[idx * 3 + 2];
+        }
     }
-    store_rgb_pad(dpad + idx * ldp, ldp, r, g, b);
+    if (rows64)
+        store_rgb_rows64(dpad, idx, n, r, g, b);
+    else
+        store_rgb_pad(dpad + idx * ldp, ldp, r, g, b);
 }
 
 extern "C" int shm_pack_rgb16(const float* rgb, const float* noise, void* dpad, int ldp, size_t n, int dtype, void* stream) {
