@@ -450,6 +450,37 @@ def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     assert rel_l2(host(y), ref) < 1e-5
 
 
+def test_default_dispatch_fp32_grid_smaller_than_the_chip():
+    """SpecSeg's deep layers at n = 8 (and any model at batch 1): 128 -> 128 at 32 x 32 is 64 64-wide halo blocks for 256 CUs -> the
+    64 x 64 DMA tile (256 blocks), forward with fused statistics and input gradient; the same layer in bf16 stays on the halo block."""
+    ops = _ops()
+    rng = np.random.default_rng(25)
+    n, h, c = 8, 32, 128
+    x = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, c, c)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    for dt, sym in (("f32", "dma64x64"), ("bf16", "halo64_st")):
+        ref = conv_ref(_rnd(x, dt), _rnd(w, dt), 1) + b
+        ref = np.where(ref > 0, ref, 0.2 * ref)
+        adt = BF if dt == "bf16" else torch.float32
+        y = torch.empty((n, h, h, c), device="cuda", dtype=adt)
+        stats = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
+        ops.conv2d_in_fwd(_dev(x, dt), None, 0, c, 0, _wk(w, c, dt), torch.from_numpy(b).cuda(), y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+        assert ops.last_kernel() == _sym(sym, dt), ops.last_kernel()
+        got = host(y.float())
+        assert rel_l2(got, ref) < TOL[dt]
+        _check_stats(stats, got, n, c, dt)
+        assert float(scr.abs().max()) == 0.0
+    dy = rng.standard_normal((n, h, h, c)).astype(np.float32)
+    xt = torch.zeros(n, c, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, t64(w), 1), xt, nchw(dy))
+    dx = torch.empty((n, h, h, c), device="cuda")
+    ops.conv2d_dgrad(_dev(dy, "f32"), c, _dev(w, "f32"), dx, None, c, c, 0, n, h, h, c, c, 3, 1)
+    assert ops.last_kernel() == _sym("dma64x64", "f32"), ops.last_kernel()
+    assert rel_l2(host(dx), nhwc(ref.detach())) < 1e-5
+
+
 def test_default_dispatch_fp32_cout64_at_256():
     """The headline block: 64 -> 64 at 256 x 256, n = 8 (fp32 default = the weights-in-registers kernel)."""
     ops = _ops()
