@@ -175,6 +175,11 @@ int shm_in_stats(const void* a, int lda, double* stats, int batch, int hw, int c
 /* out = (a - mean) * inv + beta[c]  (out may alias a). */
 int shm_in_apply(const void* a, int lda, const double* stats, const float* beta, void* out,
                  int ldo, int batch, int hw, int c, int dtype, void* stream);
+/* out = InstanceNorm apply as above AND pooled = AveragePooling2D(2)(out) in the same pass (the second block of an
+ * encoder level feeds both the skip connection and the pool, SHM.py:246-247): bit-identical to shm_in_apply followed by
+ * shm_avgpool2_fwd, without the pooling pass's read of the normalised tensor.  h, w even; pooled [batch, h/2, w/2, c], pitch ldp. */
+int shm_in_apply_pool(const void* a, int lda, const double* stats, const float* beta, void* out, int ldo,
+                      void* pooled, int ldp, int batch, int h, int w, int c, int dtype, void* stream);
 /* Backward of LeakyReLU -> IN given the gradient at the IN output:
  *   d_out = g1 + 0.25 * g2[h/2][w/2]   (g2 = gradient of AveragePooling2D(2,2), may be NULL)
  *   dz = lrelu'(a) * inv * (d_out - mean(d_out) - xhat * mean(d_out * xhat))

@@ -33,6 +33,18 @@ enum ShmTune {
 };
 int shm_tune(int id);
 
+// Barrier of the LDS-DMA pipelines.  A stage is refilled by DMA instructions issued AFTER the barrier that follows its last use, so a
+// wave must not enter that barrier with fragment reads of the stage still queued: the MFMAs that consume them are register-only
+// instructions which hipcc is free to sink below the barrier (it does, with the nine taps unrolled), taking the implicit
+// s_waitcnt lgkmcnt with them -- and with the LDS pipe saturated (bf16) a queued ds_read can then be overtaken by the DMA write
+// of another wave (tools/conv_repeat_probe.py: one 16-byte weight chunk stale in 1 of 30 launches).  Hence the explicit wait; a
+// __syncthreads() would also drain vmcnt, i.e. the DMA pipeline.
+#define SHM_LDS_BARRIER()                                       \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+    } while (0)
+
 #define SHM_TG_COUNT 17           // SHM_TG_* of include/shmgan_hip.h
 
 // 4-channel vector access in either element type; arithmetic is always fp32.

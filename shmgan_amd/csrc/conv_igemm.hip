@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // all waves: stage s landed, compute(s-1) finished
+        SHM_LDS_BARRIER();          // all waves: stage s landed, compute(s-1) finished
         asm volatile("" ::: "memory");
 #ifndef SHM_ABL_NODMA
         if (s + AHEAD < ksteps) dma(nxt);      // overwrites the buffer compute(s-1) was reading
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
-                __builtin_amdgcn_s_barrier();
+                SHM_LDS_BARRIER();
                 asm volatile("" ::: "memory");
 #ifndef SHM_ABL_NODMA
                 if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        SHM_LDS_BARRIER();
         asm volatile("" ::: "memory");
 #ifndef SHM_ABL_NODMA
         if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int q = q0; q < q1; ++q) {
         const int buf = (q - q0) & 1;
-        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave (each waited for its own part at the end
+        SHM_LDS_BARRIER();                   // halo(q) landed for every wave (each waited for its own part at the end
         asm volatile("" ::: "memory");                  // of the previous patch); everyone is done with the other buffer
 #ifndef SHM_ABL_NODMA
         if (q + 1 < q1) dma(q + 1, buf ^ 1);
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int q = q0; q < q1; ++q) {
         const int buf = (q - q0) & 1;
-        __builtin_amdgcn_s_barrier();                   // halo(q) landed for every wave; everyone is done with the other buffer
+        SHM_LDS_BARRIER();                   // halo(q) landed for every wave; everyone is done with the other buffer
         asm volatile("" ::: "memory");
         if (q + 1 < q1) dma(q + 1, buf ^ 1);
 
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
     dma(0);
     for (int chunk = 0; chunk < nch; ++chunk) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        SHM_LDS_BARRIER();
         asm volatile("" ::: "memory");
         if (chunk + 1 < nch) dma(chunk + 1);                   // the other stage: last read before this barrier
         const unsigned Ab = sA_lds + (unsigned)((chunk & 1) * ASTG * 4);

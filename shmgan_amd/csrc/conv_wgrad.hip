@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            SHM_LDS_BARRIER();
             asm volatile("" ::: "memory");
             if (s + 2 < nstages) dma(nxt2);
             compute(cur);
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            SHM_LDS_BARRIER();
             asm volatile("" ::: "memory");
             if (s + 2 < nstages) dma(nxt2);
             compute(cur);
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            SHM_LDS_BARRIER();
             asm volatile("" ::: "memory");
             if (s + 2 < nstages) dma(nxt2);
             compute(cur);

@@ -324,6 +324,87 @@ extern "C" int shm_in_apply(const void* a, int lda, const double* stats, const f
     return SHM_OK;
 }
 
+// InstanceNorm apply + AveragePooling2D(2) in one pass (the second block of every encoder level feeds both the skip and the
+// pool): a thread normalises the four pixels of a 2 x 2 quad for its four channels, writes them, and writes their mean -- the
+// pooled tensor is formed from the values as stored (rounded to T), in avgpool2_kernel's order, so it is bit-identical to
+// shm_in_apply followed by shm_avgpool2_fwd; the separate pooling pass (a full read of the normalised tensor) is gone.
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_pool_kernel(const T* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
+                                                            T* __restrict__ out, int ldo, T* __restrict__ pooled, int ldp, int h, int w, int c, int chunk,
+                                                            int rev) {
+    PixMap pm(c);
+    if (!pm.active) return;
+    const int n = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int bx = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int wo = w >> 1, hq = (h >> 1) * wo;
+    const int q0 = bx * chunk, q1 = min(hq, q0 + chunk);
+    float mean[4], inv[4], bt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int ch = pm.cl * 4 + e;
+        mean[e] = (float)stats[((size_t)n * c + ch) * 2];
+        inv[e] = (float)stats[((size_t)n * c + ch) * 2 + 1];
+        bt[e] = beta[ch];
+    }
+    const T* base = a + (size_t)n * h * w * lda + pm.cl * 4;
+    T* ob = out + (size_t)n * h * w * ldo + pm.cl * 4;
+    T* pb = pooled + (size_t)n * hq * ldp + pm.cl * 4;
+    constexpr int U = 2;
+    auto quad = [&](int q, f32x4 (&x)[4]) {
+        const int oy = q / wo, ox = q - oy * wo;
+        const size_t p = (size_t)(2 * oy) * w + 2 * ox;
+        x[0] = ld4(base + p * lda);
+        x[1] = ld4(base + (p + 1) * lda);
+        x[2] = ld4(base + (p + w) * lda);
+        x[3] = ld4(base + (p + w + 1) * lda);
+    };
+    auto finish = [&](int q, const f32x4 (&x)[4]) {
+        const int oy = q / wo, ox = q - oy * wo;
+        const size_t p = (size_t)(2 * oy) * w + 2 * ox;
+        f32x4 y[4], s;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[t][e] = rnd_as((const T*)nullptr, (x[t][e] - mean[e]) * inv[e] + bt[e]);
+        st4(ob + p * ldo, y[0]);
+        st4(ob + (p + 1) * ldo, y[1]);
+        st4(ob + (p + w) * ldo, y[2]);
+        st4(ob + (p + w + 1) * ldo, y[3]);
+        s = ((y[0] + y[1]) + y[2]) + y[3];
+        st4(pb + (size_t)q * ldp, s * 0.25f);
+    };
+    int q = q0 + pm.pp;
+    for (; q + (U - 1) * pm.PP < q1; q += U * pm.PP) {
+        f32x4 x[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) quad(q + u * pm.PP, x[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish(q + u * pm.PP, x[u]);
+    }
+    for (; q < q1; q += pm.PP) {
+        f32x4 x[4];
+        quad(q, x);
+        finish(q, x);
+    }
+}
+
+extern "C" int shm_in_apply_pool(const void* a, int lda, const double* stats, const float* beta, void* out, int ldo, void* pooled, int ldp, int batch,
+                                 int h, int w, int c, int dtype, void* stream) {
+    SHM_CHECK_C(c, "shm_in_apply_pool");
+    SHM_REQUIRE(lda % 4 == 0 && ldo % 4 == 0 && ldp % 4 == 0, SHM_E_SHAPE, "shm_in_apply_pool: bad pitch");
+    SHM_REQUIRE(h % 2 == 0 && w % 2 == 0, SHM_E_SHAPE, "shm_in_apply_pool: odd size %dx%d", h, w);
+    SHM_REQUIRE(a && stats && beta && out && pooled, SHM_E_SHAPE, "shm_in_apply_pool: null pointer");
+    if (batch == 0 || h * w == 0) return SHM_OK;
+    const int hq = (h / 2) * (w / 2);
+    int nch = pix_chunks(hq, batch, c);
+    int chunk = shm_cdiv(hq, nch);
+    SHM_DISPATCH(dtype, "shm_in_apply_pool",
+                 hipLaunchKernelGGL(in_apply_pool_kernel<T>, dim3(shm_cdiv(hq, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats, beta,
+                                    (T*)out, ldo, (T*)pooled, ldp, h, w, c, chunk, shm_tune(SHM_TUNE_ELEM_REVERSE)));
+    SHM_LAUNCH_CHECK("shm_in_apply_pool");
+    return SHM_OK;
+}
+
 // --------------------------------------------------------------------------- IN backward
 struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' element type T
     const void* g1;

@@ -365,8 +365,9 @@ class Generator(_ModelBase):
         ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
 
     # -- forward --------------------------------------------------------------------------
-    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w):
-        """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record)."""
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, pooled=None):
+        """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record).
+        pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation."""
         _, _, k, cin, cout = self.layers[li]
         cin_p = _padk(cin, self.pad)
         A = self.arena
@@ -376,7 +377,10 @@ class Generator(_ModelBase):
         scr = A.get(f"stats_scratch/{n * cout}", (ops.STATS_SLOTS * n * cout * 2,), torch.float64)
         ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
                           k, 1, LRELU, stats, IN_EPS, cin_real=cin, scratch=scr)
-        ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
+        if pooled is not None:
+            ops.in_apply_pool(a, cout, stats, self.betas[bi], ahat, cout, pooled, cout, n, h, w, cout)
+        else:
+            ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
         return ahat, rec
 
@@ -393,8 +397,11 @@ class Generator(_ModelBase):
         li = bi = 0
         downs = []
         for lvl in range(4):
-            for _ in range(2):
-                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+            pooled = None
+            for j in range(2):
+                if j == 1:            # the level's second block: its normalisation pass also writes the pooled tensor
+                    pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, self.layers[li][4]), self.adt)
+                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, pooled=pooled)
                 recs.append(r)
                 ld = self.layers[li][4]
                 li += 1
@@ -405,8 +412,6 @@ class Generator(_ModelBase):
                 downs.append((skip, ld, h))
             else:
                 downs.append((cur, ld, h))
-            pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, ld), self.adt)
-            ops.avgpool2_fwd(cur, ld, pooled, ld, n, h, h, ld)
             cur, h = pooled, h // 2
         for _ in range(2):                       # the two 1x1 blocks
             cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)

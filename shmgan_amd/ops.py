@@ -198,6 +198,11 @@ def in_stats(a, lda, stats, batch, hw, c, eps):
     check(lib().shm_in_stats(_p(a), lda, _p(stats), batch, hw, c, eps, _dt(a), _stream()), "shm_in_stats")
 
 
+def in_apply_pool(a, lda, stats, beta, out, ldo, pooled, ldp, batch, h, w, c):
+    check(lib().shm_in_apply_pool(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, _p(pooled), ldp, batch, h, w, c, _dt(a), _stream()),
+          "shm_in_apply_pool")
+
+
 def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
     check(lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()),
           "shm_in_apply")

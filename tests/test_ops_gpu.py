@@ -222,6 +222,15 @@ def test_instance_norm_fwd_bwd(n, h, c):
     pl = torch.empty((n, h // 2, h // 2, c), device="cuda")
     ops.avgpool2_fwd(out, c, pl, c, n, h, h, c)
     assert rel_l2(host(pl), nhwc(pooled.detach())) < TOL
+    # the same two results from ONE pass (shm_in_apply_pool): bit-identical, in both dtypes
+    for dt in (torch.float32, torch.bfloat16):
+        a_t = ad.to(dt)
+        o1, p1 = torch.empty((n, h, h, c), device="cuda", dtype=dt), torch.empty((n, h // 2, h // 2, c), device="cuda", dtype=dt)
+        o2, p2 = torch.full_like(o1, 7.0), torch.full_like(p1, 7.0)
+        ops.in_apply(a_t, c, stats, dev(beta), o1, c, n, h * h, c)
+        ops.avgpool2_fwd(o1, c, p1, c, n, h, h, c)
+        ops.in_apply_pool(a_t, c, stats, dev(beta), o2, c, p2, c, n, h, h, c)
+        assert torch.equal(o1, o2) and torch.equal(p1, p2)
     # numpy restatement of the backward (no pooled term)
     ops.in_bwd(dev(g1), c, None, 0, ad, c, stats, red, dz, c, None, n, h, h, c, 0.2)
     ref2 = tn.leaky_relu_grad(z, tn.instance_norm_bwd(a, g1))

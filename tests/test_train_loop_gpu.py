@@ -107,3 +107,62 @@ def test_step_is_reproducible_run_to_run():
             assert abs(l1[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, v, l1[k])
     assert rel_l2(host(y1), host(y0)) <= 1e-6
     assert rel_l2(host(g1), host(g0)) <= 1e-6 and rel_l2(host(d1), host(d0)) <= 1e-6
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float32"])
+def test_full_size_step_is_reproducible_over_many_runs(dt):
+    """BASELINE configs[1] geometry (S=256, F=64, B=8), ten repetitions of the same step: every repetition agrees with the first
+    in gen_Y and the discriminator outputs BITWISE and in the named losses / flat gradients to the float64-atomics bound.
+    This is the race detector of the LDS-DMA pipelines: a fragment read overtaken by the refill of its stage (a barrier entered
+    with ds_reads still queued -- see SHM_LDS_BARRIER in csrc/common.h) showed up here as one stale 16-byte weight chunk in about
+    one launch in thirty of the bf16 128-wide halo block, i.e. in roughly every third step."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 256, 64, 8
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+    inp, dr = st.make_inputs(B, S), st.make_draws(5, B, S, F)
+    ref = None
+    for r in range(10):
+        m.train_step(*inp, draws=dr, apply=False)
+        torch.cuda.synchronize()
+        cur = (dict(m.losses()), m.gen_Y.clone(), m.D.ctx["rf"].clone(), m.D.ctx["cls"].clone(), m.G.P.grad.clone(), m.D.P.grad.clone())
+        if ref is None:
+            ref = cur
+            continue
+        assert torch.equal(cur[1], ref[1]) and torch.equal(cur[2], ref[2]) and torch.equal(cur[3], ref[3]), r
+        for k, v in ref[0].items():
+            if k != "ssim":
+                assert abs(cur[0][k] - v) <= 1e-6 * max(1.0, abs(v)), (r, k, v, cur[0][k])
+        assert rel_l2(host(cur[4]), host(ref[4])) <= 1e-6 and rel_l2(host(cur[5]), host(ref[5])) <= 1e-6, r
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_conv_entry_points_are_bitwise_reproducible(dt):
+    """The hot tap-GEMM and weight-gradient kernels on a full-size layer (256 -> 256 at 64 x 64, n = 40), thirty launches each:
+    identical bits every time (their only atomics are the float64 statistics, which do not feed the output tensor)."""
+    from shmgan_amd import ops
+    adt = torch.bfloat16 if dt == "bf16" else torch.float32
+    n, h, c = 40, 64, 256
+    torch.manual_seed(1)
+    x = torch.randn((n, h, h, c), device="cuda").to(adt)
+    dy = torch.randn((n, h, h, c), device="cuda").to(adt)
+    w = torch.randn((3, 3, c, c), device="cuda") * 0.05
+    wk = torch.zeros(9 * c * c, device="cuda", dtype=adt)
+    ops.transpose_taps(w, wk, 9, c, c, c)
+    wop = w.to(adt)
+    b = torch.randn(c, device="cuda")
+    stats = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, c, c, 3) // 4 + 1024, device="cuda")
+    ref = None
+    for r in range(30):
+        y = torch.empty((n, h, h, c), device="cuda", dtype=adt)
+        dx = torch.empty((n, h, h, c), device="cuda", dtype=adt)
+        dw = torch.empty((3, 3, c, c), device="cuda")
+        ops.conv2d_in_fwd(x, None, 0, c, 0, wk, b, y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+        ops.conv2d_dgrad(dy, c, wop, dx, None, c, c, 0, n, h, h, c, c, 3, 1)
+        ops.conv2d_wgrad(x, None, 0, c, 0, dy, c, dw, n, h, h, c, c, c, 3, 1, 0, ws)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (y, dx, dw)
+        else:
+            assert torch.equal(y, ref[0]) and torch.equal(dx, ref[1]) and torch.equal(dw, ref[2]), r
