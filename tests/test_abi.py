@@ -109,3 +109,17 @@ def test_generator_gradient_buckets_partition_the_flat_buffer():
         if F == 64:
             mb = [sum(hi - lo for lo, hi in sl) * 4 / 1e6 for _, sl in plan]
             assert abs(sum(mb) - 74.1) < 0.1 and mb[1] > 45
+
+
+def test_every_pipeline_barrier_waits_for_its_lds_reads():
+    """Source lint for the race fixed in round 2: a raw s_barrier in a kernel source would let a wave enter the barrier with
+    fragment reads still queued (the refill of the stage is issued right after it); kernels use SHM_LDS_BARRIER() -- s_waitcnt
+    lgkmcnt(0) + s_barrier -- or __syncthreads()."""
+    from pathlib import Path
+    csrc = Path(_lib.__file__).resolve().parent / "csrc"
+    for f in sorted(csrc.glob("*.hip")):
+        assert "__builtin_amdgcn_s_barrier" not in f.read_text(), f.name
+    common = (csrc / "common.h").read_text()
+    i = common.index("#define SHM_LDS_BARRIER()")
+    body = common[i:i + 400]
+    assert body.index("s_waitcnt lgkmcnt(0)") < body.index("__builtin_amdgcn_s_barrier()")
