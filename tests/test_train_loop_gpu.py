@@ -112,7 +112,7 @@ def test_step_is_reproducible_run_to_run():
 @pytest.mark.parametrize("dt", ["bfloat16", "float32"])
 def test_full_size_step_is_reproducible_over_many_runs(dt):
     """BASELINE configs[1] geometry (S=256, F=64, B=8), ten repetitions of the same step: every repetition agrees with the first
-    in gen_Y and the discriminator outputs BITWISE and in the named losses / flat gradients to the float64-atomics bound.
+    in gen_Y, the discriminator outputs, the named losses and the flat gradients to the float64-atomics bound (1e-6).
     This is the race detector of the LDS-DMA pipelines: a fragment read overtaken by the refill of its stage (a barrier entered
     with ds_reads still queued -- see SHM_LDS_BARRIER in csrc/common.h) showed up here as one stale 16-byte weight chunk in about
     one launch in thirty of the bf16 128-wide halo block, i.e. in roughly every third step."""
@@ -128,7 +128,10 @@ def test_full_size_step_is_reproducible_over_many_runs(dt):
         if ref is None:
             ref = cur
             continue
-        assert torch.equal(cur[1], ref[1]) and torch.equal(cur[2], ref[2]) and torch.equal(cur[3], ref[3]), r
+        # (in practice bitwise equal; the bound leaves room for a float64 statistics sum that crosses an fp32 rounding boundary
+        # when its atomics arrive in another order -- the race moved these outputs by 1e-2)
+        for i in (1, 2, 3):
+            assert rel_l2(host(cur[i]), host(ref[i])) <= 1e-6, (r, i)
         for k, v in ref[0].items():
             if k != "ssim":
                 assert abs(cur[0][k] - v) <= 1e-6 * max(1.0, abs(v)), (r, k, v, cur[0][k])
