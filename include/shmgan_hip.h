@@ -226,6 +226,14 @@ int shm_head_fwd(const void* x, int ldx, const float* w, const float* bias, floa
 int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const float* dy, void* dx,
                  int lddx, double* dw_acc, double* db_acc, double* red, size_t npix, int c, float slope,
                  int dtype, void* stream);
+/* The same two on the UN-normalised activation a [batch, hw, c] of the block in front of the head + its InstanceNorm statistics
+ * (shm_conv2d_in_fwd's `stats`) and beta: the head applies (a - mean) * inv + beta on the fly, so that block needs no
+ * shm_in_apply and its normalised tensor is never written.  dx [G] is the gradient at the NORMALISED activation (shm_in_bwd's g1). */
+int shm_head_in_fwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* bias,
+                    float* y, int batch, int hw, int c, float slope, int dtype, void* stream);
+int shm_head_in_bwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* y,
+                    const float* dy, void* dx, int lddx, double* dw_acc, double* db_acc, double* red, int batch, int hw,
+                    int c, float slope, int dtype, void* stream);
 /* PatchGAN logits Conv2D(1, k=3, no bias) + LeakyReLU (SHM.py:365-369). x [batch,h,w,c]. */
 int shm_patch_fwd(const void* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,
                   float slope, int dtype, void* stream);

@@ -835,15 +835,35 @@ extern "C" int shm_avgpool2_fwd(const void* x, int ldx, void* y, int ldy, int ba
 
 // -------------------------------------------------------------------------- generator head
 // y[p] = lrelu(sum_c x[p][c] w[c] + b); C/4 lanes per pixel (power of two <= 64).
-template <typename T>
+// NORM: x is the UN-normalised activation of the last decoder block and the kernel applies its InstanceNorm on the fly
+// (xh = (x - mean) * inv + beta, the expression of in_apply_kernel: identical fp32 values) -- the apply pass of that block and
+// the normalised tensor do not exist.  grid.y = sample, npix = pixels per sample.
+template <typename T, bool NORM>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y, size_t npix, int c, float slope) {
+                                                       float* __restrict__ y, size_t npix, int c, float slope, const double* __restrict__ stats,
+                                                       const float* __restrict__ beta) {
     const int lanes_c = c >> 2, PP = 256 / lanes_c;
     const int pp = threadIdx.x / lanes_c, cl = threadIdx.x % lanes_c;
     f32x4 wv = *(const f32x4*)(w + cl * 4);
     const float b = bias ? bias[0] : 0.f;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = cl * 4 + e;
+            mean[e] = (float)stats[((size_t)blockIdx.y * c + ch) * 2];
+            inv[e] = (float)stats[((size_t)blockIdx.y * c + ch) * 2 + 1];
+            bt[e] = beta[ch];
+        }
+        x += (size_t)blockIdx.y * npix * ldx;
+        y += (size_t)blockIdx.y * npix;
+    }
     for (size_t p = (size_t)blockIdx.x * PP + pp; p < npix; p += (size_t)gridDim.x * PP) {
         f32x4 xv = ld4(x + p * ldx + cl * 4);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mean[e]) * inv[e] + bt[e];
+        }
         float s = xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
         for (int o = lanes_c >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (cl == 0) y[p] = shm_lrelu(s + b, slope);
@@ -859,16 +879,41 @@ extern "C" int shm_head_fwd(const void* x, int ldx, const float* w, const float*
     long blocks = ((long)npix + PP - 1) / PP;
     if (blocks > 8192) blocks = 8192;
     SHM_DISPATCH(dtype, "shm_head_fwd",
-                 hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, bias, y, npix, c, slope));
+                 hipLaunchKernelGGL((head_fwd_kernel<T, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, bias, y, npix, c, slope,
+                                    (const double*)nullptr, (const float*)nullptr));
     SHM_LAUNCH_CHECK("shm_head_fwd");
     return SHM_OK;
 }
 
-template <typename T, typename TG>
+template <typename T, typename TG, bool NORM>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
-                                                       TG* __restrict__ dx, int lddx, double* dpart, size_t npix, int c, float slope) {
+                                                       TG* __restrict__ dx, int lddx, double* dpart, size_t npix, int c, float slope,
+                                                       const double* __restrict__ stats, const float* __restrict__ beta) {
     PixMap pm(c);
     f32x4 wv = *(const f32x4*)(w + pm.cl * 4);
+    // NORM (see head_fwd_kernel): x un-normalised, grid.y = sample, npix = pixels per sample; dx is the gradient at the NORMALISED
+    // activation (what shm_in_bwd takes), the weight gradient uses the normalised value
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = pm.cl * 4 + e;
+            mean[e] = (float)stats[((size_t)blockIdx.y * c + ch) * 2];
+            inv[e] = (float)stats[((size_t)blockIdx.y * c + ch) * 2 + 1];
+            bt[e] = beta[ch];
+        }
+        x += (size_t)blockIdx.y * npix * ldx;
+        y += (size_t)blockIdx.y * npix;
+        dy += (size_t)blockIdx.y * npix;
+        dx += (size_t)blockIdx.y * npix * lddx;
+    }
+    auto norm = [&](f32x4 v) {
+        if constexpr (NORM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean[e]) * inv[e] + bt[e];
+        }
+        return v;
+    };
     double v[1][4] = {};
     double dbs = 0.0;
     constexpr int U = 4;                   // pixels in flight per thread; partial sums in fp32, accumulated in f64
@@ -882,7 +927,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
             const size_t q = p + u * stride;
             const float g = dy[q];
             dz[u] = y[q] > 0.f ? g : g * slope;
-            xv[u] = ld4(x + q * ldx + pm.cl * 4);
+            xv[u] = norm(ld4(x + q * ldx + pm.cl * 4));
         }
         float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
 #pragma unroll
@@ -899,17 +944,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     for (; p < npix; p += stride) {
         const float g = dy[p];
         const float dz = y[p] > 0.f ? g : g * slope;
-        const f32x4 xv = ld4(x + p * ldx + pm.cl * 4);
+        const f32x4 xv = norm(ld4(x + p * ldx + pm.cl * 4));
         st4(dx + p * lddx + pm.cl * 4, wv * dz);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[0][e] += (double)xv[e] * (double)dz;
         if (pm.cl == 0) dbs += (double)dz;
     }
     // staged per slot (slot = block % SHM_LRELU_RED_SLOTS): [slot][c] weight-gradient sums, then [slot] bias sums
-    double* slotw = dpart + (size_t)(blockIdx.x % SHM_LRELU_RED_SLOTS) * c;
+    const int slot = (int)((blockIdx.x + blockIdx.y) % SHM_LRELU_RED_SLOTS);
+    double* slotw = dpart + (size_t)slot * c;
     block_reduce_atomic<1>(v, pm, slotw, c, true);
     dbs = shm_wave_sum(dbs);
-    if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(dpart + (size_t)SHM_LRELU_RED_SLOTS * c + (blockIdx.x % SHM_LRELU_RED_SLOTS), dbs);
+    if ((threadIdx.x & 63) == 0 && dbs != 0.0) atomicAdd(dpart + (size_t)SHM_LRELU_RED_SLOTS * c + slot, dbs);
 }
 
 __global__ void head_fold_kernel(const double* __restrict__ dpart, double* __restrict__ dw_acc, double* __restrict__ db_acc, int c) {
@@ -937,11 +983,50 @@ extern "C" int shm_head_bwd(const void* x, int ldx, const float* w, const float*
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     SHM_DISPATCH_G(dtype, "shm_head_bwd",
-                 hipLaunchKernelGGL((head_bwd_kernel<T, TG>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, red,
-                                    npix, c, slope));
+                 hipLaunchKernelGGL((head_bwd_kernel<T, TG, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, red,
+                                    npix, c, slope, (const double*)nullptr, (const float*)nullptr));
     SHM_LAUNCH_CHECK("shm_head_bwd");
     hipLaunchKernelGGL(head_fold_kernel, dim3(shm_cdiv(c + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dw_acc, db_acc, c);
     SHM_LAUNCH_CHECK("shm_head_bwd(fold)");
+    return SHM_OK;
+}
+
+// The generator head on the UN-normalised activation of the last decoder block + that block's InstanceNorm statistics: the
+// block's apply pass (a read and a write of the largest activation of the network) is folded into the head's forward and backward.
+extern "C" int shm_head_in_fwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* bias, float* y, int batch,
+                               int hw, int c, float slope, int dtype, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && lda % 4 == 0, SHM_E_SHAPE, "shm_head_in_fwd: channels %d unsupported", c);
+    SHM_REQUIRE(a && stats && beta && w && y, SHM_E_SHAPE, "shm_head_in_fwd: null pointer");
+    if (batch == 0 || hw == 0) return SHM_OK;
+    int PP = 256 / (c / 4);
+    long blocks = ((long)hw + PP - 1) / PP;
+    const long cap = 8192 / batch > 1 ? 8192 / batch : 1;
+    if (blocks > cap) blocks = cap;
+    SHM_DISPATCH(dtype, "shm_head_in_fwd",
+                 hipLaunchKernelGGL((head_fwd_kernel<T, true>), dim3((int)blocks, batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, bias, y,
+                                    (size_t)hw, c, slope, stats, beta));
+    SHM_LAUNCH_CHECK("shm_head_in_fwd");
+    return SHM_OK;
+}
+
+extern "C" int shm_head_in_bwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* y, const float* dy, void* dx,
+                               int lddx, double* dw_acc, double* db_acc, double* red, int batch, int hw, int c, float slope, int dtype, void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && lda % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_head_in_bwd: channels %d unsupported", c);
+    SHM_REQUIRE(a && stats && beta && red && dw_acc && db_acc, SHM_E_SHAPE, "shm_head_in_bwd: null pointer");
+    if (batch == 0 || hw == 0) return SHM_OK;
+    int r = shm_zero(red, (size_t)SHM_LRELU_RED_SLOTS * (c + 1) * sizeof(double), stream);
+    if (r) return r;
+    int PP = 256 / (c / 4);
+    long blocks = ((long)hw + (long)PP * 8 - 1) / ((long)PP * 8);
+    const long cap = 4096 / batch > 1 ? 4096 / batch : 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    SHM_DISPATCH_G(dtype, "shm_head_in_bwd",
+                 hipLaunchKernelGGL((head_bwd_kernel<T, TG, true>), dim3((int)blocks, batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, y, dy, (TG*)dx,
+                                    lddx, red, (size_t)hw, c, slope, stats, beta));
+    SHM_LAUNCH_CHECK("shm_head_in_bwd");
+    hipLaunchKernelGGL(head_fold_kernel, dim3(shm_cdiv(c + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dw_acc, db_acc, c);
+    SHM_LAUNCH_CHECK("shm_head_in_bwd(fold)");
     return SHM_OK;
 }
 

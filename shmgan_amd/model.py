@@ -365,23 +365,26 @@ class Generator(_ModelBase):
         ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
 
     # -- forward --------------------------------------------------------------------------
-    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, pooled=None):
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, pooled=None, apply=True):
         """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record).
-        pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation."""
+        pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation.
+        apply=False: the consumer normalises on the fly (the head, ops.head_in_fwd): returns the un-normalised tensor."""
         _, _, k, cin, cout = self.layers[li]
         cin_p = _padk(cin, self.pad)
         A = self.arena
         a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
-        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt)
+        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt) if apply else None
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
         scr = A.get(f"stats_scratch/{n * cout}", (ops.STATS_SLOTS * n * cout * 2,), torch.float64)
         ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
                           k, 1, LRELU, stats, IN_EPS, cin_real=cin, scratch=scr)
+        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi)
+        if not apply:
+            return a, rec
         if pooled is not None:
             ops.in_apply_pool(a, cout, stats, self.betas[bi], ahat, cout, pooled, cout, n, h, w, cout)
         else:
             ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
-        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w)
         return ahat, rec
 
     def forward(self, x16, tag, attn=None):
@@ -434,13 +437,14 @@ class Generator(_ModelBase):
             ld = self.layers[li][4]
             li += 1
             bi += 1
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+            # the last block's InstanceNorm is applied by the head kernels (forward and backward) on the fly
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, apply=lvl < 3)
             recs.append(r)
             li += 1
             bi += 1
         y = A.get(f"{tag}/y", (n, S, S, 1))
-        ops.head_fwd(cur, ld, self.P.vars[2 * li], self.P.vars[2 * li + 1], y, n * S * S, ld, LRELU)
-        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, y=y, x16=x16, attn=attn is not None)
+        ops.head_in_fwd(cur, ld, r["stats"], self.betas[r["bi"]], self.P.vars[2 * li], self.P.vars[2 * li + 1], y, n, S * S, ld, LRELU)
+        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, head_rec=r, y=y, x16=x16, attn=attn is not None)
         return y
 
     # -- backward -------------------------------------------------------------------------
@@ -491,8 +495,9 @@ class Generator(_ModelBase):
         hx = c["head_x"]
         dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F), self.gdt)
         hred = A.get(f"bwd/hred/{F}", (ops.LRELU_RED_SLOTS * (F + 1),), torch.float64)
-        ops.head_bwd(hx, F, self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
-                     self._acc_slice(2 * (nl - 1) + 1), n * S * S, F, LRELU, hred)
+        hr = c["head_rec"]
+        ops.head_in_bwd(hx, F, hr["stats"], self.betas[hr["bi"]], self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
+                        self._acc_slice(2 * (nl - 1) + 1), n, S * S, F, LRELU, hred)
         ri = len(recs) - 1
         dskips = [None] * 4
         for lvl in range(3, -1, -1):

@@ -238,6 +238,15 @@ def head_fwd(x, ldx, w, bias, y, npix, c, slope):
     check(lib().shm_head_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), npix, c, slope, _dt(x), _stream()), "shm_head_fwd")
 
 
+def head_in_fwd(a, lda, stats, beta, w, bias, y, batch, hw, c, slope):
+    check(lib().shm_head_in_fwd(_p(a), lda, _p(stats), _p(beta), _p(w), _p(bias), _p(y), batch, hw, c, slope, _dt(a), _stream()), "shm_head_in_fwd")
+
+
+def head_in_bwd(a, lda, stats, beta, w, y, dy, dx, lddx, dw_acc, db_acc, batch, hw, c, slope, red):
+    check(lib().shm_head_in_bwd(_p(a), lda, _p(stats), _p(beta), _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), _p(red), batch, hw, c,
+                                slope, _dtg(a, dx), _stream()), "shm_head_in_bwd")
+
+
 def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope, red=None):
     """red: f64 scratch [LRELU_RED_SLOTS * (c + 1)] (allocated per call when omitted: tests only)."""
     if red is None:
