@@ -228,12 +228,18 @@ int shm_head_bwd(const void* x, int ldx, const float* w, const float* y, const f
                  int dtype, void* stream);
 /* The same two on the UN-normalised activation a [batch, hw, c] of the block in front of the head + its InstanceNorm statistics
  * (shm_conv2d_in_fwd's `stats`) and beta: the head applies (a - mean) * inv + beta on the fly, so that block needs no
- * shm_in_apply and its normalised tensor is never written.  dx [G] is the gradient at the NORMALISED activation (shm_in_bwd's g1). */
+ * shm_in_apply and its normalised tensor is never written.  dx [G] (may be NULL) is the gradient at the NORMALISED activation
+ * (shm_in_bwd's g1); dz_out [batch*hw] fp32 (may be NULL) = dy * lrelu'(y), the scalar factor of that gradient (dx = dz_out (x) w). */
 int shm_head_in_fwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* bias,
                     float* y, int batch, int hw, int c, float slope, int dtype, void* stream);
 int shm_head_in_bwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* y,
-                    const float* dy, void* dx, int lddx, double* dw_acc, double* db_acc, double* red, int batch, int hw,
-                    int c, float slope, int dtype, void* stream);
+                    const float* dy, void* dx, int lddx, float* dz_out, double* dw_acc, double* db_acc, double* red,
+                    int batch, int hw, int c, float slope, int dtype, void* stream);
+/* shm_in_bwd for the block in front of the head: its output gradient is the rank-1 tensor hdz[n*h*w + p] * hw_[ch] (hdz =
+ * shm_head_in_bwd's dz_out [batch*h*w] with dx = NULL, hw_ = the head kernel [c]), formed on the fly: the head writes no input
+ * gradient and neither pass of the backward reads one.  Otherwise as shm_in_bwd (red, dz, dbias, slope). */
+int shm_in_bwd_rank1(const float* hdz, const float* hw_, const void* a, int lda, const double* stats, double* red, void* dz,
+                     int lddz, double* dbias, int batch, int h, int w, int c, float slope, int dtype, void* stream);
 /* PatchGAN logits Conv2D(1, k=3, no bias) + LeakyReLU (SHM.py:365-369). x [batch,h,w,c]. */
 int shm_patch_fwd(const void* x, int ldx, const float* w, float* y, int batch, int h, int wd, int c,
                   float slope, int dtype, void* stream);

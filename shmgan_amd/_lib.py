@@ -53,7 +53,8 @@ SIGNATURES = {
     "shm_head_fwd": (I, [P, I, P, P, P, Z, I, F, I, P]),
     "shm_head_bwd": (I, [P, I, P, P, P, P, I, P, P, P, Z, I, F, I, P]),
     "shm_head_in_fwd": (I, [P, I, P, P, P, P, P, I, I, I, F, I, P]),
-    "shm_head_in_bwd": (I, [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, I, P]),
+    "shm_head_in_bwd": (I, [P, I, P, P, P, P, P, P, I, P, P, P, P, I, I, I, F, I, P]),
+    "shm_in_bwd_rank1": (I, [P, P, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
     "shm_patch_fwd": (I, [P, I, P, P, I, I, I, I, F, I, P]),
     "shm_patch_bwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, F, I, P]),
     "shm_dense_fwd": (I, [P, P, P, I, I, I, I, P]),

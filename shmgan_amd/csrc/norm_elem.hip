@@ -418,13 +418,19 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     int h, w, c, chunk;
     float slope;
     int rev;
+    const float* r1_dz;          // rank-1 gradient (R1 kernels): d_out[n, p, ch] = r1_dz[n * hw + p] * r1_w[ch] -- the generator head's
+    const float* r1_w;           // input gradient, formed on the fly instead of being written by the head and read twice here
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
 // before the branch (s_waitcnt vmcnt(0) + s_cbranch per pixel), which serialises the whole stream
 // (measured 2.0 TB/s instead of 5+).
-template <typename TG, bool G2>
-__device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, int cl) {
+template <typename TG, bool G2, bool R1 = false>
+__device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, int cl, const f32x4& wv = f32x4{0.f, 0.f, 0.f, 0.f}) {
+    if constexpr (R1) {
+        const float d = k.r1_dz[(size_t)n * k.h * k.w + p];
+        return wv * d;
+    }
     f32x4 g = ld4((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
     if constexpr (G2) {
         int y = p / k.w, x = p - y * k.w;
@@ -439,9 +445,13 @@ __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, i
 // The reduce pass walks the tensor back to front when k.rev is set (the input-gradient product that wrote g1 went front to back:
 // its last samples are still in the Infinity Cache), the apply pass that follows front to back again (it starts where the
 // reduce pass ended).
-template <typename T, typename TG, bool G2>
+template <typename T, typename TG, bool G2, bool R1 = false>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
+    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (R1) {
+        if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
+    }
     const int n = k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, hw = k.h * k.w;
     const int bx = k.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int p0 = bx * k.chunk, p1 = min(hw, p0 + k.chunk);
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             f32x4 g[U], x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                g[u] = in_bwd_dout<TG, G2>(k, n, p + u * pm.PP, pm.cl);
+                g[u] = in_bwd_dout<TG, G2, R1>(k, n, p + u * pm.PP, pm.cl, wr);
                 x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
 #pragma unroll
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
             }
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout<TG, G2>(k, n, p, pm.cl);
+            f32x4 g = in_bwd_dout<TG, G2, R1>(k, n, p, pm.cl, wr);
             f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -514,7 +524,7 @@ __device__ __forceinline__ f32x8 ld8(const float* p) {
     return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <typename TG, bool G2>
+template <typename TG, bool G2, bool R1 = false>
 __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) {
     __shared__ double red[256 * 8];
     const int lanes_c = k.c >> 3, PP = 256 / lanes_c;
@@ -531,7 +541,13 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
             mean[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2];
             inv[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2 + 1];
         }
+        f32x8 wr8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (R1) wr8 = ld8(k.r1_w + cl * 8);
         auto dout = [&](int p) {
+            if constexpr (R1) {
+                const float d = k.r1_dz[(size_t)n * hw + p];
+                return wr8 * d;
+            }
             f32x8 g = ld8((const TG*)k.g1 + ((size_t)n * hw + p) * k.ldg1 + cl * 8);
             if constexpr (G2) {
                 const int y = p / k.w, x = p - y * k.w;
@@ -595,9 +611,13 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
     }
 }
 
-template <typename T, typename TG, bool G2>
+template <typename T, typename TG, bool G2, bool R1 = false>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
+    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (R1) {
+        if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
+    }
     const int n = blockIdx.y, hw = k.h * k.w;
     const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
     double v[1][4] = {};
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             f32x4 g[U], x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                g[u] = in_bwd_dout<TG, G2>(k, n, p + u * pm.PP, pm.cl);
+                g[u] = in_bwd_dout<TG, G2, R1>(k, n, p + u * pm.PP, pm.cl, wr);
                 x[u] = ld4((const T*)k.a + ((size_t)n * hw + p + u * pm.PP) * k.lda + pm.cl * 4);
             }
             float sd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
         }
         for (; p < p1; p += pm.PP) {
-            f32x4 g = in_bwd_dout<TG, G2>(k, n, p, pm.cl);
+            f32x4 g = in_bwd_dout<TG, G2, R1>(k, n, p, pm.cl, wr);
             f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
             f32x4 d;
 #pragma unroll
@@ -678,16 +698,18 @@ __global__ __launch_bounds__(256) void dbias_fold_kernel(double* __restrict__ pa
     if (g == 0 && ch < c) dbias[ch] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
-extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
-                          const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
-                          int h, int w, int c, float slope, int dtype, void* stream) {
-    SHM_CHECK_C(c, "shm_in_bwd");
-    SHM_REQUIRE(ldg1 % 4 == 0 && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "shm_in_bwd: bad pitch");
-    SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "shm_in_bwd: pooled gradient needs even h,w");
+static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2, int ldg2, const float* r1_dz, const float* r1_w, const void* a, int lda,
+                       const double* stats, double* red, void* dz, int lddz, double* dbias, int batch, int h, int w, int c, float slope, int dtype,
+                       void* stream) {
+    const bool r1 = r1_dz != nullptr;
+    SHM_CHECK_C(c, who);
+    SHM_REQUIRE((r1 || ldg1 % 4 == 0) && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "%s: bad pitch", who);
+    SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "%s: pooled gradient needs even h,w", who);
+    SHM_REQUIRE(!(r1 && g2), SHM_E_SHAPE, "%s: the rank-1 form takes no pooled gradient", who);
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
     // `red` is zero on entry by contract and zero again on return (no memset in front of every launch)
-    InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, shm_tune(SHM_TUNE_ELEM_REVERSE)};
+    InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, shm_tune(SHM_TUNE_ELEM_REVERSE), r1_dz, r1_w};
     int hw = h * w;
     int nch = pix_chunks(hw, batch, c);
     k.chunk = shm_cdiv(hw, nch);
@@ -702,30 +724,32 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     kr.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
     dim3 gridr(shm_cdiv(hw, kr.chunk), batch);
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
-    const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && (!g2 || ldg2 % 8 == 0) &&
-                       256 / (c / 8) >= 1;
+    const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
+                       (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
     if (wide8) {
-        if (dtype == SHM_BF16) {
+        if (r1) {
+            hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false, true>), gridr, dim3(256), 0, st, kr);
+        } else if (dtype == SHM_BF16) {
             if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, true>), gridr, dim3(256), 0, st, kr);
             else hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, false>), gridr, dim3(256), 0, st, kr);
         } else {
             if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, true>), gridr, dim3(256), 0, st, kr);
             else hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false>), gridr, dim3(256), 0, st, kr);
         }
-        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-        if (g2)
-            SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
-        else
-            SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+    } else if (r1) {
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false, true>), gridr, dim3(256), 0, st, kr));
     } else if (g2) {
-        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), gridr, dim3(256), 0, st, kr));
-        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), gridr, dim3(256), 0, st, kr));
     } else {
-        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false>), gridr, dim3(256), 0, st, kr));
-        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-        SHM_DISPATCH_G(dtype, "shm_in_bwd", hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false>), gridr, dim3(256), 0, st, kr));
     }
+    SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+    if (r1)
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false, true>), grid, dim3(256), 0, st, k));
+    else if (g2)
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+    else
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
     const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
     SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(apply)", red, red_bytes, st);
     if (dbias) {
@@ -736,6 +760,22 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
     }
     SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
     return SHM_OK;
+}
+
+extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda,
+                          const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
+                          int h, int w, int c, float slope, int dtype, void* stream) {
+    SHM_REQUIRE(g1, SHM_E_SHAPE, "shm_in_bwd: null gradient");
+    return in_bwd_impl("shm_in_bwd", g1, ldg1, g2, ldg2, nullptr, nullptr, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, dtype, stream);
+}
+
+// The same backward for the block in front of the generator head, whose output gradient is the rank-1 tensor
+// d_out[n, p, ch] = hdz[n * h * w + p] * hw_[ch] (shm_head_in_bwd's dz_out and the head kernel): formed on the fly, so the head
+// never writes its input gradient and neither pass here reads it (three passes over the largest activation of the network).
+extern "C" int shm_in_bwd_rank1(const float* hdz, const float* hw_, const void* a, int lda, const double* stats, double* red, void* dz, int lddz,
+                                double* dbias, int batch, int h, int w, int c, float slope, int dtype, void* stream) {
+    SHM_REQUIRE(hdz && hw_, SHM_E_SHAPE, "shm_in_bwd_rank1: null gradient");
+    return in_bwd_impl("shm_in_bwd_rank1", nullptr, 0, nullptr, 0, hdz, hw_, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, dtype, stream);
 }
 
 // ---------------------------------------------------------------------- LeakyReLU backward
@@ -888,7 +928,7 @@ extern "C" int shm_head_fwd(const void* x, int ldx, const float* w, const float*
 template <typename T, typename TG, bool NORM>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
                                                        TG* __restrict__ dx, int lddx, double* dpart, size_t npix, int c, float slope,
-                                                       const double* __restrict__ stats, const float* __restrict__ beta) {
+                                                       const double* __restrict__ stats, const float* __restrict__ beta, float* __restrict__ dz_out) {
     PixMap pm(c);
     f32x4 wv = *(const f32x4*)(w + pm.cl * 4);
     // NORM (see head_fwd_kernel): x un-normalised, grid.y = sample, npix = pixels per sample; dx is the gradient at the NORMALISED
@@ -905,7 +945,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         x += (size_t)blockIdx.y * npix * ldx;
         y += (size_t)blockIdx.y * npix;
         dy += (size_t)blockIdx.y * npix;
-        dx += (size_t)blockIdx.y * npix * lddx;
+        if (dx) dx += (size_t)blockIdx.y * npix * lddx;
+        if (dz_out) dz_out += (size_t)blockIdx.y * npix;
     }
     auto norm = [&](f32x4 v) {
         if constexpr (NORM) {
@@ -932,7 +973,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            st4(dx + (p + u * stride) * lddx + pm.cl * 4, wv * dz[u]);
+            if (dx) st4(dx + (p + u * stride) * lddx + pm.cl * 4, wv * dz[u]);
+            if (dz_out && pm.cl == 0) dz_out[p + u * stride] = dz[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) sw[e] += xv[u][e] * dz[u];
             sb += dz[u];
@@ -945,7 +987,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         const float g = dy[p];
         const float dz = y[p] > 0.f ? g : g * slope;
         const f32x4 xv = norm(ld4(x + p * ldx + pm.cl * 4));
-        st4(dx + p * lddx + pm.cl * 4, wv * dz);
+        if (dx) st4(dx + p * lddx + pm.cl * 4, wv * dz);
+        if (dz_out && pm.cl == 0) dz_out[p] = dz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[0][e] += (double)xv[e] * (double)dz;
         if (pm.cl == 0) dbs += (double)dz;
@@ -984,7 +1027,7 @@ extern "C" int shm_head_bwd(const void* x, int ldx, const float* w, const float*
     if (blocks < 1) blocks = 1;
     SHM_DISPATCH_G(dtype, "shm_head_bwd",
                  hipLaunchKernelGGL((head_bwd_kernel<T, TG, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, w, y, dy, (TG*)dx, lddx, red,
-                                    npix, c, slope, (const double*)nullptr, (const float*)nullptr));
+                                    npix, c, slope, (const double*)nullptr, (const float*)nullptr, (float*)nullptr));
     SHM_LAUNCH_CHECK("shm_head_bwd");
     hipLaunchKernelGGL(head_fold_kernel, dim3(shm_cdiv(c + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dw_acc, db_acc, c);
     SHM_LAUNCH_CHECK("shm_head_bwd(fold)");
@@ -1010,8 +1053,10 @@ extern "C" int shm_head_in_fwd(const void* a, int lda, const double* stats, cons
 }
 
 extern "C" int shm_head_in_bwd(const void* a, int lda, const double* stats, const float* beta, const float* w, const float* y, const float* dy, void* dx,
-                               int lddx, double* dw_acc, double* db_acc, double* red, int batch, int hw, int c, float slope, int dtype, void* stream) {
-    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && lda % 4 == 0 && lddx % 4 == 0, SHM_E_SHAPE, "shm_head_in_bwd: channels %d unsupported", c);
+                               int lddx, float* dz_out, double* dw_acc, double* db_acc, double* red, int batch, int hw, int c, float slope, int dtype,
+                               void* stream) {
+    SHM_REQUIRE(c % 4 == 0 && pow2_le64(c / 4) && lda % 4 == 0 && (!dx || lddx % 4 == 0), SHM_E_SHAPE, "shm_head_in_bwd: channels %d unsupported", c);
+    SHM_REQUIRE(dx || dz_out, SHM_E_SHAPE, "shm_head_in_bwd: neither dx nor dz_out");
     SHM_REQUIRE(a && stats && beta && red && dw_acc && db_acc, SHM_E_SHAPE, "shm_head_in_bwd: null pointer");
     if (batch == 0 || hw == 0) return SHM_OK;
     int r = shm_zero(red, (size_t)SHM_LRELU_RED_SLOTS * (c + 1) * sizeof(double), stream);
@@ -1023,7 +1068,7 @@ extern "C" int shm_head_in_bwd(const void* a, int lda, const double* stats, cons
     if (blocks < 1) blocks = 1;
     SHM_DISPATCH_G(dtype, "shm_head_in_bwd",
                  hipLaunchKernelGGL((head_bwd_kernel<T, TG, true>), dim3((int)blocks, batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, y, dy, (TG*)dx,
-                                    lddx, red, (size_t)hw, c, slope, stats, beta));
+                                    lddx, red, (size_t)hw, c, slope, stats, beta, dz_out));
     SHM_LAUNCH_CHECK("shm_head_in_bwd");
     hipLaunchKernelGGL(head_fold_kernel, dim3(shm_cdiv(c + 1, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)red, dw_acc, db_acc, c);
     SHM_LAUNCH_CHECK("shm_head_in_bwd(fold)");

@@ -448,18 +448,24 @@ class Generator(_ModelBase):
         return y
 
     # -- backward -------------------------------------------------------------------------
-    def _cnl_bwd(self, tag, rec, g1, g2, n, need_dx, dx=None, dx2=None, n1=0):
+    def _cnl_bwd(self, tag, rec, g1, g2, n, need_dx, dx=None, dx2=None, n1=0, rank1=None):
         """Backward of one Conv->LReLU->IN block.  g1: gradient at the IN output (same res),
         g2: optional gradient of the 2x2 average pool that consumed the IN output.
+        rank1 = (hdz, w): g1 is the rank-1 tensor hdz (x) w of the head (formed on the fly, g1 = None).
         Accumulates dW / dbias; returns nothing (dx/dx2 are written if need_dx)."""
         li, h, w = rec["li"], rec["h"], rec["w"]
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
         dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
         red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
-        ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
-                   h, w, cout, LRELU)
+        if rank1 is not None:
+            ops.in_bwd_rank1(rank1[0], rank1[1], rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
+        else:
+            ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
+                       h, w, cout, LRELU)
         if self.debug is not None:           # test diagnostics: keep the per-layer gradients
+            if g1 is None:
+                g1 = rank1[0].reshape(n, h, w, 1) * rank1[1].reshape(1, 1, 1, -1)
             self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
         cin_p = _padk(cin, self.pad)
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
@@ -492,12 +498,15 @@ class Generator(_ModelBase):
 
     def _backward(self, dy, c, n, recs, ups, A, S, F, nl, tag, need_dx):
         # head
+        # head: weight / bias gradients and the scalar factor hdz of its input gradient (hdz (x) w is never written: the
+        # backward of the block in front of the head forms it on the fly)
         hx = c["head_x"]
-        dcur = A.get(f"bwd/d/{n}x{S}x{F}", (n, S, S, F), self.gdt)
+        hdz = A.get(f"bwd/hdz/{n}x{S}", (n, S, S), torch.float32)
         hred = A.get(f"bwd/hred/{F}", (ops.LRELU_RED_SLOTS * (F + 1),), torch.float64)
         hr = c["head_rec"]
-        ops.head_in_bwd(hx, F, hr["stats"], self.betas[hr["bi"]], self.P.vars[2 * (nl - 1)], c["y"], dy, dcur, F, self._acc_slice(2 * (nl - 1)),
-                        self._acc_slice(2 * (nl - 1) + 1), n, S * S, F, LRELU, hred)
+        ops.head_in_bwd(hx, F, hr["stats"], self.betas[hr["bi"]], self.P.vars[2 * (nl - 1)], c["y"], dy, None, 0, self._acc_slice(2 * (nl - 1)),
+                        self._acc_slice(2 * (nl - 1) + 1), n, S * S, F, LRELU, hred, dz_out=hdz)
+        dcur = None
         ri = len(recs) - 1
         dskips = [None] * 4
         for lvl in range(3, -1, -1):
@@ -507,7 +516,8 @@ class Generator(_ModelBase):
             h = r2["h"]
             cout = self.layers[r2["li"]][4]
             dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout), self.gdt)
-            self._cnl_bwd(tag, r2, dcur, None, n, True, dmid, None, cout)
+            self._cnl_bwd(tag, r2, dcur, None, n, True, dmid, None, cout,
+                          rank1=(hdz, self.P.vars[2 * (nl - 1)].reshape(-1)) if lvl == 3 else None)
             # concat block: split gradient into (du, dskip)
             cu = r1["c1"]
             cs = self.layers[r1["li"]][3] - cu

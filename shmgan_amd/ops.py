@@ -242,9 +242,15 @@ def head_in_fwd(a, lda, stats, beta, w, bias, y, batch, hw, c, slope):
     check(lib().shm_head_in_fwd(_p(a), lda, _p(stats), _p(beta), _p(w), _p(bias), _p(y), batch, hw, c, slope, _dt(a), _stream()), "shm_head_in_fwd")
 
 
-def head_in_bwd(a, lda, stats, beta, w, y, dy, dx, lddx, dw_acc, db_acc, batch, hw, c, slope, red):
-    check(lib().shm_head_in_bwd(_p(a), lda, _p(stats), _p(beta), _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dw_acc), _p(db_acc), _p(red), batch, hw, c,
-                                slope, _dtg(a, dx), _stream()), "shm_head_in_bwd")
+def head_in_bwd(a, lda, stats, beta, w, y, dy, dx, lddx, dw_acc, db_acc, batch, hw, c, slope, red, dz_out=None):
+    """dx may be None (then dz_out is required): the head's input gradient is dz_out (x) w, see in_bwd_rank1."""
+    check(lib().shm_head_in_bwd(_p(a), lda, _p(stats), _p(beta), _p(w), _p(y), _p(dy), _p(dx), lddx, _p(dz_out), _p(dw_acc), _p(db_acc), _p(red), batch,
+                                hw, c, slope, _dt(a) if dx is None else _dtg(a, dx), _stream()), "shm_head_in_bwd")
+
+
+def in_bwd_rank1(hdz, hw_, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
+    check(lib().shm_in_bwd_rank1(_p(hdz), _p(hw_), _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias), batch, h, w, c, slope, _dt(a), _stream()),
+          "shm_in_bwd_rank1")
 
 
 def head_bwd(x, ldx, w, y, dy, dx, lddx, dw_acc, db_acc, npix, c, slope, red=None):

@@ -270,6 +270,30 @@ def test_head_on_the_unnormalised_activation(n, h, c):
                 ops.head_fwd(ahat, c, dev(w), dev(b), y, n * h * h, c, 0.2)
                 ops.head_bwd(ahat, c, dev(w), y, dev(g), dx, c, dwa, dba, n * h * h, c, 0.2, red)
             res.append((host(y), host(dx.float()), host(dwa), host(dba)))
+        # the backward of the block in front of the head from the rank-1 factors (shm_in_bwd_rank1) against shm_in_bwd on the
+        # materialised gradient: fp32 to 1e-6, bf16 within the rounding of the gradient tensor it no longer stores
+        dxm = torch.empty((n, h, h, c), device="cuda", dtype=dt)
+        hdz = torch.empty((n, h, h), device="cuda")
+        dwa = torch.zeros(c, dtype=torch.float64, device="cuda")
+        dba = torch.zeros(1, dtype=torch.float64, device="cuda")
+        red = torch.zeros(ops.LRELU_RED_SLOTS * (c + 1), dtype=torch.float64, device="cuda")
+        yh = torch.empty((n, h, h, 1), device="cuda")
+        ops.head_in_fwd(ad, c, stats, dev(beta), dev(w), dev(b), yh, n, h * h, c, 0.2)
+        ops.head_in_bwd(ad, c, stats, dev(beta), dev(w), yh, dev(g), dxm, c, dwa, dba, n, h * h, c, 0.2, red, dz_out=hdz)
+        dwb, dbb = torch.zeros_like(dwa), torch.zeros_like(dba)
+        ops.head_in_bwd(ad, c, stats, dev(beta), dev(w), yh, dev(g), None, 0, dwb, dbb, n, h * h, c, 0.2, red, dz_out=hdz)
+        assert rel_l2(host(dwb), host(dwa)) < 1e-12 and rel_l2(host(dbb), host(dba)) < 1e-12
+        r3 = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
+        dz_a, dz_b = torch.empty((n, h, h, c), device="cuda", dtype=dt), torch.empty((n, h, h, c), device="cuda", dtype=dt)
+        db_a, db_b = torch.zeros(c, dtype=torch.float64, device="cuda"), torch.zeros(c, dtype=torch.float64, device="cuda")
+        ops.in_bwd(dxm, c, None, 0, ad, c, stats, r3, dz_a, c, db_a, n, h, h, c, 0.2)
+        ops.in_bwd_rank1(hdz, dev(w), ad, c, stats, r3, dz_b, c, db_b, n, h, h, c, 0.2)
+        assert float(r3.abs().max()) == 0.0
+        if tol == 0.0:
+            # (not bitwise: with the product formed in registers hipcc contracts it into the sums' FMAs)
+            assert rel_l2(host(dz_b), host(dz_a)) < 1e-6 and rel_l2(host(db_b), host(db_a)) < 1e-6
+        else:
+            assert rel_l2(host(dz_b.float()), host(dz_a.float())) < 2e-2
         (y0, dx0, w0, b0), (y1, dx1, w1, b1) = res
         if tol == 0.0:
             assert np.array_equal(y0, y1) and np.array_equal(dx0, dx1)
