@@ -260,40 +260,7 @@ def test_golden_fixture_on_device(name):
             assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
     assert np.abs(host(m.gen_Y) - gold["gen_Y"]).max() < 1e-4
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
-    # un-pinned LeakyReLU kinks: 4 M pre-activations per 64-channel layer put a few elements of EVERY layer on the other side
-    # of zero, so the typical tensor sits at ~1.5e-3 here (measured) instead of the 3e-6 of a pinned comparison --
-    # test_train_step_parity_full_size below pins them and holds every tensor to 1e-3
-    _check_grad_fixture(m, gold, med_tol=5e-3)
-
-
-def test_train_step_parity_full_size():
-    """The whole step at BASELINE's layer widths and image size (S=256, F=64, B=1) against the float64 oracle evaluated
-    on the GPU box's host cores (~1 min, ~12 GB), with the device's LeakyReLU sign pattern pinned as in
-    test_train_step_parity: named losses 1e-4, gen_Y 1e-4, every weight-gradient tensor rel-L2 <= 1e-3 and cosine >= 0.9999."""
-    S, F, B, step = 256, 64, 1, 0
-    m, (g, d, gb, db) = _mk(S, F, B)
-    inp = st.make_inputs(B, S)
-    dr = st.make_draws(step, B, S, F)
-    sf = st.style_factor_intended(S)
-    m.train_step(*inp, draws=dr, style_factor=sf, apply=False)
-    torch.cuda.synchronize()
-    masks = {"g1": m.G.lrelu_masks("g1"), "cyc": m.G.lrelu_masks("cyc"), "d": m.D.lrelu_masks()}
-    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
-    ref = st.train_step(g, d, gb, db, inp, dr, sf, F, masks=masks)
-    got = m.losses()
-    for k, v in ref["losses"].items():
-        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
-    assert np.abs(host(m.gen_Y) - ref["outs"]["gen_Y"].numpy()).max() < 1e-4
-    worst = 0.0
-    for name, P, rg in (("D", m.D.P, ref["gD"]), ("G", m.G.P, ref["gG"])):
-        for i, (got_g, r) in enumerate(zip(P.grads, rg)):
-            r = r.numpy()
-            if np.linalg.norm(r) < 1e-12:
-                continue
-            e = rel_l2(host(got_g), r)
-            worst = max(worst, e)
-            assert e < 1e-3 and cosine(host(got_g), r) > 0.9999, (name, i, e)
-    print("full-size parity: worst per-tensor rel-L2", worst)
+    _check_grad_fixture(m, gold)
 
 
 def _check_grad_fixture(m, gold, med_tol=1e-3):
