@@ -160,7 +160,7 @@ def test_discriminator_forward_backward():
     assert rel_l2(host(dx)[..., :3], gx_only.numpy()) < 1e-3
 
 
-@pytest.mark.parametrize("S,F,B,step", [(64, 16, 1, 0), (64, 16, 2, 1)])
+@pytest.mark.parametrize("S,F,B,step", [(64, 16, 1, 0), (64, 16, 2, 1), (64, 32, 1, 0)])      # F = 32: K = 32 layers (narrow weights-in-registers forms)
 def test_train_step_parity(S, F, B, step):
     m, (g, d, gb, db) = _mk(S, F, B)
     inp = st.make_inputs(B, S)
