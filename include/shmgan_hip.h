@@ -104,6 +104,10 @@ int shm_get_tuning(const char* key, int* value);
  * [tap][Cout][Cin] for the implicit-GEMM B operand. */
 int shm_transpose_taps(const float* w, void* wt, int ntaps, int rows, int cols, int rows_pad,
                        int dtype, void* stream);
+/* `count` (<= 48) such transposes in one launch: the host arrays hold one entry per layer (weights of a whole model after an
+ * optimizer step). */
+int shm_transpose_taps_multi(int count, const void* const* w, void* const* wt, const int* ntaps, const int* rows,
+                             const int* cols, const int* rows_pad, int dtype, void* stream);
 /* dst[i] = (dtype) src[i]: operand copies of weights that are already K-contiguous as stored. */
 int shm_cast_f32(const float* src, void* dst, size_t n, int dtype, void* stream);
 

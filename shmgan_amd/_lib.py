@@ -31,6 +31,7 @@ SIGNATURES = {
     "shm_set_tuning": (I, [C.c_char_p, I]),
     "shm_get_tuning": (I, [C.c_char_p, P]),
     "shm_transpose_taps": (I, [P, P, I, I, I, I, I, P]),
+    "shm_transpose_taps_multi": (I, [I, P, P, P, P, P, P, I, P]),
     "shm_cast_f32": (I, [P, P, Z, I, P]),
     "shm_conv2d_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
     "shm_conv2d_in_fwd": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, P, F, I, P]),

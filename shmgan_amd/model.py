@@ -204,10 +204,13 @@ class AttentionBranch:
         self.wk2 = torch.zeros(9 * c * c, dtype=owner.adt, device=owner.dev)
         self.ctx = None
 
-    def prepare_weights(self):
+    def transpose_items(self):
         P, c = self.o.P, self.c
-        ops.transpose_taps(P.vars[self.vi], self.wk1, 9, 1, c, self.o.pad)
-        ops.transpose_taps(P.vars[self.vi + 2], self.wk2, 9, c, c, c)
+        return [(P.vars[self.vi], self.wk1, 9, 1, c, self.o.pad), (P.vars[self.vi + 2], self.wk2, 9, c, c, c)]
+
+    def prepare_weights(self):
+        for it in self.transpose_items():
+            ops.transpose_taps(*it)
 
     def forward(self, mask, B, S):
         """mask [B,S,S,1] fp32 -> attention map [B, S/pool, S/pool, C] (activation dtype)."""
@@ -295,6 +298,7 @@ class Generator(_ModelBase):
         self.attn = [AttentionBranch(self, nbase + 4 * lvl, filter_size << lvl, 1 << lvl, f"g/attn{lvl}") for lvl in range(4)] \
             if self.attention else []
         self.weights_dirty = True
+        self._tb = None
         self.ctx = {}
         self.debug = None
         self._on_wgrad = None
@@ -329,14 +333,18 @@ class Generator(_ModelBase):
         if not self.weights_dirty:
             return
         self.P.refresh_operands()
-        for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
-            w = self.P.vars[2 * i]
-            if kind == "c":      # HWIO [t][cin][cout] -> [t][cout][cin_pad]
-                ops.transpose_taps(w, self.wk[i], k * k, cin, cout, _padk(cin, self.pad))
-            else:                # Keras convT [t][cout][cin] -> [t][cin][cout] (for its dgrad)
-                ops.transpose_taps(w, self.wk[i], 9, cout, cin, cout)
-        for br in self.attn:
-            br.prepare_weights()
+        if self._tb is None:              # one launch for every layer's K-contiguous copy
+            items = []
+            for i, (_, kind, k, cin, cout) in enumerate(self.layers[:-1]):
+                w = self.P.vars[2 * i]
+                if kind == "c":      # HWIO [t][cin][cout] -> [t][cout][cin_pad]
+                    items.append((w, self.wk[i], k * k, cin, cout, _padk(cin, self.pad)))
+                else:                # Keras convT [t][cout][cin] -> [t][cin][cout] (for its dgrad)
+                    items.append((w, self.wk[i], 9, cout, cin, cout))
+            for br in self.attn:
+                items += br.transpose_items()
+            self._tb = ops.TransposeBatch(items)
+        self._tb.run()
         self.weights_dirty = False
 
     def zero_grad(self):
@@ -645,6 +653,7 @@ class Discriminator(_ModelBase):
         self.wk = [torch.zeros(9 * self.chan[i + 1] * _padk(self.chan[i], self.pad), dtype=dtype, device=device)
                    for i in range(5)]
         self.weights_dirty = True
+        self._tb = None
         self.ctx = None
 
     def set_betas(self, arrays):
@@ -655,10 +664,12 @@ class Discriminator(_ModelBase):
         if not self.weights_dirty:
             return
         self.P.refresh_operands()
-        for i in range(5):
-            ops.transpose_taps(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _padk(self.chan[i], self.pad))
-        if self.attn is not None:
-            self.attn.prepare_weights()
+        if self._tb is None:
+            items = [(self.P.vars[i], self.wk[i], 9, self.chan[i], self.chan[i + 1], _padk(self.chan[i], self.pad)) for i in range(5)]
+            if self.attn is not None:
+                items += self.attn.transpose_items()
+            self._tb = ops.TransposeBatch(items)
+        self._tb.run()
         self.weights_dirty = False
 
     def zero_grad(self):

@@ -119,6 +119,28 @@ def cast_f32(src, dst, n):
     check(lib().shm_cast_f32(_p(src), _p(dst), n, _dt(dst), _stream()), "shm_cast_f32")
 
 
+class TransposeBatch:
+    """Host tables of shm_transpose_taps_multi for a fixed set of (w, wt, ntaps, rows, cols, rows_pad): built once (the
+    tensors are persistent views), launched after every optimizer step."""
+
+    def __init__(self, items):
+        import ctypes as C
+        self.items = list(items)              # keeps the tensors alive
+        n = len(self.items)
+        assert n <= 48
+        self.n = n
+        self.dt = _dt(self.items[0][1]) if n else 0
+        assert all(_dt(it[1]) == self.dt for it in self.items)
+        self.w = (C.c_void_p * n)(*[it[0].data_ptr() for it in self.items])
+        self.wt = (C.c_void_p * n)(*[it[1].data_ptr() for it in self.items])
+        self.ntaps, self.rows, self.cols, self.rows_pad = [(C.c_int * n)(*[int(it[k]) for it in self.items]) for k in (2, 3, 4, 5)]
+
+    def run(self):
+        if self.n:
+            check(lib().shm_transpose_taps_multi(self.n, self.w, self.wt, self.ntaps, self.rows, self.cols, self.rows_pad, self.dt, _stream()),
+                  "shm_transpose_taps_multi")
+
+
 def transpose_taps(w, wt, ntaps, rows, cols, rows_pad):
     check(lib().shm_transpose_taps(_p(w), _p(wt), ntaps, rows, cols, rows_pad, _dt(wt), _stream()), "shm_transpose_taps")
 

@@ -576,3 +576,26 @@ def test_device_random_draws():
     ops.keep_mask(m, 0.2, 99, 1)
     k = host(m)
     assert set(np.unique(k)) == {0.0, 1.0} and abs(k.mean() - 0.8) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_transpose_taps_batch_equals_the_per_layer_calls(dt):
+    """shm_transpose_taps_multi (every layer of a model in one launch) against shm_transpose_taps per layer: identical bits,
+    including the zero padding of the row pitch and shapes that are not multiples of the 32 x 32 tile."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    shapes = [(9, 10, 64, 16 if dt == torch.float32 else 32), (9, 64, 64, 64), (1, 512, 512, 512), (9, 33, 70, 48), (4, 128, 256, 128), (9, 1, 64, 32)]
+    items, ref = [], []
+    for ntaps, rows, cols, rp in shapes:
+        w = torch.from_numpy(rng.standard_normal((ntaps, rows, cols)).astype(np.float32)).cuda()
+        a = torch.full((ntaps * cols * rp,), 3.0, device="cuda", dtype=dt)
+        b = torch.full((ntaps * cols * rp,), 5.0, device="cuda", dtype=dt)
+        ops.transpose_taps(w, a, ntaps, rows, cols, rp)
+        items.append((w, b, ntaps, rows, cols, rp))
+        ref.append(a)
+    ops.TransposeBatch(items).run()
+    torch.cuda.synchronize()
+    for (w, b, ntaps, rows, cols, rp), a in zip(items, ref):
+        assert torch.equal(a, b), (ntaps, rows, cols, rp)
+        got = b.float().reshape(ntaps, cols, rp)
+        assert float(got[..., rows:].abs().max() if rp > rows else 0.0) == 0.0
