@@ -1433,6 +1433,15 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
                 v = SHM_TG_HALO64_ST;
         } else if ((long)shm_cdiv(a.M, 64) * shm_cdiv(a.nout, 128) * nphase < 256) {
             v = SHM_TG_DMA_64x64;           // not even one 64x128 tile per CU
+        } else if (nphase == 1 && a.nout > 64 && a.K <= (sizeof(T) == 2 ? 256 : 128) &&
+                   (long)shm_cdiv(a.M, 256) * shm_cdiv(a.nout, 128) >= 256) {
+            // stride-2 forward products with a short K loop (discriminator blocks, Conv2DTranspose input gradients): eight waves on a
+            // 256 x 128 tile amortise the per-step barrier and the weight slice over twice the rows (tools/bench_s2.py: bf16 64 -> 128
+            // @256x256 n = 40 230 -> 183 us, n = 96 @128x128 135 -> 110; fp32 859 -> 801, 522 -> 490; from K = 256 (fp32) / 512 (bf16) on it loses)
+            v = SHM_TG_DMA_256x128;
+        } else if (sizeof(T) == 2 && nphase == 1 && a.nout > 64 && bk32_ok && a.K >= 256) {
+            // bf16, long K: 64 channels per K step -- twice the MFMAs per barrier (256 -> 512 @32x32 n = 96: 109 -> 88 us, 512 -> 1024 @16x16: 108 -> 83)
+            v = SHM_TG_DMA_128x128_BK32;
         } else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID)) {
             // small grids (16x16 maps, the n = 8 pass of the stride-2 / transposed layers): 64-row tiles double the number of
             // blocks, so a CU holds two waves per SIMD instead of one and the K-step bubbles of one wave hide behind the other's MFMAs

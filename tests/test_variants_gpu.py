@@ -414,7 +414,8 @@ def test_default_dispatch_fp32_halo128_on_a_generator_layer():
 def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     """dgrad of generator conv2d_24 at full resolution (n = 8, 256 x 256, 128 <- 64, the gradient split into its upsampled and
     skip halves: K = 64 -> the weights-in-registers kernel, two N tiles), a 128 <- 128 dgrad at n = 16 (static-tap halo 128) and a
-    discriminator block (64 -> 128, stride 2, n = 32: 1024 tiles -> DMA 128x128)."""
+    discriminator block (64 -> 128, stride 2, n = 32: K = 64 and 512 tiles of 256 x 128 -> the eight-wave DMA tile; the same block
+    with 256 input channels -> DMA 128x128)."""
     ops = _ops()
     rng = np.random.default_rng(22)
     n, h, cin, cout = 8, 256, 128, 64
@@ -446,8 +447,19 @@ def test_default_dispatch_fp32_dgrad_256_and_dma128x128():
     ref = np.where(ref > 0, ref, 0.2 * ref)
     y = torch.empty((n, h // 2, h // 2, cout), device="cuda")
     ops.conv2d_fwd(_dev(x, "f32"), None, 0, cin, 0, _wk(w, cin, "f32"), None, y, cout, n, h, h, cin, cout, 3, 2, 0.2)
-    assert ops.last_kernel() == _sym("dma128x128", "f32"), ops.last_kernel()
+    assert ops.last_kernel() == _sym("dma256x128", "f32"), ops.last_kernel()
     assert rel_l2(host(y), ref) < 1e-5
+    n, h, cin, cout = 16, 64, 256, 256
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
+    ref = conv_ref(x, w, 2)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    for dt, sym in (("f32", "dma64x128"), ("bf16", "dma128x128_bk32")):       # 256 tiles of 128 x 128: fp32 small-grid tile, bf16 long-K tile
+        y = torch.empty((n, h // 2, h // 2, cout), device="cuda", dtype=BF if dt == "bf16" else torch.float32)
+        ops.conv2d_fwd(_dev(x, dt), None, 0, cin, 0, _wk(w, cin, dt), None, y, cout, n, h, h, cin, cout, 3, 2, 0.2)
+        assert ops.last_kernel() == _sym(sym, dt), ops.last_kernel()
+        r = conv_ref(_rnd(x, dt), _rnd(w, dt), 2)
+        assert rel_l2(host(y.float()), np.where(r > 0, r, 0.2 * r)) < TOL[dt]
 
 
 def test_default_dispatch_fp32_grid_smaller_than_the_chip():
