@@ -968,10 +968,11 @@ static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 
     // the split-K slab traffic (ns * 9*cin*cout floats written + read) small
     long M = (long)batch * ho * wo;
     int tiles = shm_cdiv(cin, 64) * shm_cdiv(cout, 64);
-    // (bf16: the MFMA kernel is ~6x faster, so the slab traffic of the split weighs more: 512 blocks measured
-    // best, 35.0 vs 36.0 ms/step at 1024)
+    // (bf16: the MFMA kernel is ~6x faster, so the slab traffic of the split weighs more and the launches, which run on the
+    // second stream beside the input-gradient chain, should leave that chain room: 256 blocks measured best with the four-row
+    // stages -- step 25.8 ms at 512, 24.9 at 256, 25.3 at 384, 26.1 at 192, 29.7 at 128; fp32: 1024 (122.3 ms; 512: 123.3, 2048: 122.9))
     const int target_tuned = shm_tune(SHM_TUNE_WGRAD_BLOCKS);
-    const int target = target_tuned ? target_tuned : (esz == 2 ? 512 : 1024);
+    const int target = target_tuned ? target_tuned : (esz == 2 ? 256 : 1024);
     int want = shm_cdiv(target, tiles);
     long maxs = (M + 255) / 256;                 // at least 256 pixels per split
     if (want > maxs) want = (int)maxs;
