@@ -55,24 +55,34 @@ def main():
                     help="f32 = BASELINE configs[1] (default, the headline line); bf16 = configs[3]/[4] (bf16 MFMA path)")
     args = ap.parse_args()
 
+    # --gpus N is the contract: N ranks, one per GPU.  Launched by the driver through torch.distributed.run the environment
+    # carries WORLD_SIZE = N; launched as plain `python bench.py --gpus N` this process only becomes the launcher: it starts
+    # the N ranks as children (before anything here touches the GPU: no exec from a GPU process) and relays their output.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong rank count",
+              file=sys.stderr, flush=True)
+        return 2
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
     t_start = time.perf_counter()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.same_device and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible (use --same-device --backend gloo "
+              "to rehearse on one GPU)", file=sys.stderr, flush=True)
+        return 2
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from shmgan_amd.dist import init_process_group
         if args.same_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+        init_process_group(args.backend, device=torch.device("cuda", local_rank))      # finite timeout: a dead rank ends the job
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -124,14 +134,16 @@ def main():
     if args.serialize:
         lane.stream = None
     note(f"model built, arena {model.arena.nbytes() / 2**30:.2f} GiB")
+    # every step hands the following batch (here: the same resident tensors) to train_step's look-ahead, as the training
+    # loop does: its weight-independent prologue is issued under this step's last gradient collective
     for i in range(args.warmup):
-        model.train_step(*inputs, draws=draws_for(i))
+        model.train_step(*inputs, draws=draws_for(i), next_batch=inputs)
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        model.train_step(*inputs, draws=draws_for(args.warmup + i))
+        model.train_step(*inputs, draws=draws_for(args.warmup + i), next_batch=inputs)
     sync()
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f}s")
@@ -145,7 +157,7 @@ def main():
             ops.TIMER = timer
         t1 = time.perf_counter()
         for i in range(args.steps):
-            model.train_step(*inputs, draws=draws_for(args.warmup + args.steps + i))
+            model.train_step(*inputs, draws=draws_for(args.warmup + args.steps + i), next_batch=inputs)
         torch.cuda.synchronize()
         dt_serial = time.perf_counter() - t1
         ops.TIMER = None
@@ -174,6 +186,10 @@ def main():
                                    + (" (BASELINE configs[4], per GPU)" if (S, B, F, args.dtype) == (256, 32, 64, "bf16") else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "losses_finite": bool(finite)},
+            # what actually ran: ranks in the process group, its backend, GPUs visible to rank 0
+            "rccl_ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
+                           "backend": dist.get_backend() if world > 1 else None,
+                           "device_count": torch.cuda.device_count(), "same_device": bool(args.same_device)},
         }
         if timer is not None:
             summ = timer.summary()
@@ -214,6 +230,23 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as children of this (GPU-free) process through
+    torch.distributed.run, exactly as the driver does, and pass rank 0's JSON line and the exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(S, F, steps, note=lambda m: None):
@@ -250,4 +283,4 @@ def cpu_baseline(S, F, steps, note=lambda m: None):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -305,9 +305,18 @@ int shm_keep_mask(float* out, size_t n, float rate, unsigned long long seed, uns
  * [D1: B][D3: 5B, k-major][D2: B][D4: 5B, k-major].  rf [12B, np], cls [12B,5].
  * Outputs: loss[16] (f64 sums over the batch of: D1_RF, D3_RF, D2_RF, D4_RF, D1_cls, D3_cls,
  * D4_cls), drf_D/dcls_D = gradient of mean_b(total_D+total_Class), drf_G [6B,np] = gradient of
- * mean_b((D1_RF + D3_RF)/6). */
+ * mean_b((D1_RF + D3_RF)/6).
+ * xent_mode selects the class-logit gradient of tf.nn.softmax_cross_entropy_with_logits (SHM.py:695-713):
+ *   SHM_XENT_TF_FUSED (the reference AS EXECUTED): TF's fused kernel returns backprop = softmax - labels and the registered
+ *     gradient is grad_loss * backprop, which is the derivative only for labels that sum to 1.  The D1 term's label row is
+ *     [0,0,0,0,TARGET_LABELS] (SHM.py:477, 533, 688, 702; TARGET_LABELS ~ U(0.8,1.2), SHM.py:986), so the executed gradient
+ *     is softmax - T*onehot;
+ *   SHM_XENT_INTENDED: the true derivative sum(labels)*softmax - labels = T*(softmax - onehot).
+ * The loss values are the same in both modes; the modes coincide when target == 1 and for every one-hot row (D3, D4). */
+#define SHM_XENT_TF_FUSED 0
+#define SHM_XENT_INTENDED 1
 int shm_dhead_losses(const float* rf, const float* cls, double* loss, float* drf_d, float* dcls_d,
-                     float* drf_g, int batch, int np, float target, void* stream);
+                     float* drf_g, int batch, int np, float target, int xent_mode, void* stream);
 /* Image-space generator losses + gradient wrt the generated Y planes.
  * gen_rgb [B,S,S,3], cyc_rgb [5B,S,S,3] (k-major), cyc_y [5B,S,S,1], cbcr [B,S,S,2],
  * orig_k [B,S,S,3] raw rgb, ds_k [B,S,S,3] standardised yuv.

@@ -181,12 +181,55 @@ def instance_norm(x, beta):
     return x * inv + (beta.view(1, -1, 1, 1) - mean * inv)
 
 
+class KinkRecorder:
+    """Collects, per (pass tag, layer), the pre-activations the float64 step finds within `thr` of LeakyReLU's kink,
+    as flat NHWC indices into the DEVICE's batched tensors ([B] rows for "g1", [5B] k-major for "cyc", [12B] ordered
+    [D1][D3 x5][D2][D4 x5] for "d") together with the side of zero the float64 value lies on.  A float32 run can only
+    disagree with float64 about the sign of such elements; tests/test_step_gpu.py pins the device to the recorded side at
+    the (few) elements where it does, which makes an un-pinned fixture comparable to 1e-3 per tensor (the reverse of the
+    `masks=` pinning of _act).  batch_total / sample_offset: the fixture is generated one sample at a time."""
+
+    def __init__(self, thr=1e-4, batch_total=1, sample_offset=0):
+        self.thr, self.B, self.b0 = float(thr), int(batch_total), int(sample_offset)
+        self.tag, self.row0 = None, 0
+        self.items = {}
+
+    def at(self, tag, group):
+        """Next forward call is device pass `tag`, rows starting at group * batch_total + sample_offset."""
+        self.tag, self.row0 = tag, group * self.B + self.b0
+
+    def add(self, layer, z):
+        zd = z.detach()
+        zn = zd.permute(0, 2, 3, 1) if zd.dim() == 4 else zd          # NCHW -> NHWC
+        near = (zn.abs() < self.thr).reshape(zn.shape[0], -1)
+        r, off = torch.nonzero(near, as_tuple=True)
+        per = near.shape[1]
+        idx = (r + self.row0) * per + off
+        pos = zn.reshape(zn.shape[0], -1)[r, off] > 0
+        key = (self.tag, layer)
+        old = self.items.get(key)
+        self.items[key] = (idx, pos) if old is None else (torch.cat([old[0], idx]), torch.cat([old[1], pos]))
+
+    def to_npz(self):
+        out = {"kink/thr": np.float64(self.thr)}
+        for (tag, layer), (idx, pos) in sorted(self.items.items()):
+            o = torch.argsort(idx)
+            out[f"kink/{tag}/{layer:02d}/idx"] = idx[o].numpy().astype(np.int64)
+            out[f"kink/{tag}/{layer:02d}/pos"] = pos[o].numpy().astype(np.bool_)
+        return out
+
+
+_KINKS = None          # active KinkRecorder (set by train_step(kinks=...) for the duration of the call)
+
+
 def _act(z, masks, idx):
     """LeakyReLU(0.2).  `masks` (optional list of NHWC bool arrays, one per activation in layer
     order) pins which side of the kink every element is evaluated on: a float32 device can round a
     |z| < 1e-6 pre-activation to the other side of 0, where the derivative jumps 0.2 <-> 1; giving
     the oracle the device's sign pattern removes those (legitimate) discontinuity events from a
     gradient comparison.  The forward value changes by at most 0.8*|z| ~ 1e-6 there."""
+    if _KINKS is not None:
+        _KINKS.add(idx, z)
     if masks is None:
         return F.leaky_relu(z, LRELU)
     m = torch.as_tensor(np.asarray(masks[idx])).bool()
@@ -403,12 +446,44 @@ def adam_apply(params, grads, st: AdamState, lr0, beta1, beta2, eps=1e-7):
 # ---------------------------------------------------------------------------
 # the step
 # ---------------------------------------------------------------------------
+class _XentTFFused(torch.autograd.Function):
+    """tf.nn.softmax_cross_entropy_with_logits(labels, logits) AS EXECUTED by TensorFlow 2.8 (call sites SHM.py:695-713).
+    Forward: -sum(labels * log_softmax(logits)) per row.  Backward wrt logits: the op's second output
+    `backprop = softmax(logits) - labels` (tensorflow/core/kernels/xent_op.h) times the incoming gradient
+    (`_SoftmaxCrossEntropyWithLogitsGrad`, tensorflow/python/ops/nn_grad.py: `grad = _BroadcastMul(grad_loss,
+    op.outputs[1])`).  That is the derivative only when every label row sums to 1; the D1 term's row is
+    [0,0,0,0,TARGET_LABELS] (SHM.py:477, 533, 688, 702) with TARGET_LABELS ~ U(0.8, 1.2) (SHM.py:986), for which the
+    true derivative would be T*softmax - labels.  Labels are constants here (no gradient wrt labels is needed).
+    TensorFlow is not installable in this container, so this is restated from TF's published sources, not run against it."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logp = torch.log_softmax(logits, dim=-1)
+        ctx.save_for_backward(logp.exp() - labels)
+        return -(labels * logp).sum(dim=-1)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (backprop,) = ctx.saved_tensors
+        return grad_loss.unsqueeze(-1) * backprop, None
+
+
+def softmax_xent(logits, labels, mode="executed"):
+    """Per-row softmax cross entropy [B]: mode "executed" = TF's fused kernel and its registered gradient (_XentTFFused),
+    "intended" = plain autograd of -sum(labels * log_softmax) (the true derivative).  Values are identical."""
+    assert mode in ("executed", "intended")
+    if mode == "executed":
+        return _XentTFFused.apply(logits, labels)
+    return -(labels * torch.log_softmax(logits, dim=-1)).sum(dim=-1)
+
+
 def _mslice(masks, lo, hi):
     return None if masks is None else [np.asarray(m)[lo:hi] for m in masks]
 
 
 def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_factor,
-               filter_size=64, dtype=torch.float64, need_grads=True, masks=None, specseg=None, attention=None):
+               filter_size=64, dtype=torch.float64, need_grads=True, masks=None, specseg=None, attention=None,
+               xent_mode="executed", kinks=None):
     """One SHM.py:467-875 forward + both tape.gradient calls (no optimizer apply).
 
     gvars/dvars/gbetas/dbetas: lists of numpy arrays or tensors (TF layouts).
@@ -421,7 +496,22 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     the step's SpecSeg mask (needs `specseg`; a constant, no gradient flows into SpecSeg) through attention_layer into
     the four generator skips and the discriminator, for every G / D call of the step.  The result then carries gGa / gDa,
     the gradients of the attention variables (G loss / D loss).  masks may hold "ga" (8) and "da" (2) sign patterns.
+    xent_mode: "executed" (default) = the class-logit gradient of TF's fused softmax-cross-entropy kernel
+    (softmax - labels, see _XentTFFused); "intended" = the true derivative.  Only D1's label row [0,0,0,0,T] tells them apart.
+    kinks: optional KinkRecorder that receives the near-kink pre-activations of every LeakyReLU of the step.
     """
+    global _KINKS
+    _KINKS = kinks
+    try:
+        return _train_step(gvars, dvars, gbetas, dbetas, inputs, draws, style_factor, filter_size, dtype, need_grads, masks,
+                           specseg, attention, xent_mode, kinks)
+    finally:
+        _KINKS = None
+
+
+def _train_step(gvars, dvars, gbetas, dbetas, inputs, draws, style_factor, filter_size, dtype, need_grads, masks, specseg,
+                attention, xent_mode, kinks):
+    at = kinks.at if kinks is not None else (lambda tag, group: None)
     mk = masks or {}
     T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dtype)
     gv = [T(a).clone().requires_grad_(need_grads) for a in gvars]
@@ -456,19 +546,24 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
         assert spec_mask is not None, "attention='live' needs the SpecSeg weights"
         ga = [T(a).clone().requires_grad_(need_grads) for a in attention["G"]]
         da = [T(a).clone().requires_grad_(need_grads) for a in attention["D"]]
+        at("ga", 0)
         attn_g = generator_attention(ga, spec_mask, mk.get("ga"))
+        at("da", 0)
         attn_d, _ = attention_layer(da, spec_mask.permute(0, 3, 1, 2), 16, mk.get("da"), 0)
 
     # G(1)  SHM.py:517-538
     rand_inp = [zeros if flags[k] else Ych[k] for k in range(5)]
     gen_input = torch.cat(rand_inp + [zeros, zeros, zeros, zeros, ones], dim=3)
+    at("g1", 0)
     gen_Y = generator_forward(gv, gb, gen_input, filter_size, masks=mk.get("g1"), attn=attn_g)
     gen_yuv = torch.cat([gen_Y, avgCbCr], dim=3)
     gen_rgb = yuv_to_rgb(gen_yuv)
 
     # D(1), D(2): training=True  SHM.py:559-563
     md = mk.get("d")
+    at("d", 0)
     rf_D1, cls_D1 = discriminator_forward(dv, db, gen_rgb, noise[:B], keep[:B], masks=_mslice(md, 0, B), attn=attn_d)
+    at("d", 6)
     rf_D2, cls_D2 = discriminator_forward(dv, db, orig[4], noise[B:], keep[B:], masks=_mslice(md, 6 * B, 7 * B), attn=attn_d)
 
     # G(2): cyclic inputs  SHM.py:576-607
@@ -477,20 +572,28 @@ def train_step(gvars, dvars, gbetas, dbetas, inputs, draws: StepDraws, style_fac
     for k in range(5):
         chans = [zeros if j == k else sub[j] for j in range(5)]
         onehot = [ones if j == k else zeros for j in range(5)]
+        at("cyc", k)
         cyc_Y.append(generator_forward(gv, gb, torch.cat(chans + onehot, dim=3), filter_size,
                                        masks=_mslice(mk.get("cyc"), k * B, (k + 1) * B), attn=attn_g))
     cyc_yuv = [torch.cat([cy, avgCbCr], dim=3) for cy in cyc_Y]
     cyc_rgb = [yuv_to_rgb(c) for c in cyc_yuv]
 
     # D(3), D(4): training=False  SHM.py:627-642
-    D3 = [discriminator_forward(dv, db, c, masks=_mslice(md, (1 + k) * B, (2 + k) * B), attn=attn_d) for k, c in enumerate(cyc_rgb)]
-    D4 = [discriminator_forward(dv, db, o, masks=_mslice(md, (7 + k) * B, (8 + k) * B), attn=attn_d) for k, o in enumerate(orig)]
+    D3, D4 = [], []
+    for k in range(5):
+        at("d", 1 + k)
+        D3.append(discriminator_forward(dv, db, cyc_rgb[k], masks=_mslice(md, (1 + k) * B, (2 + k) * B), attn=attn_d))
+    for k in range(5):
+        at("d", 7 + k)
+        D4.append(discriminator_forward(dv, db, orig[k], masks=_mslice(md, (7 + k) * B, (8 + k) * B), attn=attn_d))
 
     def mse(a, t):      # per-sample mean -> [B]
         return ((a - t) ** 2).mean(dim=(1, 2, 3))
 
-    def xent(logits, k, w=1.0):
-        return -w * torch.log_softmax(logits, dim=-1)[:, k]
+    def xent(logits, k, w=1.0):          # label row = w * onehot(k)
+        lab = torch.zeros_like(logits)
+        lab[:, k] = w
+        return softmax_xent(logits, lab, xent_mode)
 
     # losses SHM.py:669-844 (per-sample [B] vectors; reduced with mean at the end)
     D3_RF = sum(mse(D3[k][0], tl) for k in range(5))

@@ -213,6 +213,16 @@ def softmax_xent(labels, logits):
     return -(labels * logsm).sum(axis=-1)
 
 
+def softmax_xent_backprop(labels, logits):
+    """Second output of TF's SoftmaxCrossEntropyWithLogits kernel (tensorflow/core/kernels/xent_op.h):
+    backprop = softmax(logits) - labels.  The registered gradient multiplies it by the incoming loss gradient
+    (nn_grad.py, _SoftmaxCrossEntropyWithLogitsGrad), so this -- not sum(labels)*softmax - labels -- is d loss / d logits
+    as executed, whatever the labels sum to."""
+    z = logits - logits.max(axis=-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=-1, keepdims=True) - labels
+
+
 def exp_decay_lr(lr0, step, decay_steps=10000, decay_rate=0.95):
     """ExponentialDecay(staircase=False) SHM.py:169-171."""
     return lr0 * decay_rate ** (step / decay_steps)

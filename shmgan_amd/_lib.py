@@ -70,7 +70,7 @@ SIGNATURES = {
     "shm_rgb16_to_dy": (I, [P, I, P, Z, I, I, P]),
     "shm_randn": (I, [P, Z, F, C.c_ulonglong, C.c_uint, P]),
     "shm_keep_mask": (I, [P, Z, F, C.c_ulonglong, C.c_uint, P]),
-    "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "shm_dhead_losses": (I, [P, P, P, P, P, P, I, I, F, I, P]),
     "shm_image_losses_workspace": (Z, [I, I]),
     "shm_image_losses": (I, [P, P, P, P, P, P, I, F, P, P, P, P, Z, I, I, P]),
     "shm_pack_channels": (I, [P, I, I, I, P, I, Z, P]),

@@ -315,7 +315,7 @@ extern "C" int shm_rgb16_to_dy(const void* d16, int ld, float* dy, size_t n, int
 //  4 mse(rf_D2,T)  5 sum_k mse(rf_D4k,T)  6 ce_D1  7 sum_k ce_D3k  8 sum_k ce_D4k
 __global__ __launch_bounds__(64) void dhead_losses_kernel(const float* __restrict__ rf, const float* __restrict__ cls, double* __restrict__ loss,
                                                           float* __restrict__ drf_d, float* __restrict__ dcls_d, float* __restrict__ drf_g,
-                                                          int batch, int np, float T) {
+                                                          int batch, int np, float T, int xent_mode) {
     const int i = blockIdx.x;
     int group, k = 0;        // 0:D1 1:D3 2:D2 3:D4
     if (i < batch) group = 0;
@@ -349,7 +349,12 @@ __global__ __launch_bounds__(64) void dhead_losses_kernel(const float* __restric
         double ce = -(double)lw * ((double)z[lab] - lse);
         for (int j = 0; j < 5; ++j) {
             float sm = (float)exp((double)z[j] - lse);
-            dcls_d[(size_t)i * 5 + j] = coef * lw * (sm - (j == lab ? 1.0f : 0.0f)) * invB;
+            // SHM_XENT_TF_FUSED: tf.nn.softmax_cross_entropy_with_logits returns backprop = softmax - labels and its registered
+            // gradient is grad_loss * backprop (exact only when the labels sum to 1; D1's label row [0,0,0,0,T] does not);
+            // SHM_XENT_INTENDED: the true derivative of -sum(labels * log_softmax) = sum(labels) * softmax - labels
+            const float onehot = (j == lab ? 1.0f : 0.0f);
+            const float g = xent_mode == SHM_XENT_TF_FUSED ? (sm - lw * onehot) : lw * (sm - onehot);
+            dcls_d[(size_t)i * 5 + j] = coef * g * invB;
         }
         double m = smse * invnp, q = ssq * invnp;
         if (group == 0) { atomicAdd(&loss[0], m); atomicAdd(&loss[2], q); atomicAdd(&loss[6], ce); }
@@ -359,11 +364,12 @@ __global__ __launch_bounds__(64) void dhead_losses_kernel(const float* __restric
     }
 }
 
-extern "C" int shm_dhead_losses(const float* rf, const float* cls, double* loss, float* drf_d, float* dcls_d, float* drf_g, int batch, int np, float target, void* stream) {
+extern "C" int shm_dhead_losses(const float* rf, const float* cls, double* loss, float* drf_d, float* dcls_d, float* drf_g, int batch, int np, float target, int xent_mode, void* stream) {
+    SHM_REQUIRE(xent_mode == SHM_XENT_TF_FUSED || xent_mode == SHM_XENT_INTENDED, SHM_E_SHAPE, "shm_dhead_losses: xent_mode %d is neither SHM_XENT_TF_FUSED nor SHM_XENT_INTENDED", xent_mode);
     if (batch == 0) return SHM_OK;
     int r = shm_zero(loss, 16 * sizeof(double), stream);
     if (r) return r;
-    hipLaunchKernelGGL(dhead_losses_kernel, dim3(12 * batch), dim3(64), 0, (hipStream_t)stream, rf, cls, loss, drf_d, dcls_d, drf_g, batch, np, target);
+    hipLaunchKernelGGL(dhead_losses_kernel, dim3(12 * batch), dim3(64), 0, (hipStream_t)stream, rf, cls, loss, drf_d, dcls_d, drf_g, batch, np, target, xent_mode);
     SHM_LAUNCH_CHECK("shm_dhead_losses");
     return SHM_OK;
 }

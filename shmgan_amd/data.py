@@ -7,12 +7,18 @@ scaled by 1/255 and flipped top-to-bottom.  As executed the flip is unconditiona
 `x if self.random_flip else flip_up_down(x)` (datasetLoader.py:61) is traced once with the constructor's
 `self.random_flip = 0.0` (SHM.py:203); `flip_ud=` makes it explicit.
 
-Decode is PIL on the host; the decoded bytes go to the GPU as uint8 and the rest is one kernel
-(shm_resize_bilinear_u8) per image, on a side stream so the next batch is prepared under the current step.
+Decode is PIL on the host, in a WORKER THREAD: the decoded bytes land in pinned uint8 staging buffers, go to the GPU
+with non-blocking copies on the loader's side stream, and the rest is one kernel (shm_resize_bilinear_u8) per image on
+that stream.  The training thread only enqueues the next batch and, when it takes a batch, waits for the worker's
+future and makes its stream wait for the batch's event -- the 5 B decodes of batch j+1 run under step j.
+
+Under torch.distributed the loader shards by rank: global batch i of rank r is images [(i*world + r)*B, +B), so N ranks
+consume N*B distinct samples per step (the data-parallel identity of shmgan_amd/dist.py) and len() = n // (B*world).
 """
 from __future__ import annotations
 
 import os
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -34,48 +40,89 @@ def list_images(directory):
 class PolarDataset:
     """Iterable of 5-tuples of [B,S,S,3] float32 device tensors in [0,1]."""
 
-    def __init__(self, data_dir, image_size, batch_size=1, subdirs=PSD_SUBDIRS, flip_ud=True, device=None, epochs=1):
+    def __init__(self, data_dir, image_size, batch_size=1, subdirs=PSD_SUBDIRS, flip_ud=True, device=None, epochs=1,
+                 rank=None, world=None):
         self.S, self.B, self.flip_ud, self.epochs = image_size, batch_size, flip_ud, epochs
         self.files = [list_images(os.path.join(data_dir, s)) for s in subdirs]
         n = len(self.files[0])
         if any(len(f) != n for f in self.files):
             raise ValueError(f"the five view directories hold different numbers of images: {[len(f) for f in self.files]}")
         self.n = n
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.dev = torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.dev)
+        if rank is None or world is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        self.rank, self.world = int(rank), int(world)
+        self._dev, self._stream = device, None
+        self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="shm-loader")
+        # pinned staging, two generations (a batch in preparation + the one just handed over): {(gen, view, b): uint8 [H,W,3]}
+        self._pin = {}
+        self._gen_event = [None, None]
+        self._prepared = 0
+
+    @property
+    def dev(self):
+        if self._dev is None:
+            self._dev = torch.device("cuda", torch.cuda.current_device())
+        return torch.device(self._dev)
+
+    @property
+    def stream(self):
+        """The loader's side stream (created on first use: listing and sharding need no GPU)."""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.dev)
+        return self._stream
 
     def __len__(self):
-        return self.n // self.B
+        return self.n // (self.B * self.world)
 
-    def _load(self, path, out):
+    def image_index(self, index, b):
+        """Dataset position of sample b of this rank's batch `index`."""
+        return (index * self.world + self.rank) * self.B + b
+
+    def _decode(self, path, key):
         from PIL import Image
         with Image.open(path) as im:
-            a = np.array(im.convert("RGB"), dtype=np.uint8)             # own, writable copy
-        # allocated, filled and consumed on the loader stream: the caching allocator hands the block back to
-        # loader-stream allocations only, which are ordered behind the resize kernel -- no host sync needed
-        src = torch.from_numpy(a).to(self.dev, non_blocking=False)
-        ops.resize_bilinear_u8(src, out, 1.0 / 255.0, self.flip_ud)
+            a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        buf = self._pin.get(key)
+        if buf is None or tuple(buf.shape) != a.shape:
+            buf = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
+            self._pin[key] = buf
+        buf.numpy()[...] = a
+        return buf
 
-    def prepare(self, index):
-        """Start batch `index` (0-based) on the loader's stream; returns (five [B,S,S,3] tensors, ready event).
-        The outputs are ALLOCATED on the loader stream: a block the consumer has dropped is then only reused
-        after the consumer stream's work recorded by `take()` has finished (train_step is fully asynchronous and
-        reads its inputs late in the step, so allocating them on the consumer stream would let the next batch's
-        resize kernels overwrite images that queued step kernels still read)."""
-        with torch.cuda.stream(self.stream):
+    def _prepare_worker(self, index, gen):
+        """Runs on the loader thread (torch's current stream is per thread): decode into this generation's pinned buffers,
+        then enqueue copy + resize per image on the loader stream and record the batch's event."""
+        if self._gen_event[gen] is not None:         # the copies that last read this generation's staging buffers
+            self._gen_event[gen].synchronize()       # (a host wait, but on the loader thread)
+        staged = [[self._decode(self.files[v][self.image_index(index, b)], (gen, v, b)) for b in range(self.B)] for v in range(5)]
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+            # allocated, filled and consumed on the loader stream: the caching allocator hands a block back to loader-stream
+            # allocations only, which are ordered behind the resize kernel that read it
             outs = [torch.empty((self.B, self.S, self.S, 3), device=self.dev) for _ in range(5)]
             for v in range(5):
                 for b in range(self.B):
-                    self._load(self.files[v][index * self.B + b], outs[v][b])
+                    src = staged[v][b].to(self.dev, non_blocking=True)
+                    ops.resize_bilinear_u8(src, outs[v][b], 1.0 / 255.0, self.flip_ud)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._gen_event[gen] = ev
         return tuple(outs), ev
 
+    def prepare(self, index):
+        """Start batch `index` (0-based, of this rank) on the loader thread / stream; returns a future of
+        (five [B,S,S,3] tensors, ready event).  The outputs are ALLOCATED on the loader stream: a block the consumer has
+        dropped is then only reused after the consumer stream's work recorded by `take()` has finished (train_step is
+        fully asynchronous and reads its inputs late in the step, so allocating them on the consumer stream would let the
+        next batch's resize kernels overwrite images that queued step kernels still read)."""
+        gen = self._prepared & 1
+        self._prepared += 1
+        return self._pool.submit(self._prepare_worker, index, gen)
+
     def take(self, prepared):
-        """Hand a prepared batch to the current stream."""
-        outs, ev = prepared
+        """Hand a prepared batch to the current stream (waits for the loader thread's host work, not for the GPU)."""
+        outs, ev = prepared.result() if hasattr(prepared, "result") else prepared
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
         for t in outs:
@@ -87,7 +134,7 @@ class PolarDataset:
         return self.take(self.prepare(index))
 
     def __iter__(self):
-        """One batch is always in preparation on the loader stream while the previous one is consumed."""
+        """One batch is always in preparation on the loader thread while the previous one is consumed."""
         order = [i for _ in range(self.epochs) for i in range(len(self))]
         nxt = self.prepare(order[0]) if order else None
         for j in range(len(order)):
@@ -102,5 +149,6 @@ def datasetLoad(trainer, subdirs=PSD_SUBDIRS, flip_ud=True):
     ds = PolarDataset(trainer.data_dir, trainer.image_size, trainer.batch_size, subdirs, flip_ud, trainer.device,
                       epochs=trainer.num_epochs)
     trainer.stddev_arr, trainer.mean_arr, trainer.variance_arr = [], [], []
-    trainer.length_dataset, trainer.loadedDataset = ds.n, ds
-    return ds.n, ds
+    # per-rank length: batches_per_epoch = length // batch_size (SHM.py:957) then counts this rank's batches
+    trainer.length_dataset, trainer.loadedDataset = ds.n // ds.world, ds
+    return trainer.length_dataset, ds

@@ -9,12 +9,36 @@ N ranks x B samples equal to one step on N*B samples under the batch rule (mean 
 """
 from __future__ import annotations
 
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradExchangeError(RuntimeError):
+    """A gradient collective failed or timed out (a peer rank died or hung).  The step cannot be completed: the process
+    must end with a non-zero exit code so that the launcher tears the job down -- never retried, never re-exec'ed."""
+
+
+def init_process_group(backend="nccl", device=None, timeout_s=None, **kw):
+    """torch.distributed.init_process_group with a failure path for the gradient exchange: a finite collective timeout
+    (SHM_DP_TIMEOUT_S, default 300 s; the library default for nccl is 10 min, for gloo 30 min) and, for nccl (= RCCL), the
+    watchdog's asynchronous error handling, so that a rank whose peer has died aborts with an error instead of
+    waiting in all_reduce forever.  Rendezvous defaults to 127.0.0.1 (one node; the container hostname may not resolve)."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SHM_DP_TIMEOUT_S", "300"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")        # tear the process down on a failed / timed-out collective
+        if device is not None:
+            kw.setdefault("device_id", torch.device(device))
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
 
 
 class GradReducer:
@@ -32,7 +56,7 @@ class GradReducer:
         if world_size() == 1:
             return None
         if not flat.is_cuda:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._reduce(flat)
             return None
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=flat.device)
@@ -43,9 +67,18 @@ class GradReducer:
             self.stream.wait_event(ready)
             if after is not None:
                 self.stream.wait_event(after)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._reduce(flat)
             done.record(self.stream)
         return done
+
+    @staticmethod
+    def _reduce(flat):
+        """all-reduce(sum); any backend error (peer gone, timeout, aborted communicator) becomes GradExchangeError."""
+        try:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        except Exception as e:          # torch raises RuntimeError / DistBackendError / DistNetworkError depending on the backend
+            raise GradExchangeError(f"rank {dist.get_rank()}: all-reduce of a {flat.numel()}-element gradient bucket failed: "
+                                    f"{type(e).__name__}: {e}") from e
 
     @staticmethod
     def wait(event):

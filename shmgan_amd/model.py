@@ -302,6 +302,7 @@ class Generator(_ModelBase):
         self.ctx = {}
         self.debug = None
         self._on_wgrad = None
+        self._dattn = [None] * 4           # attention skip gradients of the step in flight (reset by zero_grad)
 
     # -- parameter plumbing ---------------------------------------------------------------
     def set_betas(self, arrays):
@@ -348,8 +349,11 @@ class Generator(_ModelBase):
         self.weights_dirty = False
 
     def zero_grad(self):
+        """Start of a step: clear the flat gradient and the f64 accumulators, and forget the attention skip gradients of
+        the previous step (a step that aborted between its two backward passes must not leak them into this one)."""
         ops.zero(self.P.grad)
         ops.zero(self.acc)
+        self._dattn = [None] * 4
 
     # -- live attention branch ---------------------------------------------------------------
     def attention_forward(self, mask, B):
@@ -366,7 +370,7 @@ class Generator(_ModelBase):
         """Backward of the four attention branches from the skip gradients every backward() of this step accumulated."""
         for lvl, br in enumerate(self.attn):
             br.backward(self._dattn[lvl])
-        self._dattn_live = False
+        self._dattn = [None] * 4
 
     def finish_grads(self):
         """Fold the f64-accumulated head-kernel / bias gradients into the flat fp32 gradient."""
@@ -534,14 +538,10 @@ class Generator(_ModelBase):
             self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu)
             dskips[3 - lvl] = dsk
             if c["attn"]:                       # d attn_k = sum of the skip gradient over every copy of the sample
-                B = self._attn_B
-                if lvl == 3 and not getattr(self, "_dattn_live", False):       # first backward pass of the step
-                    self._dattn = [None] * 4
+                B = self._attn_B                # (state reset by zero_grad() at the start of every step)
                 da = A.get(f"bwd/dattn{3 - lvl}/{B}", (B, h, h, cs), self.gdt)
                 ops.sum_groups(dsk, da, n, h * h * cs, B, 0, accumulate=self._dattn[3 - lvl] is not None)
                 self._dattn[3 - lvl] = da
-                if lvl == 0:
-                    self._dattn_live = True
             # Conv2DTranspose: LeakyReLU', bias grad, wgrad (roles swapped), dgrad = stride-2 conv
             tli = up["li"]
             _, _, _, tcin, tcout = self.layers[tli]
@@ -586,17 +586,22 @@ class Generator(_ModelBase):
                 return dz0 if need_dx == "dz" else None
         return None
 
-    def lrelu_masks(self, tag):
-        """Sign pattern (a > 0) of the 23 LeakyReLU outputs of the forward tagged `tag`, in layer
-        order (test diagnostics: lets the float64 oracle take the same side of every kink)."""
+    def lrelu_tensors(self, tag):
+        """The 23 stored LeakyReLU outputs of the forward tagged `tag`, in layer order: the tensors whose sign the
+        backward pass reads as the LeakyReLU mask (test diagnostics)."""
         c = self.ctx[tag]
         out = [None] * len(self.layers)
         for r in c["recs"]:
-            out[r["li"]] = (r["a"] > 0).cpu().numpy()
+            out[r["li"]] = r["a"]
         for u in c["ups"]:
-            out[u["li"]] = (u["u"] > 0).cpu().numpy()
-        out[-1] = (c["y"] > 0).cpu().numpy()
+            out[u["li"]] = u["u"]
+        out[-1] = c["y"]
         return out
+
+    def lrelu_masks(self, tag):
+        """Sign pattern (a > 0) of the 23 LeakyReLU outputs of the forward tagged `tag`, in layer
+        order (test diagnostics: lets the float64 oracle take the same side of every kink)."""
+        return [(t > 0).cpu().numpy() for t in self.lrelu_tensors(tag)]
 
     def __call__(self, x, training=False, tag="call"):
         """Keras-style call on a [N,S,S,10] tensor (reference: self.G(x, training=...))."""
@@ -829,10 +834,14 @@ class Discriminator(_ModelBase):
     def attention_masks(self):
         return [(self.attn.ctx[k] > 0).cpu().numpy() for k in ("y1", "y2")]
 
+    def lrelu_tensors(self):
+        """The 6 stored LeakyReLU outputs of the last forward (5 convs + patch logits; test diagnostics)."""
+        c = self.ctx
+        return [r["a"] for r in c["recs"]] + [c["rf"]]
+
     def lrelu_masks(self):
         """Sign pattern of the 6 LeakyReLU outputs of the last forward (5 convs + patch logits)."""
-        c = self.ctx
-        return [(r["a"] > 0).cpu().numpy() for r in c["recs"]] + [(c["rf"] > 0).cpu().numpy()]
+        return [(t > 0).cpu().numpy() for t in self.lrelu_tensors()]
 
     def __call__(self, x, training=False, noise=None, keep_mask=None):
         """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""

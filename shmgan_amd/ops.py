@@ -348,9 +348,14 @@ def keep_mask(out, rate, seed, stream_id=0):
     check(lib().shm_keep_mask(_p(out), out.numel(), rate, int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id), _stream()), "shm_keep_mask")
 
 
-def dhead_losses(rf, cls, loss, drf_d, dcls_d, drf_g, batch, np_, target):
+XENT_TF_FUSED, XENT_INTENDED = 0, 1          # SHM_XENT_* of include/shmgan_hip.h
+
+
+def dhead_losses(rf, cls, loss, drf_d, dcls_d, drf_g, batch, np_, target, xent_mode=XENT_TF_FUSED):
+    """xent_mode: XENT_TF_FUSED = the class-logit gradient TF's fused softmax-cross-entropy kernel returns (softmax - labels:
+    the reference as executed), XENT_INTENDED = the true derivative for the un-normalised D1 label row."""
     check(lib().shm_dhead_losses(_p(rf), _p(cls), _p(loss), _p(drf_d), _p(dcls_d), _p(drf_g), batch, np_, target,
-                                 _stream()), "shm_dhead_losses")
+                                 int(xent_mode), _stream()), "shm_dhead_losses")
 
 
 def image_losses_workspace(batch, s):

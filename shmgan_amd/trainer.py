@@ -64,7 +64,8 @@ _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32
 
 
 class ShmGANwithSSpecSeg:
-    def __init__(self, args=None, device=None, compute_dtype="float32", grad_dtype=None, attention="executed", **overrides):
+    def __init__(self, args=None, device=None, compute_dtype="float32", grad_dtype=None, attention="executed",
+                 xent_mode="executed", **overrides):
         """compute_dtype: "float32" (the reference's precision: exact-fp32 MFMA) or "bfloat16" (BASELINE
         configs 4-5: activations and MFMA operands in bf16, fp32 accumulation, fp32 master weights,
         statistics, losses, weight gradients and Adam).
@@ -74,6 +75,12 @@ class ShmGANwithSSpecSeg:
         generator skips (SHM.py:290-293) and the discriminator (SHM.py:359), its 10 convolutions are trained."""
         assert attention in ("executed", "live")
         self.attention = attention
+        # "executed" (default): the classification-loss gradient as TensorFlow computes it -- the fused
+        # softmax_cross_entropy_with_logits kernel hands back softmax - labels, which for D1's un-normalised label row
+        # [0,0,0,0,TARGET_LABELS] (SHM.py:477, 688, 702) is not the derivative (SURVEY-style finding 8, DESIGN section 1);
+        # "intended": the true derivative TARGET_LABELS * (softmax - onehot).  Loss values do not depend on the mode.
+        assert xent_mode in ("executed", "intended")
+        self.xent_mode = xent_mode
         self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
         # gradient-signal tensors between an input-gradient product and the next IN/LeakyReLU backward:
         # default = compute_dtype; "float32" with bf16 compute selects SHM_BF16_GF32 (include/shmgan_hip.h)
@@ -114,7 +121,11 @@ class ShmGANwithSSpecSeg:
         self._rng = np.random.default_rng(self.seed)
         self._draw_count = 0
         self._reducer = GradReducer(self.device)
+        self._prefetched = None          # _prologue() of the next batch, issued by train_step(next_batch=)
         self._loss_cache = None
+        # test diagnostics: called with no arguments between the last forward pass and the first backward kernel of a step
+        # (tests/test_step_gpu.py pins LeakyReLU signs there; never set on the hot path)
+        self.before_backward = None
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
     # ------------------------------------------------------------------ workspace
@@ -206,6 +217,30 @@ class ShmGANwithSSpecSeg:
         ops.rgb2yuv_std(rgb, yuv, acc, scale, B, S * S)
         return yuv, scale
 
+    def _prologue(self, orig, slot):
+        """The weight-independent head of a step (SHM.py:480-505 + the SpecSeg.predict of SHM.py:492): rgb->yuv +
+        standardisation of the five views, the CbCr average and the specular mask (on the second stream).  Nothing here
+        reads G's or D's weights, so train_step(next_batch=) issues it for step t+1 while step t's last gradient bucket is
+        still being all-reduced ("the next batch's weight-independent prologue"); buffers are double-buffered
+        by `slot`."""
+        A, S = self.arena, self.image_size
+        B = orig[0].shape[0]
+        ds, scales = [], []
+        for k in range(5):
+            y, sc = self.preprocess(orig[k], f"{k}/s{slot}")
+            ds.append(y)
+            scales.append(sc)
+        cbcr = A.get(f"pre/cbcr/s{slot}", (B, S, S, 2))
+        ops.avg_cbcr(ds, cbcr, B * S * S)
+        # specular mask: nothing on the gradient path reads it, so it runs on the second stream beside the generator forward
+        lane = self._get_lane()
+        if self.SpecSeg is None:
+            self.SpecSeg = self.build_specseg()
+        box = {}
+        lane.submit(lambda: box.__setitem__("mask", self.SpecSeg.forward_plane(ds[2], 3, 0, B, tag=f"specseg/step{slot}")))
+        return SimpleNamespace(slot=slot, key=tuple((t.data_ptr(), tuple(t.shape)) for t in orig), orig=orig, ds=ds,
+                               scales=scales, cbcr=cbcr, mask=box["mask"])
+
     def gram_matrix(self, x):
         """SHM.py:1176-1180 (host-side convenience on a torch tensor; not on the hot path)."""
         return torch.einsum('bijc,bijd->bcd', x, x) / float(x.shape[1] * x.shape[2])
@@ -244,8 +279,12 @@ class ShmGANwithSSpecSeg:
         return self._reducer.allreduce_async(flat, after)
 
     # ------------------------------------------------------------------ the step
-    def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True):
-        """One SHM.py:467-875 step: D update + G update from a 5-view batch [B,S,S,3] in [0,1]."""
+    def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True, next_batch=None):
+        """One SHM.py:467-875 step: D update + G update from a 5-view batch [B,S,S,3] in [0,1].
+        next_batch: the five tensors of the FOLLOWING step (or a callable returning them, called late in this step's issue
+        order; None when it returns None): their weight-independent prologue (_prologue) is issued before this step waits
+        for its last gradient collective, and the next train_step on those same tensors (same storage, not modified in
+        between) picks the result up instead of recomputing it."""
         if self.G is None:
             self.build()
         G, D, A = self.G, self.D, self.arena
@@ -268,23 +307,14 @@ class ShmGANwithSSpecSeg:
         G.prepare_weights()
         D.prepare_weights()
 
-        # ---- pre-processing (outside the tape)  SHM.py:480-505
-        ds, scales = [], []
-        for k in range(5):
-            y, sc = self.preprocess(orig[k], k)
-            ds.append(y)
-            scales.append(sc)
-        cbcr = A.get("pre/cbcr", (B, S, S, 2))
-        ops.avg_cbcr(ds, cbcr, B * npix)
-
-        # ---- specular mask: SpecSeg.predict(I90_Ych), outside the tape (SHM.py:492).  Nothing on the
-        # gradient path reads it, so it runs on the second stream beside the generator forward.
+        # ---- pre-processing (outside the tape, SHM.py:480-505) and the specular mask SpecSeg.predict(I90_Ych) (SHM.py:492):
+        # taken from the previous step's look-ahead when it was given these tensors, issued here otherwise
         lane = self._get_lane()
-        if self.SpecSeg is None:
-            self.SpecSeg = self.build_specseg()
-        box = {}
-        lane.submit(lambda: box.__setitem__("mask", self.SpecSeg.forward_plane(ds[2], 3, 0, B, tag="specseg/step")))
-        self.specular_candidate = box["mask"]
+        pro, self._prefetched = self._prefetched, None
+        if pro is None or pro.key != tuple((t.data_ptr(), tuple(t.shape)) for t in orig):
+            pro = self._prologue(orig, 0 if pro is None else pro.slot)
+        ds, scales, cbcr = pro.ds, pro.scales, pro.cbcr
+        self.specular_candidate = pro.mask
 
         # ---- live attention branch: the maps of this step's mask, shared by the six G calls and the twelve D calls
         attn_g = attn_d = None
@@ -323,7 +353,8 @@ class ShmGANwithSSpecSeg:
         drf_d = A.get("loss/drf_d", (12 * B, np_))
         dcls_d = A.get("loss/dcls_d", (12 * B, 5))
         drf_g = A.get("loss/drf_g", (6 * B, np_))
-        ops.dhead_losses(rf, cls, dl, drf_d, dcls_d, drf_g, B, np_, T)
+        ops.dhead_losses(rf, cls, dl, drf_d, dcls_d, drf_g, B, np_, T,
+                         ops.XENT_TF_FUSED if self.xent_mode == "executed" else ops.XENT_INTENDED)
         il = A.get("loss/img", (32,), torch.float64)
         dgen_y = A.get("loss/dgen_y", (B, S, S, 1))
         dcyc_y = A.get("loss/dcyc_y", (5 * B, S, S, 1))
@@ -335,6 +366,8 @@ class ShmGANwithSSpecSeg:
         lane.submit(lambda: ops.spec_loss(cyc_Y, cbcr, dptr, self.specular_candidate, sl, B, npix))
 
         # ---- D backward (weights) then its all-reduce overlapped with everything below
+        if self.before_backward is not None:
+            self.before_backward()
         D.backward_params(drf_d, dcls_d)
         ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event())
 
@@ -376,6 +409,12 @@ class ShmGANwithSSpecSeg:
         if reduce_g:
             for lo, hi in plan[None]:
                 ev_g = self._allreduce_async(G.P.grad[lo:hi])        # the reducer stream runs its collectives in order
+
+        # ---- look-ahead: the next batch's weight-independent prologue goes in front of the waits on this step's collectives
+        if next_batch is not None:
+            nb = next_batch() if callable(next_batch) else next_batch
+            if nb is not None:
+                self._prefetched = self._prologue([self._dev(t) for t in nb], pro.slot ^ 1)
 
         # ---- clip + Adam  SHM.py:859-872
         if apply:
@@ -433,19 +472,34 @@ class ShmGANwithSSpecSeg:
         self.length_dataset, dataset = datasetLoad(self)                       # SHM.py:904
         if self.G is None:
             self.build()                                                       # SHM.py:911-912, 930-931
-        os.makedirs(self.log_dir, exist_ok=True)
-        for mdl, fn in ((self.G, "Generator_summary.txt"), (self.D, "Discriminator_summary.txt"), (self.SpecSeg, "SpecSeg_summary.txt")):
-            with open(os.path.join(self.log_dir, fn), "w") as f:               # SHM.py:914-919, 933-935
-                mdl.summary(print_fn=lambda x: f.write(x + "\n"))
-        os.makedirs(self.checkpoint_save_dir, exist_ok=True)
-        latest = self._latest_checkpoint()
-        if latest is not None:                                                 # SHM.py:949-951 (delete_old_checkpoints is False)
-            self.load_npz(latest)
+        # data parallel: every rank trains on its own shard of the dataset (PolarDataset shards by rank) and holds the same
+        # weights; files (summaries, checkpoints, log lines) are rank 0's business, the others wait at a barrier
+        rank0 = self._rank() == 0
+        if not rank0:
+            print_fn = lambda *a, **k: None
+        if rank0:
+            os.makedirs(self.log_dir, exist_ok=True)
+            for mdl, fn in ((self.G, "Generator_summary.txt"), (self.D, "Discriminator_summary.txt"), (self.SpecSeg, "SpecSeg_summary.txt")):
+                with open(os.path.join(self.log_dir, fn), "w") as f:           # SHM.py:914-919, 933-935
+                    mdl.summary(print_fn=lambda x: f.write(x + "\n"))
+            os.makedirs(self.checkpoint_save_dir, exist_ok=True)
+        self._barrier()
+        latest = self._restore_latest()                                        # SHM.py:949-951 (delete_old_checkpoints is False)
+        if latest is not None:
             print_fn(f"Latest checkpoint restored!! ({latest})")
         iterator = iter(dataset)                                               # SHM.py:955
         batches_per_epoch = int(self.length_dataset / self.batch_size)         # SHM.py:957
         self.batch_step = 0
         done = False
+        total_steps = self.num_epochs * max(batches_per_epoch - 1, 0)
+        if max_steps is not None:
+            total_steps = min(total_steps, max_steps)
+        ahead = []                       # the batch train_step's look-ahead already took from the iterator
+
+        def fetch_next():
+            ahead.append(next(iterator, None))
+            return ahead[-1]
+
         for epoch in range(self.num_epochs):                                   # SHM.py:969
             self.epoch = epoch
             print_fn(f"\nStart of Training Epoch {self.epoch}")
@@ -453,8 +507,10 @@ class ShmGANwithSSpecSeg:
                 self.batch_step += 1
                 self.random_flip = bool(self._rng.random() >= 0.5)            # SHM.py:983 (inert: the map lambda is already traced)
                 self.TARGET_LABELS = float(self._rng.uniform(0.8, 1.2))       # SHM.py:986
-                element = next(iterator)                                       # SHM.py:990
-                self.train_step(*element)                                      # SHM.py:998
+                element = ahead.pop() if ahead else next(iterator)             # SHM.py:990
+                # SHM.py:998; the next tuple is taken from the loader late in this step (its prologue overlaps this step's
+                # last gradient collective), not before it: this step must not wait for the next batch's decode
+                self.train_step(*element, next_batch=fetch_next if self.batch_step < total_steps else None)
                 if max_steps is not None and self.batch_step >= max_steps:
                     done = True
                     break
@@ -478,15 +534,45 @@ class ShmGANwithSSpecSeg:
         c = self._checkpoints()
         return c[-1] if c else None
 
+    def _barrier(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+
+    def _restore_latest(self):
+        """Load the newest checkpoint that reads back; a truncated / corrupt newest file (a run killed mid-write by an
+        older version, a full disk) falls back to the one before it.  A checkpoint of the other attention mode is a
+        configuration error and raises."""
+        import zipfile
+        for path in reversed(self._checkpoints()):
+            try:
+                self.load_npz(path)
+                return path
+            except (zipfile.BadZipFile, EOFError, OSError, KeyError) as e:
+                if isinstance(e, KeyError) and "attention" in str(e):
+                    raise
+                print(f"checkpoint {path} is unreadable ({type(e).__name__}: {e}); trying the previous one")
+        return None
+
     def _save_checkpoint(self, max_to_keep=3):
-        """tf.train.CheckpointManager(ckpt, checkpoint_dir, max_to_keep=3).save() (SHM.py:944, 1127)."""
+        """tf.train.CheckpointManager(ckpt, checkpoint_dir, max_to_keep=3).save() (SHM.py:944, 1127).  Rank 0 writes (to a
+        temporary name, then an atomic rename) and prunes; every rank leaves through a barrier, so nobody races ahead into a
+        collective while the file is still being written and nobody deletes a file another rank is about to open."""
         import os
-        c = self._checkpoints()
-        n = int(os.path.basename(c[-1])[5:-4]) + 1 if c else 1
-        path = os.path.join(self.checkpoint_save_dir, f"ckpt-{n}.npz")
-        self.save_npz(path)
-        for old in (c + [path])[:-max_to_keep]:
-            os.remove(old)
+        path = None
+        if self._rank() == 0:
+            c = self._checkpoints()
+            n = int(os.path.basename(c[-1])[5:-4]) + 1 if c else 1
+            path = os.path.join(self.checkpoint_save_dir, f"ckpt-{n}.npz")
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:                 # a file object: np.savez would append ".npz" to a name
+                self.save_npz(f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, path)
+            for old in (c + [path])[:-max_to_keep]:
+                os.remove(old)
+        self._barrier()
         return path
 
     # ------------------------------------------------------------------ inference (test.py:218-297)
@@ -543,10 +629,23 @@ class ShmGANwithSSpecSeg:
         if self.SpecSeg is not None:
             for i, w in enumerate(self.SpecSeg.get_weights()):
                 d[f"SpecSeg/var{i:02d}"] = w
+        # trainer state a resumed run continues from: the step-level draw streams (flags / TARGET_LABELS generator, the
+        # Philox counter of the noise and dropout kernels), the epoch, and which graph the variables belong to
+        import json
+        d["trainer/state"] = np.array(json.dumps({
+            "attention": self.attention, "epoch": int(self.epoch), "draw_count": int(self._draw_count),
+            "rng": self._rng.bit_generator.state, "batch_step": int(getattr(self, "batch_step", 0))}))
         np.savez(path, **d)
 
     def load_npz(self, path):
         z = np.load(path)
+        state = None
+        if "trainer/state" in z.files:
+            import json
+            state = json.loads(str(z["trainer/state"]))
+            if state["attention"] != self.attention:
+                raise KeyError(f"checkpoint {path} holds an attention='{state['attention']}' model, this trainer was built with "
+                               f"attention='{self.attention}' (the live branch adds 20 + 4 variables)")
         if self.G is None:
             self.build()
         for name, M in (("G", self.G), ("D", self.D)):
@@ -559,6 +658,10 @@ class ShmGANwithSSpecSeg:
             if self.SpecSeg is None:
                 self.SpecSeg = self.build_specseg()
             self.SpecSeg.set_weights([z[f"SpecSeg/var{i:02d}"] for i in range(len(self.SpecSeg.vars))])
+        if state is not None:            # continue the draw streams instead of replaying the first run's opening steps
+            self.epoch = int(state["epoch"])
+            self._draw_count = int(state["draw_count"])
+            self._rng.bit_generator.state = state["rng"]
 
     def _img_ws(self, B):
         n = ops.image_losses_workspace(B, self.image_size)

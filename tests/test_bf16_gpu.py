@@ -380,22 +380,82 @@ def test_bf16_training_reduces_the_loss_like_fp32():
     assert curves["bfloat16"][-1] < curves["bfloat16"][0]
 
 
-def test_config4_image_size_512_runs_and_tracks_fp32():
-    """BASELINE configs[3] geometry (S=512, bf16) at B=1: finite named losses, and within 2e-2 of the fp32 run of the same step
-    (the batch of 4 is the bench's; rocprofv3 evidence for it: profiles/r02_s512_b4_bf16_*)."""
-    from shmgan_amd import ShmGANwithSSpecSeg
-    S, F, B = 512, 64, 1
-    inp, dr = st.make_inputs(B, S), st.make_draws(6, B, S, F)
-    res = {}
-    for dt in ("bfloat16", "float32"):
-        m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
-        m.train_step(*inp, draws=dr, apply=False)
-        torch.cuda.synchronize()
-        res[dt] = m.losses()
-        assert all(np.isfinite(v) for k, v in res[dt].items() if k != "ssim"), (dt, res[dt])
-        assert m.D.count_params() == 6359744 - 81920 + 5 * 16 * 16 * 1024          # Dense grows with S: 1 310 720 weights at 512
-        del m
-        torch.cuda.empty_cache()
-    for k, v in res["float32"].items():
+def _fixture(name):
+    from pathlib import Path
+    return np.load(Path(__file__).resolve().parent / "golden" / name)
+
+
+def _check_forward_fixture(m, gold, B, sub, loss_tol, y_tol, ssim_tol):
+    got = m.losses()
+    for k in got:
         if k != "ssim":
-            assert abs(res["bfloat16"][k] - v) <= 2e-2 * max(1.0, abs(v)), (k, v, res["bfloat16"][k])
+            v = float(gold[f"loss/{k}"])
+            assert abs(got[k] - v) <= loss_tol * max(1.0, abs(v)), (k, got[k], v)
+    gy = host(m.gen_Y)
+    for b in range(B):                      # per sample: subsampled values and the two moments
+        assert rel_l2(gy[b, ::sub, ::sub], gold["gen_Y_sub"][b]) <= y_tol, b
+    npix = gy[0].size                       # |sum - ref| relative to sqrt(N * sum of squares) = |mean error| / rms
+    assert (np.abs(gy.reshape(B, -1).sum(1) - gold["gen_Y_sum"]) / np.sqrt(npix * gold["gen_Y_sq"])).max() <= y_tol
+    assert np.abs((gy.reshape(B, -1) ** 2).sum(1) / gold["gen_Y_sq"] - 1).max() <= 2 * y_tol
+    assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() <= ssim_tol
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float32"])
+def test_config3_s512_b4_against_the_oracle_fixture(dt):
+    """BASELINE configs[3] -- S=512, F=64, **B=4**, bf16 -- against the committed float64-oracle fixture
+    tests/golden/step_S512_F64_B4_fwd.npz (oracle/make_golden.py --s512: forward pass of the whole step, sample by
+    sample): every named loss, per-sample gen_Y and the five SSIM values.  bf16 within SURVEY 8(c)'s 2e-2 contract; the
+    fp32 run of the same configuration within the fp32 contract (losses 1e-4, gen_Y 1e-4).  The backward of the same step
+    runs too (apply=False) and must leave finite gradients."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    from oracle import specseg_torch as sp
+    gold = _fixture("step_S512_F64_B4_fwd.npz")
+    S, F, B, step, sub = [int(v) for v in gold["meta"]]
+    assert (S, F, B) == (512, 64, 4)
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+    m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    assert m.D.count_params() == 6359744 - 81920 + 5 * 16 * 16 * 1024          # Dense grows with S: 1 310 720 weights at 512
+    m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    if dt == "bfloat16":
+        _check_forward_fixture(m, gold, B, sub, loss_tol=2e-2, y_tol=2e-2, ssim_tol=2e-2)
+    else:
+        _check_forward_fixture(m, gold, B, sub, loss_tol=1e-4, y_tol=1e-4, ssim_tol=1e-4)
+    assert bool(torch.isfinite(m.G.P.grad).all()) and bool(torch.isfinite(m.D.P.grad).all())
+    assert float(m.G.P.grad.norm()) > 0 and float(m.D.P.grad.norm()) > 0
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_config4_b32_bf16_equals_the_b8_fixture_under_the_batch_rule():
+    """BASELINE configs[4]'s per-GPU workload -- S=256, F=64, **B=32**, bf16 -- through the batch rule: the B=8 fixture's
+    inputs and draws tiled four times are 32 independent samples whose losses (means over samples) equal the B=8 fixture's
+    and whose per-sample gen_Y equals its B=8 twin (tests/golden/step_S256_F64_B8.npz, float64 oracle), to the bf16 contract
+    (2e-2).  The four copies of a sample must also agree with each other exactly (same kernels, same data)."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    from oracle import specseg_torch as sp
+    gold = _fixture("step_S256_F64_B8.npz")
+    S, F, B8, step, sub = [int(v) for v in gold["meta"][:5]]
+    R = 4
+    B = R * B8
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype="bfloat16").build()
+    m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    inp = [np.tile(a, (R, 1, 1, 1)) for a in st.make_inputs(B8, S)]
+    d8 = st.make_draws(step, B8, S, F)
+    tile2 = lambda a: np.concatenate([np.tile(a[:B8], (R, 1, 1, 1)), np.tile(a[B8:], (R, 1, 1, 1))], 0)   # [D1 rows][D2 rows]
+    dr = st.StepDraws(d8.flags, d8.target_label, tile2(d8.noise), tile2(d8.keep_mask))
+    m.train_step(*inp, draws=dr, style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    got = m.losses()
+    for k in got:
+        if k != "ssim":
+            v = float(gold[f"loss/{k}"])
+            assert abs(got[k] - v) <= 2e-2 * max(1.0, abs(v)), (k, got[k], v)
+    gy = host(m.gen_Y)
+    for b in range(B):
+        assert rel_l2(gy[b, ::sub, ::sub], gold["gen_Y_sub"][b % B8]) <= 2e-2, b
+        assert np.array_equal(gy[b], gy[b % B8]), b
+    assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() <= 2e-2
+    assert bool(torch.isfinite(m.G.P.grad).all()) and bool(torch.isfinite(m.D.P.grad).all())
+    del m
+    torch.cuda.empty_cache()

@@ -117,6 +117,51 @@ def test_instance_norm_and_pool_and_ssim():
     assert abs(tn.gauss_window().sum() - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("T", [1.0, 0.83, 1.17])
+def test_xent_executed_vs_intended_gradient(T):
+    """tf.nn.softmax_cross_entropy_with_logits as executed: values equal the plain formula; the gradient is
+    grad_loss * (softmax - labels).  For a label row [0,0,0,0,T] that coincides with the true derivative at T = 1 and
+    differs from it by (T - 1) * softmax otherwise (SHM.py:477, 688, 702); one-hot rows never differ."""
+    rng = np.random.default_rng(11)
+    lg = rng.standard_normal((4, 5))
+    lab = np.zeros((4, 5)); lab[:, 4] = T
+    gl = rng.standard_normal(4)
+    grads = {}
+    for mode in ("executed", "intended"):
+        z = torch.from_numpy(lg).requires_grad_(True)
+        v = st.softmax_xent(z, torch.from_numpy(lab), mode)
+        assert np.abs(v.detach().numpy() - tn.softmax_xent(lab, lg)).max() < 1e-13
+        grads[mode], = torch.autograd.grad((v * torch.from_numpy(gl)).sum(), [z])
+    p = torch.softmax(torch.from_numpy(lg), -1).numpy()
+    assert np.abs(grads["executed"].numpy() - gl[:, None] * tn.softmax_xent_backprop(lab, lg)).max() < 1e-13
+    assert np.abs(grads["intended"].numpy() - gl[:, None] * (T * p - lab)).max() < 1e-13
+    d = (grads["intended"] - grads["executed"]).numpy()
+    assert np.abs(d - gl[:, None] * (T - 1.0) * p).max() < 1e-13
+    if T == 1.0:
+        assert np.abs(d).max() < 1e-15
+
+
+def test_step_xent_mode_only_moves_the_discriminator_class_path():
+    """Whole step, both modes: every loss value and the whole generator gradient are identical (G receives no
+    classification gradient); the discriminator gradient differs (through D1's class logits) when T != 1."""
+    S, F, B = 32, 8, 1
+    g, d, gb, db = st.init_params(F, S)
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(0, B, S, F)
+    dr.target_label = 1.15
+    sf = st.style_factor_intended(S)
+    a = st.train_step(g, d, gb, db, inp, dr, sf, F, xent_mode="executed")
+    b = st.train_step(g, d, gb, db, inp, dr, sf, F, xent_mode="intended")
+    assert a["losses"] == b["losses"]
+    assert all(torch.equal(x, y) for x, y in zip(a["gG"], b["gG"]))
+    rel = float((a["gD"][6] - b["gD"][6]).norm() / b["gD"][6].norm())
+    assert rel > 1e-3, rel                      # the Dense(5) kernel sees the (T-1)*softmax/6 difference
+    dr.target_label = 1.0
+    a = st.train_step(g, d, gb, db, inp, dr, sf, F, xent_mode="executed")
+    b = st.train_step(g, d, gb, db, inp, dr, sf, F, xent_mode="intended")
+    assert all(float((x - y).abs().max()) < 1e-14 for x, y in zip(a["gD"], b["gD"]))
+
+
 def test_colour_standardise_rescale_gram_xent_adam():
     rng = np.random.default_rng(3)
     x = rng.random((2, 8, 8, 3))

@@ -13,7 +13,10 @@ from util import cosine, dev, host, rel_l2, t64
 pytestmark = pytest.mark.gpu
 
 
-def test_dhead_losses():
+@pytest.mark.parametrize("mode", ["executed", "intended"])
+def test_dhead_losses(mode):
+    """Both class-logit gradient modes of shm_dhead_losses against the oracle's softmax_xent: "executed" = TF's fused
+    kernel (softmax - labels; differs from the derivative on D1's label row [0,0,0,0,T], T != 1), "intended" = autograd."""
     from shmgan_amd import ops
     rng = np.random.default_rng(20)
     B, npatch, T = 3, 4, 1.07
@@ -22,7 +25,10 @@ def test_dhead_losses():
     rft, clst = t64(rf).requires_grad_(True), t64(cls).requires_grad_(True)
     sl = lambda g, k=0: slice((g + k) * B, (g + k + 1) * B)       # group start in units of B
     mse = lambda a, t: ((a - t) ** 2).mean(dim=1)
-    xent = lambda lg, k, w=1.0: -w * torch.log_softmax(lg, -1)[:, k]
+    def xent(lg, k, w=1.0):
+        lab = torch.zeros_like(lg)
+        lab[:, k] = w
+        return st.softmax_xent(lg, lab, mode)
     D1, D2 = sl(0), sl(6)
     D3 = [sl(1, k) for k in range(5)]
     D4 = [sl(7, k) for k in range(5)]
@@ -39,15 +45,26 @@ def test_dhead_losses():
     drf_d = torch.empty((12 * B, npatch), device="cuda")
     dcls_d = torch.empty((12 * B, 5), device="cuda")
     drf_g = torch.empty((6 * B, npatch), device="cuda")
-    ops.dhead_losses(dev(rf), dev(cls), loss, drf_d, dcls_d, drf_g, B, npatch, T)
+    ops.dhead_losses(dev(rf), dev(cls), loss, drf_d, dcls_d, drf_g, B, npatch, T,
+                     ops.XENT_TF_FUSED if mode == "executed" else ops.XENT_INTENDED)
     assert rel_l2(host(drf_d), gd_rf.numpy()) < 1e-5
     assert rel_l2(host(dcls_d), gd_cls.numpy()) < 1e-5
+    # the two modes differ on the D1 rows by (T - 1) * softmax / (6 B) and nowhere else
+    other = torch.empty_like(dcls_d)
+    ops.dhead_losses(dev(rf), dev(cls), loss, drf_d, other, drf_g, B, npatch, T,
+                     ops.XENT_INTENDED if mode == "executed" else ops.XENT_TF_FUSED)
+    diff = host(other) - host(dcls_d)
+    sign = 1.0 if mode == "executed" else -1.0
+    want = sign * (T - 1.0) * torch.softmax(t64(cls[:B]), -1).numpy() / (6.0 * B)
+    assert np.abs(diff[:B] - want).max() < 1e-6 and np.abs(diff[B:]).max() == 0.0
+    with pytest.raises(RuntimeError):
+        ops.dhead_losses(dev(rf), dev(cls), loss, drf_d, other, drf_g, B, npatch, T, 7)
     assert rel_l2(host(drf_g), gg_rf.numpy()[:6 * B]) < 1e-5
     L = host(loss)
     ref = [D1_RF.sum(), D3_RF.sum(), (rft[D1] ** 2).mean(dim=1).sum(),
            sum((rft[s] ** 2).mean(dim=1) for s in D3).sum(), mse(rft[D2], T).sum(),
            sum(mse(rft[s], T) for s in D4).sum(), D1_c.sum(), D3_c.sum(), D4_c.sum()]
-    assert rel_l2(L[:9], [float(r) for r in ref]) < 1e-5
+    assert rel_l2(L[:9], [float(r.detach()) for r in ref]) < 1e-5
 
 
 @pytest.mark.parametrize("B,S,flags", [(1, 32, (False, True, False, False, False)), (2, 48, (True, False, False, True, False))])
@@ -263,22 +280,51 @@ def test_golden_fixture_on_device(name):
     _check_grad_fixture(m, gold)
 
 
-def _check_grad_fixture(m, gold, med_tol=1e-3):
+def _pin_kinks(m, gold):
+    """Hook for trainer.before_backward: put the device on the float64 oracle's side of every LeakyReLU kink.  The
+    fixture lists, per pass and layer, the pre-activations with |z| < kink/thr in float64 and their sign
+    (oracle.step_torch.KinkRecorder); float32 rounding can only disagree about those.  Where the stored activation has
+    the other sign it is replaced by +-1e-30 (a forward change of at most 0.8*thr at a few elements of tensors that are
+    already consumed), so the backward pass differentiates the same piecewise-linear function as the oracle did.
+    Returns a dict that receives {(tag, layer): (listed, flipped)}."""
+    stats = {}
+
+    def hook():
+        tensors = {"g1": m.G.lrelu_tensors("g1"), "cyc": m.G.lrelu_tensors("cyc"), "d": m.D.lrelu_tensors()}
+        for key in gold.files:
+            if not key.startswith("kink/") or not key.endswith("/idx"):
+                continue
+            _, tag, layer, _ = key.split("/")
+            idx = torch.from_numpy(gold[key]).cuda()
+            pos = torch.from_numpy(gold[key[:-3] + "pos"]).cuda()
+            flat = tensors[tag][int(layer)].view(-1)
+            assert idx.numel() == 0 or int(idx.max()) < flat.numel()
+            cur = flat[idx]
+            bad = (cur > 0) != pos
+            # a disagreement may only concern a value float32 puts within rounding distance of zero
+            assert float(cur[bad].abs().max()) < 10 * float(gold["kink/thr"]) if bool(bad.any()) else True
+            flat[idx[bad]] = torch.where(pos[bad], 1e-30, -1e-30).to(flat.dtype)
+            stats[(tag, int(layer))] = (int(idx.numel()), int(bad.sum()))
+    return hook, stats
+
+
+def _check_grad_fixture(m, gold, med_tol=1e-3, worst_tol=5e-2):
     """Per-tensor gradient norms and fixed random projections of the fixture (oracle/make_golden.py: one
     default_rng(99) stream over the G tensors, then the D tensors).  A LeakyReLU kink event (see
     test_train_step_parity: the fixture cannot pin the device's sign pattern) can move one layer by ~1e-2, so the
-    worst tensor is held to 5e-2 of its norm and the median to 1e-3."""
+    worst tensor is held to 5e-2 of its norm and the median to 1e-3 -- unless the caller pinned the kinks (_pin_kinks),
+    which holds every tensor to worst_tol = 1e-3."""
     rng = np.random.default_rng(99)
     for nm, P in (("gG", m.G.P), ("gD", m.D.P)):
         n = np.array([float(t.norm()) for t in P.grads])
         ref = gold[f"{nm}/norm"]
         ok = ref > 1e-12
-        assert np.abs(n[ok] / ref[ok] - 1).max() < 5e-2, (nm, np.abs(n[ok] / ref[ok] - 1).max())
+        assert np.abs(n[ok] / ref[ok] - 1).max() < worst_tol, (nm, np.abs(n[ok] / ref[ok] - 1).max())
         assert np.median(np.abs(n[ok] / ref[ok] - 1)) < med_tol
         proj = np.array([float((t.detach().reshape(-1).double().cpu() * torch.from_numpy(rng.standard_normal(t.numel()))).sum())
                          for t in P.grads])
         err = np.abs(proj - gold[f"{nm}/proj"])[ok] / ref[ok]          # |<g - g_ref, r>| / |g_ref| ~ rel-L2 error
-        assert err.max() < 5e-2, (nm, err.max(), int(err.argmax()))
+        assert err.max() < worst_tol, (nm, err.max(), int(err.argmax()))
         assert np.median(err) < med_tol, (nm, np.median(err))
 
 
@@ -287,12 +333,15 @@ def test_golden_fixture_full_size(name):
     """BASELINE configs[1] at full size (S=256, F=64; B=8 is the bench batch) against the committed float64-oracle
     fixture: every named loss, gen_Y (subsampled values + per-sample moments), SSIM, the SpecSeg mask, and per-tensor
     gradient norms and projections of all 53 weight tensors.  This is the only place the fp32 kernels' full-size
-    dispatch (halo 128, DMA 128x128 / 128x64 / 64x128, halo weight gradient) is compared with the oracle end to end."""
+    dispatch (halo 128, DMA 128x128 / 128x64 / 64x128, halo weight gradient) is compared with the oracle end to end.
+    The fixture carries the float64 step's near-kink pre-activations; the device is pinned to their signs (_pin_kinks),
+    so ALL 53 tensors are held to 1e-3 at B=1 and at the bench batch B=8."""
     from pathlib import Path
     gold = np.load(Path(__file__).resolve().parent / "golden" / name)
     S, F, B, step, sub = [int(v) for v in gold["meta"]]
     m, _ = _mk(S, F, B)
     m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    m.before_backward, pinned = _pin_kinks(m, gold)
     m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
     torch.cuda.synchronize()
     got = m.losses()
@@ -306,10 +355,12 @@ def test_golden_fixture_full_size(name):
     assert np.abs((gy.reshape(B, -1) ** 2).sum(1) / gold["gen_Y_sq"] - 1).max() < 1e-5
     assert np.abs(host(m.specular_candidate)[:, ::sub, ::sub] - gold["specular_candidate_sub"]).max() < 1e-5
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
-    # un-pinned LeakyReLU kinks: 4 M pre-activations per 64-channel layer put a few elements of EVERY layer on the other side
-    # of zero, so the typical tensor sits at ~1.5e-3 here (measured) instead of the 3e-6 of a pinned comparison --
-    # test_train_step_parity_full_size below pins them and holds every tensor to 1e-3
-    _check_grad_fixture(m, gold, med_tol=5e-3)
+    # un-pinned, 4 M pre-activations per 64-channel layer put a few elements of EVERY layer on the other side of zero and the
+    # typical tensor sits at ~1.5e-3 (round 2: median held to 5e-3, worst to 5e-2); pinned, every tensor meets the contract
+    listed, flipped = sum(v[0] for v in pinned.values()), sum(v[1] for v in pinned.values())
+    print(f"kink pins: {flipped} of {listed} listed near-kink elements had the other sign on the device")
+    assert listed > 0 and flipped < 0.2 * listed
+    _check_grad_fixture(m, gold, med_tol=1e-3, worst_tol=1e-3)
 
 
 def test_train_step_parity_full_size():

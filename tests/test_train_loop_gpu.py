@@ -63,6 +63,73 @@ def test_train_entry_runs_epochs_and_checkpoints(tmp_path):
     assert sorted(p.name for p in (tmp_path / "ckpt").glob("*.npz")) == ["ckpt-3.npz", "ckpt-4.npz", "ckpt-5.npz"]
 
 
+def test_checkpoints_are_atomic_resumable_and_mode_checked(tmp_path):
+    """Round-2 advisor findings on the checkpoint path: the file is written under a temporary name and renamed (no
+    half-written ckpt-N.npz), a corrupt newest checkpoint falls back to the previous one, a resumed run continues the
+    draw streams (flags generator state + Philox counter) instead of replaying the first run's opening steps, and a
+    checkpoint of the other attention mode is refused with a clear error."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 32, 16, 1
+    kw = dict(image_size=S, filter_size=F, batch_size=B, checkpoint_save_dir=str(tmp_path))
+    m = ShmGANwithSSpecSeg(**kw).build()
+    inp = st.make_inputs(B, S)
+    for _ in range(3):
+        m.train_step(*inp)                       # default draws: advances _rng and _draw_count
+    p1 = m._save_checkpoint()
+    m.train_step(*inp)
+    p2 = m._save_checkpoint()
+    assert sorted(q.name for q in tmp_path.iterdir()) == ["ckpt-1.npz", "ckpt-2.npz"]         # no .tmp left behind
+    state2 = (m._draw_count, m._rng.bit_generator.state, m.G.P.iterations)
+    nxt = m._default_draws(B).flags                                                            # what step 5 would draw
+    with open(p2, "r+b") as f:                   # a kill mid-write as older versions could leave it
+        f.truncate(1000)
+    r = ShmGANwithSSpecSeg(**kw)
+    assert r._restore_latest() == p1 and r._draw_count == 3 and r.G.P.iterations == 3
+    m._save_checkpoint()                         # ckpt-3 (state after the extra _default_draws call above)
+    r2 = ShmGANwithSSpecSeg(**kw)
+    assert r2._restore_latest().endswith("ckpt-3.npz")
+    assert r2._draw_count == state2[0] + 1 and r2.G.P.iterations == state2[2]
+    r3 = ShmGANwithSSpecSeg(**kw)
+    r3.load_npz(p1)
+    for _ in range(1):
+        r3.train_step(*inp)
+    assert r3._draw_count == state2[0] and r3._rng.bit_generator.state == state2[1]            # same stream position as m had
+    assert r3._default_draws(B).flags == nxt
+    with pytest.raises(KeyError, match="attention"):
+        ShmGANwithSSpecSeg(attention="live", **kw).load_npz(p1)
+
+
+def test_lookahead_prologue_changes_nothing_but_the_issue_order():
+    """train_step(next_batch=): the next step's weight-independent prologue (rgb->yuv, standardise, CbCr average, SpecSeg
+    mask) is issued at the end of the current step into the other buffer slot and picked up by the next call.  Three
+    steps with the look-ahead (tensors, then a callable) must leave bit-identical weights, losses and masks as three
+    steps without it; a look-ahead for OTHER tensors than the next call's is discarded."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    S, F, B = 64, 16, 2
+    batches = [st.make_inputs(B, S, rank=r) for r in range(3)]
+    dev = [[torch.from_numpy(a).cuda() for a in b] for b in batches]
+    runs = []
+    for mode in ("plain", "ahead", "wrong"):
+        m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+        out = []
+        for i in range(3):
+            nb = None
+            if mode == "ahead" and i < 2:
+                nb = dev[i + 1] if i == 0 else (lambda i=i: dev[i + 1])
+            if mode == "wrong":
+                nb = dev[i]                     # not the batch the next call gets
+            m.train_step(*dev[i], draws=st.make_draws(i, B, S, F), next_batch=nb)
+            if mode == "ahead" and i < 2:
+                assert m._prefetched is not None and m._prefetched.slot == (i + 1) % 2
+            out.append((dict(m.losses()), m.specular_candidate.clone()))
+        torch.cuda.synchronize()
+        runs.append((out, m.G.P.flat.clone(), m.D.P.flat.clone()))
+    for other in runs[1:]:
+        for (l0, k0), (l1, k1) in zip(runs[0][0], other[0]):
+            assert l0 == l1 and torch.equal(k0, k1)
+        assert torch.equal(runs[0][1], other[1]) and torch.equal(runs[0][2], other[2])
+
+
 def test_loader_batches_survive_an_asynchronous_consumer(tmp_path):
     """The consumer stream runs far behind the host (as train_step does when nobody reads the losses): every batch is
     copied by a kernel queued behind a long matmul chain and dropped at once.  The loader allocates its outputs on its
