@@ -194,6 +194,37 @@ int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, const void* a
                const double* stats, double* red, void* dz, int lddz, double* dbias, int batch,
                int h, int w, int c, float slope, int dtype, void* stream);
 
+/* ---- the fused block's backward: InstanceNorm sums in the producing epilogue ("gsum") -------------------------------------
+ * The IN backward needs, per (sample, channel), sum(d_out) and sum(d_out * xhat) before it can write dz: shm_in_bwd collects
+ * them in a reduce pass of its own over d_out and the stored activation a.  But d_out is itself the OUTPUT of an input-gradient
+ * product -- the dgrad of the next layer (SHM.py:244-245 block order), or the stride-2 product that is Conv2DTranspose's input
+ * gradient -- so that product's epilogue, which holds d_out in registers, adds the sums itself:
+ *
+ *   shm_conv2d_dgrad_gsum = shm_conv2d_dgrad + for each output part (dx: channels [0,n1), dx2: the rest) an optional pair
+ *       (aux, red): red[(slot, n, ch)][0] += sum_pixels g, red[...][1] += sum_pixels g * aux, g = the value as stored.
+ *       aux = activation-typed tensor [batch, hi, wi] (pitch ldaux) aligned with the part: the consumer block's stored
+ *       activation a (so that sum g*xhat = inv * (sum g*a - mean * sum g)), or -- when dx is the gradient of an
+ *       AveragePooling2D output -- the pooled NORMALISED tensor, i.e. this layer's own input (sum g*avgpool(xhat) =
+ *       sum g*pooled - beta * sum g).
+ *   shm_conv2d_fwd_gsum = shm_conv2d_fwd + the same for its single output (the stride-2 forward form is the input gradient
+ *       of Conv2DTranspose).
+ *   red = f64 [SHM_GSUM_SLOTS][batch][channels of the part][2], ZERO on entry; the slot copies cut the per-address atomic
+ *       chains.  Whether the sums were taken in the epilogue or by a follow-up reduce pass (kernels without a gsum epilogue:
+ *       the fused four-phase kernel, odd alignments, tiny maps) is the library's business: red is complete on return.
+ *   shm_in_bwd_apply = shm_in_bwd without its reduce pass: d_out = g1 + 0.25 * unpool(g2); red = sums of g1 against a,
+ *       redp = sums of g2 against the pooled normalised tensor (NULL iff g2 is NULL; needs beta [c]); dstage = f64 [batch*c]
+ *       staging of the bias gradient (required with dbias).  red / redp / dstage are zero again on return. */
+#define SHM_GSUM_SLOTS 8
+int shm_conv2d_dgrad_gsum(const void* dy, int lddy, const void* w, void* dx, void* dx2, int n1, int lddx, int lddx2, int batch,
+                          int hi, int wi, int cin, int cout, int ksize, int stride, const void* aux, int ldaux, double* red,
+                          const void* aux2, int ldaux2, double* red2, int dtype, void* stream);
+int shm_conv2d_fwd_gsum(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk, const float* bias, void* y,
+                        int ldy, int batch, int hi, int wi, int cin, int cout, int ksize, int stride, float slope,
+                        const void* aux, int ldaux, double* red, int dtype, void* stream);
+int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda, const double* stats,
+                     const float* beta, double* red, double* redp, double* dstage, void* dz, int lddz, double* dbias,
+                     int batch, int h, int w, int c, float slope, int dtype, void* stream);
+
 /* Input gradient of a FIRST layer when only its sum over a set of input channels is needed (the step never
  * uses more: d genY sums the cyclic inputs' view channels, SHM.py:576-580; yuv_to_rgb's backward sums r,g,b).
  * Conv is linear, so the weights are summed first and the 64 -> 10 / 3 channel dgrad becomes a 64 -> 1 stencil:

@@ -45,6 +45,9 @@ SIGNATURES = {
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "shm_in_apply_pool": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
+    "shm_conv2d_dgrad_gsum": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
+    "shm_conv2d_fwd_gsum": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, I, P, I, P]),
+    "shm_in_bwd_apply": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, I, I, I, I, F, I, P]),
     "shm_sum_input_channels": (I, [P, I, I, C.c_uint, P, P]),
     "shm_conv3x3_dgrad_sum1": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "shm_lrelu_bwd": (I, [P, I, P, I, P, I, P, P, Z, I, F, I, P]),

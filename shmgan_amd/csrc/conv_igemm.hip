@@ -51,8 +51,90 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
     int stats_slots;    // slot copies: wave tile t of a sample adds into slot t % stats_slots
     unsigned stats_stride;   // batch * nout * 2
     float slope;
+    // "gsum" (input-gradient launches, shm_conv2d_dgrad_gsum / shm_conv2d_fwd_gsum): the InstanceNorm backward of the block whose
+    // OUTPUT gradient this launch writes needs, per (sample, channel), sum(g) and sum(g * x_hat) over the pixels -- a full
+    // read of g and of the activation if done as a pass of its own.  The epilogue has g in registers: it adds (sum v,
+    // sum v * aux) of the values as stored, aux = the block's stored activation at the same pixel and channel, into
+    // gred[part] = f64 [gslots][batch][channels of the part][2].  Part 0 = output channels [0, n1) (y), part 1 = [n1, nout) (y2).
+    const void* gaux[2];
+    int ldgaux[2];
+    double* gred[2];
+    int gslots, gbatch;
     TapPhase ph[4];
 };
+
+// which part of a split output a channel belongs to, its channel index inside the part and the part's channel count
+__device__ __forceinline__ int gsum_part(const TapGemmArgs& a, int n, int& nl, int& pc) {
+    const int p = n < a.n1 ? 0 : 1;
+    nl = p ? n - a.n1 : n;
+    pc = p ? a.nout - a.n1 : a.n1;
+    return p;
+}
+
+// value of the activation-typed tensor `aux` (float or bf16) as float
+template <typename T>
+__device__ __forceinline__ float gsum_aux(const void* aux, size_t idx) {
+    return (float)((const T*)aux)[idx];
+}
+
+// LDS-staged (bf16) epilogues: a lane holds eight consecutive channels of one pixel as stored (v) and loads the same eight of
+// aux (16 bytes); per-lane partial sums over the rows the lane visits
+__device__ __forceinline__ void gsum_wide_accum(const u32x4& v, const u32x4& av, float (&t1)[8], float (&t2)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v0 = __uint_as_float(v[e] << 16), v1 = __uint_as_float(v[e] & 0xffff0000u);
+        const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
+        t1[2 * e] += v0;
+        t1[2 * e + 1] += v1;
+        t2[2 * e] += v0 * a0;
+        t2[2 * e + 1] += v1 * a1;
+    }
+}
+
+// CW = 4 (a wave tile of 32 channels: lane = 4 rr + ch): reduce-scatter of the sixteen per-lane sums over the sixteen lanes rr that
+// share a channel group -- fifteen shuffles instead of 64, no values carried across patches -- after which lane (rr, ch) holds the
+// wave's total of ONE (moment, channel) pair: moment rr >> 3, channel 8 ch + (rr & 7).  One 64-lane atomic instruction per call.
+__device__ __forceinline__ float gsum_scatter16(float (&t1)[8], float (&t2)[8], int lane) {
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = t1[e];
+        v[8 + e] = t2[e];
+    }
+    // step s (lane bit 5, 4, 3, 2): keep the half of the remaining values selected by that bit, add the partner's copy of them
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int half = 8 >> s, bit = 32 >> s;
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int e = 0; e < half; ++e) {
+            const float keep = up ? v[half + e] : v[e];
+            const float send = up ? v[e] : v[half + e];
+            v[e] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    return v[0];          // value index = lane >> 2 (step s fixes index bit 3 - s from lane bit 5 - s)
+}
+
+// ... combined over the lanes that hold the same channels (lane % CW equal) and added to dst[(channel) * 2 + {0, 1}]
+template <int CW>
+__device__ __forceinline__ void gsum_wide_flush(float (&t1)[8], float (&t2)[8], int lane, double* dst) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = CW; o < 64; o <<= 1) {
+            t1[e] += __shfl_xor(t1[e], o, 64);
+            t2[e] += __shfl_xor(t2[e], o, 64);
+        }
+    }
+    if (lane < CW && dst) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(dst + 2 * e, (double)t1[e]);
+            atomicAdd(dst + 2 * e + 1, (double)t2[e]);
+        }
+    }
+}
 
 // One 16-byte fragment per operand tile: four f32 MFMAs (K = 2 each) or one bf16 MFMA (K = 16).
 template <typename T, int TM, int TN>
@@ -308,12 +390,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
         const int rr = lane / CW, ch = lane % CW;
+        const int n = n0 + wn * WTN + ch * 8;
+        int gnl, gpc;
+        const int gp = gsum_part(a, n, gnl, gpc);
+        const bool gs = a.gred[gp] != nullptr && n < a.nout;         // per lane: its eight channels lie in one part
+        const unsigned short* gaux = (const unsigned short*)a.gaux[gp] + gnl;
+        float t1[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t1[e] = t2[e] = 0.f;
 #pragma unroll
         for (int it = 0; it < WTM / RPW; ++it) {
             const int row = it * RPW + rr;
             const u32x4 v = *(const u32x4*)(tile + row * WTN + ((ch ^ (row & (CW - 1))) << 3));
             const int m = m0 + wm * WTM + row;
-            const int n = n0 + wn * WTN + ch * 8;
             if (m < a.M && n < a.nout) {
                 size_t opix;
                 if (direct) {
@@ -327,8 +416,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                     *(u32x4*)((unsigned short*)a.y + opix * a.ldy + n) = v;
                 else
                     *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
+                if (gs) gsum_wide_accum(v, *(const u32x4*)(gaux + opix * a.ldgaux[gp]), t1, t2);
             }
         }
+        if (a.gred[0] || a.gred[1]) {                      // wave-uniform
+            const int mw = m0 + wm * WTM;
+            const int img = mw / a.hw;
+            const int slot = ((mw - img * a.hw) / WTM) % a.gslots;
+            double* dst = (gs && mw < a.M) ? a.gred[gp] + ((size_t)slot * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2 : nullptr;
+            gsum_wide_flush<CW>(t1, t2, lane, dst);
+        }
+    }
+    // narrow path, gsum: per column group the aux tensor of the lane's column (null: no sums for that part)
+    bool gsn[TN];
+    const T* gauxn[TN];
+    int gldn[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+        int nl, pc;
+        const int gp = gsum_part(a, n, nl, pc);
+        gsn[j] = a.gred[gp] != nullptr && n < a.nout;
+        gauxn[j] = (const T*)a.gaux[gp] + nl;
+        gldn[j] = a.ldgaux[gp];
     }
     if (!wide) {
 #pragma unroll
@@ -355,7 +465,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;                       // statistics of the value as stored
                     s1[j] += v;
-                    s2[j] += v * v;
+                    float q = v;                         // forward statistics: sum of squares; gsum: sum of v * aux
+                    if (gsn[j]) q = gsum_aux<T>(gauxn[j], opix * (size_t)gldn[j]);
+                    s2[j] += v * q;
                     if (n < a.n1)
                         ((TO*)a.y)[opix * a.ldy + n] = vo;
                     else
@@ -383,6 +495,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 if (h == 0 && n < a.nout) {
                     double* dst = a.stats + (size_t)slot * a.stats_stride + ((size_t)img * a.nout + n) * 2;
+                    atomicAdd(dst, (double)t1);
+                    atomicAdd(dst + 1, (double)t2);
+                }
+            }
+        }
+    } else if (!wide && (a.gred[0] || a.gred[1])) {
+        const int mw = m0 + wm * WTM;
+        if (mw < a.M) {
+            const int img = mw / a.hw;
+            const int slot = ((mw - img * a.hw) / WTM) % a.gslots;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                int nl, pc;
+                const int gp = gsum_part(a, n, nl, pc);
+                if (h == 0 && gsn[j]) {
+                    double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
                     atomicAdd(dst, (double)t1);
                     atomicAdd(dst + 1, (double)t2);
                 }
@@ -680,6 +811,14 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         // (differently typed) reads above the writes
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rr = lane >> 3, ch = lane & 7;
+        const int n = n0 + wn * 64 + ch * 8;
+        int gnl, gpc;
+        const int gp = gsum_part(a, n, gnl, gpc);
+        const bool gs = a.gred[gp] != nullptr && n < a.nout;         // per lane: its eight channels lie in one part
+        const unsigned short* gaux = (const unsigned short*)a.gaux[gp] + gnl;
+        float t1[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t1[e] = t2[e] = 0.f;
 #pragma unroll
         for (int it = 0; it < 4 * TM; ++it) {
             const int row = it * 8 + rr;
@@ -687,7 +826,6 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             const int i = row >> 5, r32 = row & 31;
             const int py = 2 * TM * wm + 2 * i + (r32 >> 4), px = r32 & 15;
             const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
-            const int n = n0 + wn * 64 + ch * 8;
 #ifndef SHM_ABL_NOSTORE
             if (n < a.nout) {
                 if (n < a.n1)
@@ -696,7 +834,26 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
             }
 #endif
+            if (gs) gsum_wide_accum(v, *(const u32x4*)(gaux + opix * a.ldgaux[gp]), t1, t2);
         }
+        if (a.gred[0] || a.gred[1]) {                      // block-uniform
+            const int slot = (prem * WGM + wm) % a.gslots;
+            double* dst = gs ? a.gred[gp] + ((size_t)slot * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2 : nullptr;
+            gsum_wide_flush<8>(t1, t2, lane, dst);
+        }
+    }
+    // narrow path, gsum: per column group the aux tensor of the lane's column (null: no sums for that part)
+    bool gsn[2];
+    const T* gauxn[2];
+    int gldn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        int nl, pc;
+        const int gp = gsum_part(a, n, nl, pc);
+        gsn[j] = a.gred[gp] != nullptr && n < a.nout;
+        gauxn[j] = (const T*)a.gaux[gp] + nl;
+        gldn[j] = a.ldgaux[gp];
     }
     if (!wide) {
 #pragma unroll
@@ -715,7 +872,9 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;
                     s1[j] += v;
-                    s2[j] += v * v;
+                    float q = v;                         // forward statistics: sum of squares; gsum: sum of v * aux
+                    if (gsn[j]) q = gsum_aux<T>(gauxn[j], opix * (size_t)gldn[j]);
+                    s2[j] += v * q;
 #ifdef SHM_ABL_NOSTORE
                     if (v == 123.456f)                  // timing only: keep the value live, store nothing
 #endif
@@ -739,6 +898,21 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             const int n = n0 + wn * 64 + j * 32 + l31;
             if (h == 0 && n < a.nout) {
                 double* dst = a.stats + (size_t)slot * a.stats_stride + ((size_t)img * a.nout + n) * 2;
+                atomicAdd(dst, (double)t1);
+                atomicAdd(dst + 1, (double)t2);
+            }
+        }
+    } else if (!wide && (a.gred[0] || a.gred[1])) {
+        const int slot = (prem * WGM + wm) % a.gslots;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+            const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            int nl, pc;
+            const int gp = gsum_part(a, n, nl, pc);
+            if (h == 0 && gsn[j]) {
+                double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
                 atomicAdd(dst, (double)t1);
                 atomicAdd(dst + 1, (double)t2);
             }
@@ -770,9 +944,11 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 // ((R >> 1) + R / 18) & 3 on the halo row R, which makes every 16-lane group of the fragment reads hit 16 distinct 16-byte
 // bank units for all nine taps (brute-force check: tools/halo_swizzle_check.py).  Its address arithmetic is patch independent
 // here, so unlike in tapgemm_halo_kernel it costs nothing per tap.
-template <typename TO, int NCH>
+// GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) for bf16 outputs.
+template <typename TO, int NCH, bool GS = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs a, const int npatch) {
     typedef bf16_t T;
+    static_assert(!GS || sizeof(TO) == 2, "the gsum epilogue of this kernel is the LDS-staged bf16 one");
     constexpr int PH = 8, HC = 18, NIT = 12;            // halo (PH + 2) x 18 = 180 rows, padded to 12 DMA items of 16 rows
     constexpr int ASTG = NIT * 256;                     // floats per 32-channel chunk
     constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
@@ -885,6 +1061,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = bias;
         const float* Ab = smem + buf * ABUF;
+        // gsum form: the nine fragment addresses are formed per patch -- kept across patches (hipcc hoists them) they no longer fit
+        // beside the epilogue's sums and were spilled INSIDE the MFMA loop (27 scratch reloads per patch)
+        int hbq = hb0;
+        if constexpr (GS) asm volatile("" : "+v"(hbq));
 #ifdef SHM_WREG_PRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -898,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             // channel chunk go into the instruction's offset field
             int fa[2];
             {
-                const int hrow = hb0 + tsh[t];
+                const int hrow = hbq + tsh[t];
                 fa[0] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);      // floats; the kk = 1 group is this address ^ 8
                 fa[1] = fa[0] + 2 * HC * 16;
             }
@@ -956,6 +1136,17 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
             const int rr = lane >> 2, ch = lane & 3;
             const int n = n0 + wn * 32 + ch * 8;
+            const bool part0 = __builtin_amdgcn_readfirstlane(n0 + wn * 32) < a.n1;
+            int gpc = 0, gp = 0;
+            const unsigned short* gaux = nullptr;
+            if constexpr (GS) {
+                // A wave's 32 channels lie in one part (n1 % 32 == 0).  aux is read eight bytes (four channels) at a time, in two
+                // passes over the tile: 16-byte reads with eight channels of partial sums per lane put the kernel over its 256 VGPRs
+                // (the weights were spilled inside the MFMA loop)
+                gp = part0 ? 0 : 1;                        // wave-uniform: pointers, pitches and the part test stay in SGPRs
+                gpc = gp ? a.nout - a.n1 : a.n1;
+                gaux = a.gred[gp] ? (const unsigned short*)a.gaux[gp] : nullptr;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 16 + rr;
@@ -965,11 +1156,73 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 #ifdef SHM_ABL_NOSTORE
                 asm volatile("" ::"v"(v), "v"(opix));                               // timing only
 #else
-                if (n < a.n1)
+                // the wave's 32 channels lie in one output part (n1 % 32 == 0): a scalar branch -- a per-lane choice of the buffer
+                // descriptor makes hipcc wrap every store in a readfirstlane (waterfall) loop
+                if (part0)
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy, (opix * (unsigned)a.ldy + (unsigned)n) * 2u, 0, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(n - a.n1)) * 2u, 0, 0);
 #endif
+            }
+            if constexpr (GS) {
+                if (gaux) {                                               // wave-uniform
+                    // recompute the lane's coordinates per patch: hoisted out of the patch loop they (and every address derived
+                    // from them) stay live across the MFMA loop, which has no registers to spare
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    const int rr = ln >> 2, ch = ln & 3;
+                    const int gnl = n0 + wn * 32 + ch * 8 - (gp ? a.n1 : 0);
+                    const int slot = (int)(blockIdx.x % (unsigned)a.gslots);
+                    double* const dst = a.gred[gp] + ((size_t)slot * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2;
+                    // (aux has the extent of its output part, which the launcher checked to be below 4 GiB: 32-bit offsets)
+                    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)gaux, 0, 0xfffffff0u, 0x00020000);
+                    const unsigned ldab = (unsigned)a.ldgaux[gp] * 2u;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2 av[4];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int row = it * 16 + rr;
+                            const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + (row >> 4))) * a.wi + (x0 + (row & 15)));
+                            av[it] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsa, opix * ldab + (unsigned)(gnl + 4 * half) * 2u, 0, 0));
+                        }
+                        float t[8];            // t[0..3] = sum v, t[4..7] = sum v * aux of channels 4 half .. 4 half + 3
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = 0.f;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int row = it * 16 + rr;
+                            const u32x2 v = *(const u32x2*)(tile + row * 32 + (ch << 3) + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float v0 = __uint_as_float(v[e] << 16), v1 = __uint_as_float(v[e] & 0xffff0000u);
+                                const float a0 = __uint_as_float(av[it][e] << 16), a1 = __uint_as_float(av[it][e] & 0xffff0000u);
+                                t[2 * e] += v0;
+                                t[2 * e + 1] += v1;
+                                t[4 + 2 * e] += v0 * a0;
+                                t[4 + 2 * e + 1] += v1 * a1;
+                            }
+                        }
+                        // reduce-scatter of the eight sums over the sixteen lanes rr of a channel group: three halving steps over
+                        // lane bits 5, 4, 3 leave value index rr >> 1 (bit 2 of rr = moment, bits 1-0 = channel), a last add over
+                        // lane bit 2 completes it; the even-rr lane adds it: one atomic instruction per pass
+#pragma unroll
+                        for (int st = 0; st < 3; ++st) {
+                            const int hf = 4 >> st, bit = 32 >> st;
+                            const bool up = (ln & bit) != 0;
+#pragma unroll
+                            for (int e = 0; e < hf; ++e) {
+                                const float keep = up ? t[hf + e] : t[e];
+                                const float send = up ? t[e] : t[hf + e];
+                                t[e] = keep + __shfl_xor(send, bit, 64);
+                            }
+                        }
+                        const float tot = t[0] + __shfl_xor(t[0], 4, 64);
+                        const int vi = rr >> 1;                                   // 0..3: sum v of channel vi; 4..7: sum v * aux of channel vi - 4
+                        if ((rr & 1) == 0) atomicAdd(dst + (size_t)(4 * half + (vi & 3)) * 2 + (vi >> 2), (double)tot);
+                    }
+                }
             }
 #ifdef SHM_ABL_NOEPI
         } else if constexpr (false) {
@@ -987,10 +1240,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     const float v = fmaxf(u, u * a.slope);
                     s1 += v;
                     s2 += v * v;
-                    if (ncol < a.n1)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
-                    else if (ncol < a.nout)
+                    if (__builtin_amdgcn_readfirstlane(n0 + wn * 32) < a.n1) {        // wave-uniform (n1 % 32 == 0): no waterfall loop
+                        if (ncol < a.nout)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
+                    } else if (ncol < a.nout) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(ncol - a.n1)) * 4u, 0, 0);
+                    }
                 }
         }
         S1 += s1;
@@ -1000,7 +1255,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 #if defined(SHM_ABL_NOSTORE) || defined(SHM_ABL_NOEPI)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        if constexpr (kWide)
+        if constexpr (kWide && GS) {
+            if (a.gred[n0 + wn * 32 < a.n1 ? 0 : 1])                 // wave-uniform: four stores and the gsum atomic
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if constexpr (kWide)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1022,7 +1282,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // InstanceNorm sums are carried in registers (f64) across the patches of an image.  LDS rows are 64 bytes (16 channels) with
 // the DMA source-side swizzle chunk' = (chunk + (R >> 1)) & 3 on the halo row R: conflict free for this instruction's lane
 // groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/halo_swizzle_check.py).
-template <int NCH, int WN = 4, bool TWO = false>
+// GS: the gsum epilogue (input-gradient launches, see TapGemmArgs): S2 carries sum(v * aux) instead of sum(v * v).
+template <int NCH, int WN = 4, bool TWO = false, bool GS = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
     // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
     // patches of 8 / 16 / 32 rows -- the narrow forms serve SpecSeg's 16- and 32-channel layers without idle N waves
@@ -1100,19 +1361,32 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
 
     double S1 = 0.0, S2 = 0.0;
     int simg = q0 / ppi;
+    // gsum: this lane's column lies in part gp; aux of the part, null when the part takes no sums
+    int gnl = 0, gpc = 0;
+    const int gp = gsum_part(a, ncol, gnl, gpc);
+    const float* const gaux = GS && a.gred[gp] ? (const float*)a.gaux[gp] + gnl : nullptr;
     auto flush = [&](int img) {
         double t1 = S1 + __shfl_xor(S1, 16, 64), t2 = S2 + __shfl_xor(S2, 16, 64);
         t1 += __shfl_xor(t1, 32, 64);
         t2 += __shfl_xor(t2, 32, 64);
         if (lane < 16) {
-            double* dst = a.stats + (size_t)((WM * blockIdx.x + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
-            atomicAdd(dst, t1);
-            atomicAdd(dst + 1, t2);
+            if constexpr (GS) {
+                if (gaux) {
+                    double* dst = a.gred[gp] + ((size_t)((WM * blockIdx.x + wm) % a.gslots) * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2;
+                    atomicAdd(dst, t1);
+                    atomicAdd(dst + 1, t2);
+                }
+            } else {
+                double* dst = a.stats + (size_t)((WM * blockIdx.x + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + ncol) * 2;
+                atomicAdd(dst, t1);
+                atomicAdd(dst + 1, t2);
+            }
         }
         S1 = S2 = 0.0;
     };
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy2 = __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2bytes, 0x00020000);
+    const bool part0 = __builtin_amdgcn_readfirstlane(n0 + wn * 16) < a.n1;
 
     dma(q0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1152,9 +1426,20 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         // ---- epilogue of patch q: accumulator register r of tile m = pixel (row 4 wm + m, column 4 lq + r), channel ncol
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
-        if (a.stats && img != simg) {
+        if ((GS || a.stats) && img != simg) {
             flush(simg);
             simg = img;
+        }
+        // gsum: aux at the sixteen output positions of this lane (the same 64-byte segments as the stores below)
+        float gq[4][4];
+        if constexpr (GS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t opix = (size_t)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
+                    gq[m][r] = gaux ? gaux[opix * a.ldgaux[gp]] : 0.f;
+                }
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1164,19 +1449,23 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 const float u = acc[m][r];
                 const float v = fmaxf(u, u * a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                 s1 += v;
-                s2 += v * v;
+                if constexpr (GS) s2 += v * gq[m][r];
+                else s2 += v * v;
                 const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
-                if (ncol < a.n1)
+                // the wave's 16 channels lie in one output part (n1 % 16 == 0): a scalar branch -- a per-lane choice of the buffer
+                // descriptor makes hipcc wrap every store in a readfirstlane (waterfall) loop
+                if (part0)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(ncol - a.n1)) * 4u, 0, 0);
             }
         S1 += (double)s1;
         S2 += (double)s2;
-        // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush)
+        // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush; the gsum
+        // form's aux loads are older than the stores and have been waited for)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
-    if (a.stats) flush(simg);
+    if (GS || a.stats) flush(simg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1360,10 +1649,21 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
+// gsum request of the *_gsum entry points around their launch, and whether the kernel that ran took it (otherwise the entry
+// point follows up with the stand-alone reduce pass, shm_gsum_reduce_internal)
+struct GsumReq {
+    const void* aux[2];
+    int ld[2];
+    double* red[2];
+};
+static thread_local GsumReq g_gsum = {};
+static thread_local bool g_gsum_fused = false;
+
 // Variant choice.  `forced` (shm_set_tuning("tapgemm.variant", SHM_TG_*)) overrides the automatic choice; a forced
 // variant the shape is not eligible for is an error (SHM_E_SHAPE), so a parity test that forces a variant knows it ran.
 template <typename T, typename TO>
-static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStream_t st, const char* who) {
+static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipStream_t st, const char* who) {
+    TapGemmArgs a = a_in;
     constexpr int BKE = 64 / (int)sizeof(T);
     const char* tn = sizeof(T) == 4 ? "float" : "__bf16";
     const char* ton = sizeof(TO) == 4 ? "float" : "__bf16";
@@ -1452,6 +1752,33 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             v = SHM_TG_DMA_128x64;
         }
     }
+    // gsum (input-gradient launches): which kernels take the sums in their epilogue.  The LDS-staged bf16 epilogues read aux 16
+    // bytes at a time; the DMA tiles need whole wave tiles per sample; the weights-in-registers kernels have gsum instantiations for
+    // 64 output channels per block; the fused four-phase kernel has none.  Anything else: the entry point runs the reduce pass.
+    const bool want_gs = a.gred[0] || a.gred[1];
+    bool gs_fused = false;
+    if (want_gs) {
+        bool al = true;
+        for (int p = 0; p < 2; ++p)
+            if (a.gred[p]) al = al && (sizeof(TO) == 4 || (a.ldgaux[p] % 8 == 0 && ((size_t)a.gaux[p] & 15) == 0));
+        al = al && (a.y2 == nullptr || a.n1 % 32 == 0);
+        switch (v) {
+        case SHM_TG_HALO128: case SHM_TG_HALO64: case SHM_TG_HALO128_ST: case SHM_TG_HALO64_ST: case SHM_TG_HALO128_PH8:
+            gs_fused = al;
+            break;
+        case SHM_TG_DMA_128x128: case SHM_TG_DMA_64x128: case SHM_TG_DMA_128x64: case SHM_TG_DMA_64x64: case SHM_TG_DMA_256x64:
+        case SHM_TG_DMA_256x128: case SHM_TG_DMA_128x128_BK32: case SHM_TG_DMA_128x128_NST4:
+            gs_fused = al && (a.hg * a.wg) % 64 == 0;
+            break;
+        case SHM_TG_WREG:
+            gs_fused = al && ((wreg_ok && sizeof(TO) == 2) || (wreg32_ok && wreg32_wn == 4 && a.x2 == nullptr));
+            break;
+        default:
+            break;
+        }
+        if (!gs_fused) a.gred[0] = a.gred[1] = nullptr;
+    }
+    g_gsum_fused = gs_fused;
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     const int npatch = batch * (a.hi / 16) * (a.wi / 16);
     switch (v) {
@@ -1515,11 +1842,18 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             int gx = 2 * ncu / ny;             // two 4-wave blocks per CU (LDS, VGPRs)
             if (gx < 1) gx = 1;
             if (gx > np8) gx = np8;
-            if (a.K == 64)
+            if constexpr (sizeof(TO) == 2) {
+                if (gs_fused && a.K == 64)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                else if (gs_fused)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+            }
+            if (gs_fused) {
+            } else if (a.K == 64)
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             else
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
-            shm_set_last_kernel("tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
+            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>" : "tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
         } else if constexpr (sizeof(TO) == 4) {
             // one 8-wave block per CU; patches of 8 (64 channels per block), 16 (32) or 32 (16) rows
             const int ph = 32 / wreg32_wn, npw = batch * (a.hi / ph) * (a.wi / 16), nyw = a.nout / (16 * wreg32_wn);
@@ -1539,7 +1873,18 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, WN_, TWO_>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);                \
     } while (0)
 #define SHM_WREG32_LAUNCH(NCH_, WN_) SHM_WREG32_LAUNCH2(NCH_, WN_, false)
-            if (wreg32_wn == 4 && nch == 4) SHM_WREG32_LAUNCH(4, 4);
+#define SHM_WREG32_LAUNCH_GS(NCH_)                                                                                                       \
+    do {                                                                                                                                 \
+        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, true>,                    \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * 12 * 1024);             \
+        attr = at_;                                                                                                                      \
+        if (attr == hipSuccess)                                                                                                          \
+            hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);           \
+    } while (0)
+            if (gs_fused && nch == 4) SHM_WREG32_LAUNCH_GS(4);
+            else if (gs_fused && nch == 2) SHM_WREG32_LAUNCH_GS(2);
+            else if (gs_fused) SHM_WREG32_LAUNCH_GS(1);
+            else if (wreg32_wn == 4 && nch == 4) SHM_WREG32_LAUNCH(4, 4);
             else if (wreg32_wn == 4 && nch == 2) SHM_WREG32_LAUNCH(2, 4);
             else if (wreg32_wn == 4) SHM_WREG32_LAUNCH(1, 4);
             else if (wreg32_wn == 2 && nch == 2) SHM_WREG32_LAUNCH(2, 2);
@@ -1549,8 +1894,10 @@ static int launch_tapgemm_t(const TapGemmArgs& a, int batch, int nphase, hipStre
             else SHM_WREG32_LAUNCH(1, 1);
 #undef SHM_WREG32_LAUNCH2
 #undef SHM_WREG32_LAUNCH
+#undef SHM_WREG32_LAUNCH_GS
             SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, lds, hipGetErrorString(attr));
-            shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn, a.x2 ? "true" : "false");
+            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_f32_kernel<%d, %d, %s, true>" : "tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn,
+                                a.x2 ? "true" : "false");
         }
         break;
     }
@@ -1600,6 +1947,18 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
     a.hw = g_conv_hw;
     a.stats_slots = g_conv_slots;
     a.stats_stride = (unsigned)batch * (unsigned)a.nout * 2u;
+    for (int p = 0; p < 2; ++p) {
+        a.gaux[p] = g_gsum.aux[p];
+        a.ldgaux[p] = g_gsum.ld[p];
+        a.gred[p] = g_gsum.red[p];
+    }
+    a.gslots = SHM_GSUM_SLOTS;
+    a.gbatch = batch;
+    g_gsum_fused = false;
+    if (a.gred[0] || a.gred[1]) {
+        SHM_REQUIRE(a.stats == nullptr, SHM_E_SHAPE, "%s: fused forward statistics and gsum are exclusive", who);
+        a.hw = a.hg * a.wg;           // pixels per sample in the M index space of one phase
+    }
     SHM_REQUIRE(dtype != SHM_BF16_GF32 || a.stats == nullptr, SHM_E_DTYPE, "%s: SHM_BF16_GF32 has no fused statistics", who);
     const int esz = dtype == SHM_F32 ? 4 : 2, bke = 64 / esz, che = 16 / esz;
     SHM_REQUIRE(a.K % bke == 0 && a.K > 0, SHM_E_SHAPE, "%s: contraction channels %d must be a multiple of %d", who, a.K, bke);
@@ -1966,4 +2325,53 @@ extern "C" int shm_conv2d_transpose2x2_fwd(const void* x, int ldx, const void* w
         P.widx[0] = p;
     }
     return launch_tapgemm(a, batch, 4, dtype, (hipStream_t)stream, "shm_conv2d_transpose2x2_fwd");
+}
+
+// ------------------------------------------------------------------------------------
+// gsum entry points: an input-gradient product that also delivers, per (sample, channel) of its output, sum(g) and sum(g * aux)
+// -- the two sums the InstanceNorm backward of the block whose OUTPUT gradient it writes would otherwise collect in a pass of its
+// own over g and the stored activation (shm_in_bwd's reduce pass).  red = f64 [SHM_GSUM_SLOTS][batch][channels][2], zero on entry
+// (slot copies cut the per-address atomic chains; shm_in_bwd_apply sums and clears them).  Kernels that cannot take the sums in
+// their epilogue (launch_tapgemm_t lists which can) are followed by the stand-alone reduce pass: callers always get the sums.
+int shm_gsum_reduce_internal(const void* g, int ldg, const void* aux, int ldaux, double* red, int batch, int hw, int c, int dtype, hipStream_t st);
+
+extern "C" int shm_conv2d_dgrad_gsum(const void* dy, int lddy, const void* w, void* dx, void* dx2, int n1, int lddx, int lddx2, int batch, int hi,
+                                     int wi, int cin, int cout, int ksize, int stride, const void* aux, int ldaux, double* red, const void* aux2,
+                                     int ldaux2, double* red2, int dtype, void* stream) {
+    const char* who = "shm_conv2d_dgrad_gsum";
+    SHM_REQUIRE((aux != nullptr) == (red != nullptr) && (aux2 != nullptr) == (red2 != nullptr), SHM_E_SHAPE, "%s: aux and red come in pairs", who);
+    SHM_REQUIRE(red || red2, SHM_E_SHAPE, "%s: no sums requested (use shm_conv2d_dgrad)", who);
+    SHM_REQUIRE(!red2 || dx2, SHM_E_SHAPE, "%s: sums of the second part need dx2", who);
+    g_gsum = GsumReq{{aux, aux2}, {ldaux, ldaux2}, {red, red2}};
+    int r = shm_conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride, dtype, stream);
+    const bool fused = g_gsum_fused;
+    g_gsum = GsumReq{};
+    g_gsum_fused = false;
+    if (r == SHM_OK && !fused) {
+        const int c0 = dx2 ? n1 : cin;
+        if (red) r = shm_gsum_reduce_internal(dx, lddx, aux, ldaux, red, batch, hi * wi, c0, dtype, (hipStream_t)stream);
+        if (r == SHM_OK && red2) r = shm_gsum_reduce_internal(dx2, lddx2, aux2, ldaux2, red2, batch, hi * wi, cin - n1, dtype, (hipStream_t)stream);
+    }
+    return r;
+}
+
+// The stride-2 forward form is the input gradient of Conv2DTranspose (model.py runs it with slope 1 and no bias); any forward
+// product may ask for the sums of its output.
+extern "C" int shm_conv2d_fwd_gsum(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk, const float* bias, void* y, int ldy,
+                                   int batch, int hi, int wi, int cin, int cout, int ksize, int stride, float slope, const void* aux, int ldaux,
+                                   double* red, int dtype, void* stream) {
+    const char* who = "shm_conv2d_fwd_gsum";
+    SHM_REQUIRE(aux && red, SHM_E_SHAPE, "%s: null aux / red", who);
+    g_gsum = GsumReq{{aux, nullptr}, {ldaux, 0}, {red, nullptr}};
+    int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
+    const bool fused = g_gsum_fused;
+    g_gsum = GsumReq{};
+    g_gsum_fused = false;
+    if (r == SHM_OK && !fused) {
+        int ho, wo, pt;
+        shm_same_pad(hi, ksize, stride, &ho, &pt);
+        shm_same_pad(wi, ksize, stride, &wo, &pt);
+        r = shm_gsum_reduce_internal(y, ldy, aux, ldaux, red, batch, ho * wo, cout, dtype, (hipStream_t)stream);
+    }
+    return r;
 }

@@ -420,6 +420,14 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     int rev;
     const float* r1_dz;          // rank-1 gradient (R1 kernels): d_out[n, p, ch] = r1_dz[n * hw + p] * r1_w[ch] -- the generator head's
     const float* r1_w;           // input gradient, formed on the fly instead of being written by the head and read twice here
+    // RAW apply kernels (shm_in_bwd_apply): the sums come from the epilogues of the launches that wrote g1 / g2 (gsum), as slot
+    // copies [gslots][batch][c][2]: gred = (sum g1, sum g1 * a), gredp = (sum g2, sum g2 * pooled) or null; dstage = f64 [batch][c]
+    // staging of the bias gradient
+    const double* gred;
+    const double* gredp;
+    const float* beta;
+    double* dstage;
+    int gslots;
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -611,7 +619,10 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
     }
 }
 
-template <typename T, typename TG, bool G2, bool R1 = false>
+// RAW: the two means come from gsum slot sums (InBwdArgs::gred / gredp) instead of the reduce pass's `red`:
+//   sum g     = sum g1 + sum g2                      (g2 is the gradient of the 2x2 average pool: each value reaches 4 pixels x 1/4)
+//   sum g*xh  = inv * (sum g1*a - mean * sum g1)  +  (sum g2*pooled - beta * sum g2)      (pooled = avgpool(xh) + beta)
+template <typename T, typename TG, bool G2, bool R1 = false, bool RAW = false>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     PixMap pm(k.c);
     f32x4 wr = {0.f, 0.f, 0.f, 0.f};
@@ -628,8 +639,26 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             size_t i = ((size_t)n * k.c + pm.cl * 4 + e) * 2;
             mean[e] = (float)k.stats[i];
             inv[e] = (float)k.stats[i + 1];
-            m1[e] = (float)(k.red[i] / hw);
-            m2[e] = (float)(k.red[i + 1] / hw);
+            if constexpr (RAW) {
+                const size_t sstride = (size_t)gridDim.y * k.c * 2;
+                double sg = 0.0, sga = 0.0, pg = 0.0, pgx = 0.0;
+                for (int sl = 0; sl < k.gslots; ++sl) {
+                    sg += k.gred[sl * sstride + i];
+                    sga += k.gred[sl * sstride + i + 1];
+                }
+                if (k.gredp) {
+                    for (int sl = 0; sl < k.gslots; ++sl) {
+                        pg += k.gredp[sl * sstride + i];
+                        pgx += k.gredp[sl * sstride + i + 1];
+                    }
+                }
+                const double bt = k.gredp ? (double)k.beta[pm.cl * 4 + e] : 0.0;
+                m1[e] = (float)((sg + pg) / hw);
+                m2[e] = (float)((k.stats[i + 1] * (sga - k.stats[i] * sg) + (pgx - bt * pg)) / hw);
+            } else {
+                m1[e] = (float)(k.red[i] / hw);
+                m2[e] = (float)(k.red[i + 1] / hw);
+            }
         }
         constexpr int U = sizeof(T) == 2 ? 8 : 4;
         int p = p0 + pm.pp;
@@ -672,7 +701,85 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     }
     // bias gradient: staged per sample in red[2*batch*c + n*c + ch] -- one f64 atomic address per (n, ch)
     // instead of per ch (4096 blocks on 64 addresses cost 90-210 us per launch), folded by dbias_fold_kernel
-    if (k.dbias) block_reduce_atomic<1>(v, pm, k.red + (size_t)gridDim.y * k.c * 2 + (size_t)n * k.c, k.c, true);
+    if (k.dbias) block_reduce_atomic<1>(v, pm, (RAW ? k.dstage : k.red + (size_t)gridDim.y * k.c * 2) + (size_t)n * k.c, k.c, true);
+}
+
+// shm_in_bwd_apply's last launch: fold the staged bias gradient (dbias[ch] += sum over samples) and clear the gsum slot copies the
+// apply pass consumed -- "zero on entry, zero on return" for every f64 scratch, no memset in front of a launch.
+__global__ __launch_bounds__(256) void gsum_finish_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c, double* __restrict__ clr1,
+                                                          size_t n1, double* __restrict__ clr2, size_t n2) {
+    __shared__ double red[4][64];
+    if (dbias && blockIdx.x * 64 < (unsigned)c) {
+        const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int ch = blockIdx.x * 64 + cl;
+        double s = 0.0;
+        if (ch < c)
+            for (int i = g; i < nslot; i += 4) {
+                s += part[(size_t)i * c + ch];
+                part[(size_t)i * c + ch] = 0.0;
+            }
+        red[g][cl] = s;
+        __syncthreads();
+        if (g == 0 && ch < c) dbias[ch] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) clr1[i] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) clr2[i] = 0.0;
+}
+
+// Stand-alone gsum: (sum g, sum g * aux) per (sample, channel) into slot 0 of red -- what the convolution epilogues produce for
+// the launches they can take it in (conv_igemm.hip); the *_gsum entry points fall back to this pass otherwise.
+template <typename TG, typename T>
+__global__ __launch_bounds__(256) void gsum_reduce_kernel(const TG* __restrict__ g, int ldg, const T* __restrict__ aux, int ldaux, double* __restrict__ red,
+                                                          int hw, int c, int chunk) {
+    PixMap pm(c);
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * chunk, p1 = min(hw, p0 + chunk);
+    double v[2][4] = {};
+    if (pm.active) {
+        constexpr int U = 4;
+        int p = p0 + pm.pp;
+        for (; p + (U - 1) * pm.PP < p1; p += U * pm.PP) {
+            f32x4 gv[U], x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                gv[u] = ld4(g + ((size_t)n * hw + p + u * pm.PP) * ldg + pm.cl * 4);
+                x[u] = ld4(aux + ((size_t)n * hw + p + u * pm.PP) * ldaux + pm.cl * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sg = 0.f, sx = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    sg += gv[u][e];
+                    sx += gv[u][e] * x[u][e];
+                }
+                v[0][e] += (double)sg;
+                v[1][e] += (double)sx;
+            }
+        }
+        for (; p < p1; p += pm.PP) {
+            const f32x4 gv = ld4(g + ((size_t)n * hw + p) * ldg + pm.cl * 4);
+            const f32x4 x = ld4(aux + ((size_t)n * hw + p) * ldaux + pm.cl * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[0][e] += (double)gv[e];
+                v[1][e] += (double)gv[e] * (double)x[e];
+            }
+        }
+    }
+    block_reduce_atomic<2>(v, pm, red + (size_t)n * c * 2, c, true);
+}
+
+int shm_gsum_reduce_internal(const void* g, int ldg, const void* aux, int ldaux, double* red, int batch, int hw, int c, int dtype, hipStream_t st) {
+    SHM_CHECK_C(c, "gsum reduce");
+    SHM_REQUIRE(ldg % 4 == 0 && ldaux % 4 == 0, SHM_E_SHAPE, "gsum reduce: bad pitch");
+    if (batch == 0 || hw == 0) return SHM_OK;
+    const int chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, 1024));
+    const dim3 grid(shm_cdiv(hw, chunk), batch);
+    SHM_DISPATCH_G(dtype, "gsum reduce", hipLaunchKernelGGL((gsum_reduce_kernel<TG, T>), grid, dim3(256), 0, st, (const TG*)g, ldg, (const T*)aux, ldaux, red, hw, c, chunk));
+    SHM_LAUNCH_CHECK("gsum reduce");
+    return SHM_OK;
 }
 
 // dbias[ch] += sum over slots of part[slot*c + ch]
@@ -767,6 +874,49 @@ extern "C" int shm_in_bwd(const void* g1, int ldg1, const void* g2, int ldg2, co
                           int h, int w, int c, float slope, int dtype, void* stream) {
     SHM_REQUIRE(g1, SHM_E_SHAPE, "shm_in_bwd: null gradient");
     return in_bwd_impl("shm_in_bwd", g1, ldg1, g2, ldg2, nullptr, nullptr, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, dtype, stream);
+}
+
+// InstanceNorm + LeakyReLU backward WITHOUT its reduce pass: the per-(sample, channel) sums were formed in the epilogues of the
+// launches that wrote g1 / g2 (shm_conv2d_dgrad_gsum, shm_conv2d_fwd_gsum), so this is one pass over the tensors -- read g1 [+ g2],
+// read a, write dz -- where shm_in_bwd makes two.
+extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ldg2, const void* a, int lda, const double* stats, const float* beta,
+                                double* red, double* redp, double* dstage, void* dz, int lddz, double* dbias, int batch, int h, int w, int c,
+                                float slope, int dtype, void* stream) {
+    const char* who = "shm_in_bwd_apply";
+    SHM_REQUIRE(g1 && a && stats && red && dz, SHM_E_SHAPE, "%s: null pointer", who);
+    SHM_REQUIRE((g2 != nullptr) == (redp != nullptr), SHM_E_SHAPE, "%s: the pooled gradient g2 and its sums redp come together", who);
+    SHM_REQUIRE(!redp || beta, SHM_E_SHAPE, "%s: the pooled form needs beta", who);
+    SHM_REQUIRE(!dbias || dstage, SHM_E_SHAPE, "%s: the bias gradient needs its staging scratch", who);
+    SHM_CHECK_C(c, who);
+    SHM_REQUIRE(ldg1 % 4 == 0 && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "%s: bad pitch", who);
+    SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "%s: pooled gradient needs even h,w", who);
+    if (batch == 0 || h * w == 0) return SHM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    InBwdArgs k{g1, g2, a, stats, nullptr, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, 0, nullptr, nullptr, red, redp, beta, dstage, SHM_GSUM_SLOTS};
+    const int hw = h * w;
+    k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c));
+    const dim3 grid(shm_cdiv(hw, k.chunk), batch);
+    if (g2)
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true, false, true>), grid, dim3(256), 0, st, k));
+    else
+        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false, false, true>), grid, dim3(256), 0, st, k));
+    const size_t nred = (size_t)SHM_GSUM_SLOTS * batch * c * 2;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+        const size_t nclr = (nred * (redp ? 2 : 1) + 2047) / 2048;
+        int nb = nclr < 64 ? (int)nclr : 64;
+        if (nb < shm_cdiv(c, 64)) nb = shm_cdiv(c, 64);
+        hipLaunchKernelGGL(gsum_finish_kernel, dim3(nb), dim3(256), 0, st, dstage, dbias, batch, c, red, nred, redp, redp ? nred : (size_t)0);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {           // zero on return also on the error path
+        (void)hipMemsetAsync(red, 0, nred * sizeof(double), st);
+        if (redp) (void)hipMemsetAsync(redp, 0, nred * sizeof(double), st);
+        if (dstage) (void)hipMemsetAsync(dstage, 0, (size_t)batch * c * sizeof(double), st);
+        shm_set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+        return SHM_E_HIP;
+    }
+    return SHM_OK;
 }
 
 // The same backward for the block in front of the generator head, whose output gradient is the rank-1 tensor

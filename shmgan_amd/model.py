@@ -390,7 +390,7 @@ class Generator(_ModelBase):
         scr = A.get(f"stats_scratch/{n * cout}", (ops.STATS_SLOTS * n * cout * 2,), torch.float64)
         ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
                           k, 1, LRELU, stats, IN_EPS, cin_real=cin, scratch=scr)
-        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi)
+        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout)
         if not apply:
             return a, rec
         if pooled is not None:
@@ -417,6 +417,7 @@ class Generator(_ModelBase):
                 if j == 1:            # the level's second block: its normalisation pass also writes the pooled tensor
                     pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, self.layers[li][4]), self.adt)
                 cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, pooled=pooled)
+                r["pooled"] = pooled
                 recs.append(r)
                 ld = self.layers[li][4]
                 li += 1
@@ -460,19 +461,36 @@ class Generator(_ModelBase):
         return y
 
     # -- backward -------------------------------------------------------------------------
-    def _cnl_bwd(self, tag, rec, g1, g2, n, need_dx, dx=None, dx2=None, n1=0, rank1=None):
+    def _gsum(self, rec, pooled=False):
+        """(aux, ldaux, red) for the launch that writes the gradient at `rec`'s InstanceNorm output (its epilogue then delivers the
+        sums of that block's InstanceNorm backward, ops.conv2d_dgrad(gsum=)).  pooled: the launch writes the gradient of the
+        AveragePooling2D output instead; its sums go against the pooled normalised tensor (the next level's input)."""
+        n, c = rec["n"], rec["cout"]
+        key = "gredp" if pooled else "gred"
+        red = self.arena.get(f"bwd/{key}/L{rec['li']}/{n}", (ops.GSUM_SLOTS * n * c * 2,), torch.float64)
+        rec[key] = red
+        return (rec["pooled"] if pooled else rec["a"]), c, red
+
+    def _cnl_bwd(self, tag, rec, g1, g2, n, need_dx, dx=None, dx2=None, n1=0, rank1=None, gsum=None, gsum2=None):
         """Backward of one Conv->LReLU->IN block.  g1: gradient at the IN output (same res),
         g2: optional gradient of the 2x2 average pool that consumed the IN output.
         rank1 = (hdz, w): g1 is the rank-1 tensor hdz (x) w of the head (formed on the fly, g1 = None).
+        gsum / gsum2: _gsum() of the block(s) whose output gradient dx / dx2 is.  If the launches that wrote g1 (and g2) were given
+        this block's _gsum(), the InstanceNorm backward is the single apply pass (ops.in_bwd_apply), otherwise reduce + apply.
         Accumulates dW / dbias; returns nothing (dx/dx2 are written if need_dx)."""
         li, h, w = rec["li"], rec["h"], rec["w"]
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
         dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
-        red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
         if rank1 is not None:
+            red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
             ops.in_bwd_rank1(rank1[0], rank1[1], rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
+        elif rec.get("gred") is not None and (g2 is None) == (rec.get("gredp") is None):
+            dstage = A.get(f"bwd/dstage/{n * cout}", (n * cout,), torch.float64)
+            ops.in_bwd_apply(g1, cout, g2, cout, rec["a"], cout, rec["stats"], self.betas[rec["bi"]], rec.pop("gred"), rec.pop("gredp", None),
+                             dstage, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
         else:
+            red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
             ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
                        h, w, cout, LRELU)
         if self.debug is not None:           # test diagnostics: keep the per-layer gradients
@@ -487,7 +505,8 @@ class Generator(_ModelBase):
             self._on_wgrad(li)
         if need_dx:
             lddx = rec["ldx"]
-            ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1)
+            ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1,
+                             gsum=gsum, gsum2=gsum2)
         return dz
 
     def backward(self, dy, tag, need_dx=False, on_wgrad=None):
@@ -529,13 +548,15 @@ class Generator(_ModelBase):
             cout = self.layers[r2["li"]][4]
             dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout), self.gdt)
             self._cnl_bwd(tag, r2, dcur, None, n, True, dmid, None, cout,
-                          rank1=(hdz, self.P.vars[2 * (nl - 1)].reshape(-1)) if lvl == 3 else None)
-            # concat block: split gradient into (du, dskip)
+                          rank1=(hdz, self.P.vars[2 * (nl - 1)].reshape(-1)) if lvl == 3 else None, gsum=self._gsum(r1))
+            # concat block: split gradient into (du, dskip); dskip is the gradient at the encoder block's InstanceNorm output
+            # (live attention adds its map to the skip: the same gradient)
             cu = r1["c1"]
             cs = self.layers[r1["li"]][3] - cu
             du = A.get(f"bwd/du/{n}x{h}x{cu}", (n, h, h, cu), self.gdt)
             dsk = A.get(f"bwd/dskip{3 - lvl}/{n}x{h}x{cs}", (n, h, h, cs), self.gdt)
-            self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu)
+            enc2 = recs[2 * (3 - lvl) + 1]                           # second block of encoder level 3 - lvl
+            self._cnl_bwd(tag, r1, dmid, None, n, True, du, dsk, cu, gsum2=self._gsum(enc2))
             dskips[3 - lvl] = dsk
             if c["attn"]:                       # d attn_k = sum of the skip gradient over every copy of the sample
                 B = self._attn_B                # (state reset by zero_grad() at the start of every step)
@@ -555,15 +576,18 @@ class Generator(_ModelBase):
                 self._on_wgrad(tli)
             hin = up["h"]
             dcur = A.get(f"bwd/d/{n}x{hin}x{tcin}", (n, hin, hin, tcin), self.gdt)
-            ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0)
+            # input gradient of the Conv2DTranspose = the stride-2 forward form; it writes the gradient at the InstanceNorm output
+            # of the block below (recs[ri] after the two decrements above: the previous level's second block, or the bottleneck's)
+            ops.conv2d_fwd(dzu, None, 0, tcout, 0, self.wk[tli], None, dcur, tcin, n, h, h, tcout, tcin, 3, 2, 1.0, gsum=self._gsum(recs[ri]))
         # bottleneck 1x1 blocks
-        for _ in range(2):
+        for j in range(2):
             r = recs[ri]
             ri -= 1
             h = r["h"]
             cin = self.layers[r["li"]][3]
             dn = A.get(f"bwd/db{ri}/{n}x{h}x{cin}", (n, h, h, cin), self.gdt)
-            self._cnl_bwd(tag, r, dcur, None, n, True, dn, None, cin)
+            # the first 1x1 block's input gradient is the gradient of pool 4: sums against the pooled tensor of encoder level 3
+            self._cnl_bwd(tag, r, dcur, None, n, True, dn, None, cin, gsum=self._gsum(recs[ri]) if j == 0 else self._gsum(recs[ri], pooled=True))
             dcur = dn
         dpool = dcur                                   # gradient wrt pool4 output
         for lvl in range(3, -1, -1):
@@ -572,11 +596,11 @@ class Generator(_ModelBase):
             h = r2["h"]
             cout = self.layers[r2["li"]][4]
             dmid = A.get(f"bwd/dm/{n}x{h}x{cout}", (n, h, h, cout), self.gdt)
-            self._cnl_bwd(tag, r2, dskips[lvl], dpool, n, True, dmid, None, cout)
+            self._cnl_bwd(tag, r2, dskips[lvl], dpool, n, True, dmid, None, cout, gsum=self._gsum(r1))
             cin = self.layers[r1["li"]][3]
             if lvl > 0:
                 dpool = A.get(f"bwd/dp/{n}x{h}x{cin}", (n, h, h, cin), self.gdt)
-                self._cnl_bwd(tag, r1, dmid, None, n, True, dpool, None, cin)
+                self._cnl_bwd(tag, r1, dmid, None, n, True, dpool, None, cin, gsum=self._gsum(recs[ri], pooled=True))
             else:
                 if need_dx is True:
                     dx16 = A.get(f"bwd/dx16/{n}", (n, h, h, self.pad), self.gdt)
@@ -790,14 +814,20 @@ class Discriminator(_ModelBase):
             if r0 + nr <= n:
                 ops.mul_mask(dx5[r0:r0 + nr], c["keep_mask"][m0:m0 + nr], dx5[r0:r0 + nr], nr * per, scale)
         dcur = dx5
+        gred = None
         for i in range(4, -1, -1):
             rec = c["recs"][i]
             cin, cout = self.chan[i], self.chan[i + 1]
             h = rec["h"]
             ho = h // 2
             dz = A.get(f"d/bwd/dz{i}/{n}", (n, ho, ho, cout), self.adt)
-            red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 3,), torch.float64)
-            ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
+            if gred is not None:           # the stride-2 input gradient below delivered this block's sums: one pass instead of two
+                ops.in_bwd_apply(dcur, cout, None, 0, rec["a"][:n], cout, rec["stats"], self.betas[i], gred, None, None, dz, cout, None, n, ho, ho,
+                                 cout, LRELU)
+            else:
+                red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 3,), torch.float64)
+                ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
+            gred = None
             if params:
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))
                 self.lane.submit(lambda rec=rec, dz=dz, i=i, h=h, cin=cin, cout=cout, ws=ws: ops.conv2d_wgrad(
@@ -807,7 +837,11 @@ class Discriminator(_ModelBase):
             if i > 0 or need_dx:
                 ldx = rec["ldx"]
                 dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
-                ops.conv2d_dgrad(dz, cout, self.P.op_vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2)
+                gs = None
+                if i > 0:                  # dprev is the gradient at block i-1's InstanceNorm output: its sums come with it
+                    gred = A.get(f"d/bwd/gred{i - 1}/{n}", (ops.GSUM_SLOTS * n * cin * 2,), torch.float64)
+                    gs = (c["recs"][i - 1]["a"], cin, gred)
+                ops.conv2d_dgrad(dz, cout, self.P.op_vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2, gsum=gs)
                 dcur = dprev
                 if i == 4 and params and c["attn"]:          # d attn_disc = sum over the copies of each sample; then its branch
                     B = self._attn_B

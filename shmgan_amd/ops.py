@@ -146,14 +146,21 @@ def transpose_taps(w, wt, ntaps, rows, cols, rows_pad):
 
 
 def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope,
-               cin_real=None):
-    """cin_real: un-padded input channels, only used for the algorithmic flop count."""
+               cin_real=None, gsum=None):
+    """cin_real: un-padded input channels, only used for the algorithmic flop count.
+    gsum = (aux, ldaux, red): shm_conv2d_fwd_gsum (the stride-2 forward form is Conv2DTranspose's input gradient)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
+    label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
+    if gsum is None:
+        _timed("", flops, lambda: check(
+            lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                                 cin, cout, ksize, stride, slope, _dtg(x, y), _stream()), "shm_conv2d_fwd"), label)
+        return
+    aux, ldaux, red = gsum
     _timed("", flops, lambda: check(
-        lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                             cin, cout, ksize, stride, slope, _dtg(x, y), _stream()), "shm_conv2d_fwd"),
-           f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
+        lib().shm_conv2d_fwd_gsum(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi, cin, cout, ksize, stride,
+                                  slope, _p(aux), ldaux, _p(red), _dtg(x, y), _stream()), "shm_conv2d_fwd_gsum"), label + " +gsum")
 
 
 STATS_SLOTS = 16            # SHM_STATS_SLOTS
@@ -172,13 +179,26 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
            f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
 
 
-def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride):
+GSUM_SLOTS = 8              # SHM_GSUM_SLOTS
+
+
+def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride, gsum=None, gsum2=None):
+    """gsum / gsum2 = (aux, ldaux, red) for the dx / dx2 part: the epilogue also delivers the InstanceNorm-backward sums of the
+    block whose output gradient that part is (shm_conv2d_dgrad_gsum; red = f64 [GSUM_SLOTS * batch * channels * 2], zero on entry)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
+    label = f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}"
+    if gsum is None and gsum2 is None:
+        _timed("", flops, lambda: check(
+            lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
+                                   cout, ksize, stride, _dtg(dy, dx), _stream()), "shm_conv2d_dgrad"), label)
+        return
+    a1, l1, r1 = gsum or (None, 0, None)
+    a2, l2, r2 = gsum2 or (None, 0, None)
     _timed("", flops, lambda: check(
-        lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,
-                               cout, ksize, stride, _dtg(dy, dx), _stream()), "shm_conv2d_dgrad"),
-           f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}")
+        lib().shm_conv2d_dgrad_gsum(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride,
+                                    _p(a1), l1, _p(r1), _p(a2), l2, _p(r2), _dtg(dy, dx), _stream()), "shm_conv2d_dgrad_gsum"),
+           label + " +gsum")
 
 
 def conv2d_transpose_fwd(x, ldx, w, bias, y, ldy, batch, hi, wi, cin, cout, slope):
@@ -233,6 +253,12 @@ def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
     check(lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
                            batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd")
+
+
+def in_bwd_apply(g1, ldg1, g2, ldg2, a, lda, stats, beta, red, redp, dstage, dz, lddz, dbias, batch, h, w, c, slope):
+    """shm_in_bwd without its reduce pass: the sums come from the gsum epilogues of the launches that wrote g1 / g2."""
+    check(lib().shm_in_bwd_apply(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(beta), _p(red), _p(redp), _p(dstage), _p(dz), lddz,
+                                 _p(dbias), batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd_apply")
 
 
 LRELU_RED_SLOTS = 64        # SHM_LRELU_RED_SLOTS

@@ -74,5 +74,9 @@ def test_two_ranks_on_one_gpu_equal_one_batch_of_two():
         assert rel_l2(gG / 2, refs[0]) < 1e-3 and cosine(gG / 2, refs[0]) > 0.99999, rel_l2(gG / 2, refs[0])
         assert rel_l2(gD / 2, refs[1]) < 1e-3 and cosine(gD / 2, refs[1]) > 0.99999, rel_l2(gD / 2, refs[1])
         # ... and clip + Adam with gscale = 1/world leaves the same weights on every rank
-        assert np.abs(wG - refs[2]).max() < 2e-5 and np.abs(wD - refs[3]).max() < 2e-5
+        # (first Adam step = lr * g / (|g| + 1e-6) with lr = 2e-5: a gradient element of ~1e-6 whose 1e-3-relative error flips
+        # its sign moves its weight by up to 2 lr; everywhere else the replicas' weights match the single-process ones)
+        for w, r in ((wG, refs[2]), (wD, refs[3])):
+            e = np.abs(w - r)
+            assert e.max() <= 2.02 * 2e-5 and (e > 2e-6).mean() < 1e-2, (e.max(), (e > 2e-6).mean())
     assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])     # replicas stay identical

@@ -214,13 +214,26 @@ def test_train_step_parity(S, F, B, step):
     dvv = [t64(a).clone() for a in d]
     sg = st.AdamState([torch.zeros_like(a) for a in gv], [torch.zeros_like(a) for a in gv])
     sd = st.AdamState([torch.zeros_like(a) for a in dvv], [torch.zeros_like(a) for a in dvv])
-    st.adam_apply(dvv, ref["gD"], sd, 2e-5, 0.5, 0.99)
-    st.adam_apply(gv, ref["gG"], sg, 2e-5, 0.5, 0.99)
+    # (a) the kernel: the oracle's clip+Adam applied to the DEVICE's gradients reproduces the device's weights to fp32 rounding
+    dev_gd = [t64(host(t)) for t in m.D.P.grads]
+    dev_gg = [t64(host(t)) for t in m.G.P.grads]
+    st.adam_apply(dvv, dev_gd, sd, 2e-5, 0.5, 0.99)
+    st.adam_apply(gv, dev_gg, sg, 2e-5, 0.5, 0.99)
+    # (b) end to end: the oracle's clip+Adam on the ORACLE's gradients.  The first Adam step is lr * g / (|g| + 1e-6): where a
+    # gradient element is itself ~1e-6 the 1e-3 relative gradient error can flip its sign, so single weights may differ by
+    # up to 2 lr; all but a vanishing fraction must agree to a tenth of a step
+    gv2, dvv2 = [t64(a).clone() for a in g], [t64(a).clone() for a in d]
+    sg2 = st.AdamState([torch.zeros_like(a) for a in gv2], [torch.zeros_like(a) for a in gv2])
+    sd2 = st.AdamState([torch.zeros_like(a) for a in dvv2], [torch.zeros_like(a) for a in dvv2])
+    st.adam_apply(dvv2, ref["gD"], sd2, 2e-5, 0.5, 0.99)
+    st.adam_apply(gv2, ref["gG"], sg2, 2e-5, 0.5, 0.99)
     m.optimizer_D.apply(m.D.P)
     m.optimizer_G.apply(m.G.P)
     torch.cuda.synchronize()
-    for got_w, r in zip(m.G.P.vars + m.D.P.vars, gv + dvv):
-        assert np.abs(host(got_w) - r.numpy()).max() < 2e-5     # one Adam step moves a weight by <= lr*~1
+    for got_w, r, r2 in zip(m.G.P.vars + m.D.P.vars, gv + dvv, gv2 + dvv2):
+        assert np.abs(host(got_w) - r.numpy()).max() < 1e-8 + 2e-7 * float(r.abs().max())
+        e = np.abs(host(got_w) - r2.numpy())
+        assert e.max() <= 2.02 * 2e-5 and (e > 2e-6).mean() < 1e-2, (e.max(), (e > 2e-6).mean())
 
 
 def test_train_step_properties_full_size():
