@@ -357,6 +357,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    // the bias of the lane's columns, once: read inside the store loops it is re-fetched per element (the stores may alias it for
+    // all hipcc knows) and every fetch waits with vmcnt(0), i.e. for the stores of the element before as well -- the epilogue
+    // became a chain of store round trips
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+        bj[j] = (a.bias && n < a.nout) ? a.bias[n] : 0.f;
+        // consume the value here, in straight-line code: first used inside the exec-masked element blocks below, hipcc's waitcnt
+        // pass keeps the load "pending" along the skipped paths and puts s_waitcnt vmcnt(0) -- a drain of the stores -- in
+        // front of every element
+        asm volatile("" : "+v"(bj[j]));
+    }
     // bf16 outputs (round 2): as in the halo kernels the wave's tile goes through LDS (free once every wave is past its last
     // fragment read) and leaves as 16-byte stores -- the accumulator layout gives a lane one 2-byte element per row, i.e.
     // TM*TN*16 two-byte store instructions per wave.  Works for the strided (four-phase) outputs too: a pixel's channels are
@@ -378,8 +391,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * WTN + j * 32 + l31;
-                    float v = acc[i][j][r];
-                    if (a.bias && n < a.nout) v += a.bias[n];
+                    float v = acc[i][j][r] + bj[j];
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (mv && n < a.nout) ? (float)vo : 0.f;          // statistics of the value as stored
                     s1[j] += v;
@@ -427,20 +439,71 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             gsum_wide_flush<CW>(t1, t2, lane, dst);
         }
     }
-    // narrow path, gsum: per column group the aux tensor of the lane's column (null: no sums for that part)
-    bool gsn[TN];
-    const T* gauxn[TN];
-    int gldn[TN];
+    // narrow path, gsum.  The 32 columns of a (wave, j) group lie in one output part (n1 % 32 == 0, checked by the launcher), so
+    // "this group takes sums", its aux tensor and pitch are scalars: the sixteen aux loads of a 32 x 32 tile are issued back to
+    // back in front of the tile's stores (a per-element conditional load made hipcc wait for every load AND the store before it).
+    const bool gs_any = a.gred[0] != nullptr || a.gred[1] != nullptr;
+    auto out_pix = [&](int m) -> size_t {
+        if (direct) return (size_t)m;
+        const int ow = m % a.wg, t = m / a.wg;
+        const int oh = t % a.hg, n = t / a.hg;
+        return ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
+    };
+    if (!wide && gs_any) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + l31;
-        int nl, pc;
-        const int gp = gsum_part(a, n, nl, pc);
-        gsn[j] = a.gred[gp] != nullptr && n < a.nout;
-        gauxn[j] = (const T*)a.gaux[gp] + nl;
-        gldn[j] = a.ldgaux[gp];
+        for (int j = 0; j < TN; ++j) {
+            const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * WTN + j * 32);
+            const int gp = nb < a.n1 ? 0 : 1;
+            const bool on = a.gred[gp] != nullptr && nb < a.nout;
+            const int n = nb + l31;
+            const int nl = n - (gp ? a.n1 : 0);
+            const int pc = gp ? a.nout - a.n1 : a.n1;
+            const T* gaux = (const T*)a.gaux[gp] + (n < a.nout ? nl : 0);
+            const size_t ldg = (size_t)a.ldgaux[gp];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float q[16];
+                if (on) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        q[r] = m < a.M ? (float)gaux[out_pix(m) * ldg] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) q[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m >= a.M || n >= a.nout) continue;
+                    const size_t opix = out_pix(m);
+                    float v = acc[i][j][r] + bj[j];
+                    const TO vo = (TO)shm_lrelu(v, a.slope);
+                    v = (float)vo;
+                    s1[j] += v;
+                    s2[j] += v * q[r];
+                    if (n < a.n1)
+                        ((TO*)a.y)[opix * a.ldy + n] = vo;
+                    else
+                        ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
+                }
+            }
+            const int mw = m0 + wm * WTM;
+            if (on && mw < a.M) {
+                const int img = mw / a.hw;
+                const int slot = ((mw - img * a.hw) / WTM) % a.gslots;
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (h == 0 && n < a.nout) {
+                    double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
+                    atomicAdd(dst, (double)t1);
+                    atomicAdd(dst + 1, (double)t2);
+                }
+            }
+        }
     }
-    if (!wide) {
+    if (!wide && !gs_any) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -448,26 +511,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int m = m0 + wm * WTM + i * 32 + row;
             if (m >= a.M) continue;
-            size_t opix;
-            if (direct) {
-                opix = (size_t)m;
-            } else {
-                int ow = m % a.wg, t = m / a.wg;
-                int oh = t % a.hg, n = t / a.hg;
-                opix = ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
-            }
+            const size_t opix = out_pix(m);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 if (n < a.nout) {
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[n];
+                    float v = acc[i][j][r] + bj[j];
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;                       // statistics of the value as stored
                     s1[j] += v;
-                    float q = v;                         // forward statistics: sum of squares; gsum: sum of v * aux
-                    if (gsn[j]) q = gsum_aux<T>(gauxn[j], opix * (size_t)gldn[j]);
-                    s2[j] += v * q;
+                    s2[j] += v * v;
                     if (n < a.n1)
                         ((TO*)a.y)[opix * a.ldy + n] = vo;
                     else
@@ -500,25 +553,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                 }
             }
         }
-    } else if (!wide && (a.gred[0] || a.gred[1])) {
-        const int mw = m0 + wm * WTM;
-        if (mw < a.M) {
-            const int img = mw / a.hw;
-            const int slot = ((mw - img * a.hw) / WTM) % a.gslots;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-                const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-                const int n = n0 + wn * WTN + j * 32 + l31;
-                int nl, pc;
-                const int gp = gsum_part(a, n, nl, pc);
-                if (h == 0 && gsn[j]) {
-                    double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
-                    atomicAdd(dst, (double)t1);
-                    atomicAdd(dst + 1, (double)t2);
-                }
-            }
-        }
     }
 }
 
@@ -540,7 +574,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // cost 3 % when its arithmetic sat on that path.
 // TM = 32-row MFMA tiles per wave along M (2: wave tile 64 pixels x 64 channels; 4, static taps only: 128 x 64 -- half the waves,
 // six fragment reads per eight MFMAs instead of four per four, twice the MFMAs per barrier: the bf16 form, whose K step is 8x shorter).
-template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2>
+// GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) -- an instantiation of its own, so that the forward kernels
+// carry none of its code or registers.
+template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2, bool GS = false>
 __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
     static_assert(TM == 2 || (TM == 4 && ST), "four M tiles per wave: static-tap form only");
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
@@ -777,6 +813,14 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     float s1[2], s2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) s1[j] = s2[j] = 0.f;
+    // the bias of the lane's columns, once (see tapgemm_dma_kernel: a per-element fetch serialises the stores)
+    float bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        bj[j] = (a.bias && n < a.nout) ? a.bias[n] : 0.f;
+        asm volatile("" : "+v"(bj[j]));           // waited for here, once (see tapgemm_dma_kernel)
+    }
     // bf16 outputs: the MFMA accumulator layout gives each lane one 2-byte element per row, i.e. 64 two-byte
     // store instructions per wave -- measured 29 % of a 64-channel 256x256 layer.  Stage the wave's 64 x 64 tile
     // through LDS (free once every wave is past its last fragment read) and write 16 bytes per lane instead:
@@ -795,8 +839,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + wn * 64 + j * 32 + l31;
-                    float v = acc[i][j][r];
-                    if (a.bias && n < a.nout) v += a.bias[n];
+                    float v = acc[i][j][r] + bj[j];
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = n < a.nout ? (float)vo : 0.f;
                     s1[j] += v;
@@ -812,13 +855,31 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rr = lane >> 3, ch = lane & 7;
         const int n = n0 + wn * 64 + ch * 8;
-        int gnl, gpc;
-        const int gp = gsum_part(a, n, gnl, gpc);
-        const bool gs = a.gred[gp] != nullptr && n < a.nout;         // per lane: its eight channels lie in one part
-        const unsigned short* gaux = (const unsigned short*)a.gaux[gp] + gnl;
+        // gsum: the wave's 64 columns lie in one output part (n1 % 64 == 0, checked by the launcher): part, pitch and descriptor are
+        // scalars, aux is read with 32-bit offsets (the part is below 4 GiB)
+        const int gp = __builtin_amdgcn_readfirstlane(n0 + wn * 64) < a.n1 ? 0 : 1;
+        const int gpc = gp ? a.nout - a.n1 : a.n1, gnl = n - (gp ? a.n1 : 0);
+        const bool gon = GS && a.gred[gp] != nullptr;
+        const bool gs = gon && n < a.nout;
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, gon ? 0xfffffff0u : 0u, 0x00020000);
+        const unsigned ldab = (unsigned)a.ldgaux[gp] * 2u;
         float t1[8], t2[8];
+        u32x4 gav[4 * TM];
+        if constexpr (GS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t1[e] = t2[e] = 0.f;
+            for (int e = 0; e < 8; ++e) t1[e] = t2[e] = 0.f;
+            // every aux row of the lane first (the accumulators are dead by now: 32 registers are free), then the stores -- left to
+            // itself hipcc also hoists the LDS reads and the store addresses of all eight rows and spills 200 registers
+#pragma unroll
+            for (int it = 0; it < 4 * TM; ++it) {
+                const int row = it * 8 + rr;
+                const int i = row >> 5, r32 = row & 31;
+                const int py = 2 * TM * wm + 2 * i + (r32 >> 4), px = r32 & 15;
+                const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
+                gav[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, opix * ldab + (unsigned)(n < a.nout ? gnl : 0) * 2u, 0, 0));
+            }
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int it = 0; it < 4 * TM; ++it) {
             const int row = it * 8 + rr;
@@ -834,28 +895,81 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
             }
 #endif
-            if (gs) gsum_wide_accum(v, *(const u32x4*)(gaux + opix * a.ldgaux[gp]), t1, t2);
+            if constexpr (GS) {
+                gsum_wide_accum(v, gav[it], t1, t2);
+                asm volatile("" ::: "memory");             // one row at a time
+            }
         }
-        if (a.gred[0] || a.gred[1]) {                      // block-uniform
-            const int slot = (prem * WGM + wm) % a.gslots;
-            double* dst = gs ? a.gred[gp] + ((size_t)slot * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2 : nullptr;
-            gsum_wide_flush<8>(t1, t2, lane, dst);
+        if constexpr (GS) {
+            if (gon) {                                     // wave-uniform
+                const int slot = (prem * WGM + wm) % a.gslots;
+                double* dst = gs ? a.gred[gp] + ((size_t)slot * a.gbatch * gpc + (size_t)img * gpc + gnl) * 2 : nullptr;
+                gsum_wide_flush<8>(t1, t2, lane, dst);
+            }
         }
     }
-    // narrow path, gsum: per column group the aux tensor of the lane's column (null: no sums for that part)
-    bool gsn[2];
-    const T* gauxn[2];
-    int gldn[2];
+    // narrow path, gsum.  The 32 columns of a (wave, j) group lie in one output part (n1 % 32 == 0, checked by the launcher), so
+    // "this group takes sums", its aux tensor and pitch are scalars: the sixteen aux loads of a 32 x 32 tile are issued back to
+    // back in front of the tile's stores (a per-element conditional load made hipcc wait for every load AND the store before it:
+    // 64 serialized round trips per wave tile).
+    // (bf16 outputs take their sums in the LDS-staged path above: the launcher only fuses when that path's alignment conditions hold)
+    const bool gs_any = GS && sizeof(TO) == 4 && (a.gred[0] != nullptr || a.gred[1] != nullptr);
+    if constexpr (GS && sizeof(TO) == 4) if (!wide && gs_any) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        int nl, pc;
-        const int gp = gsum_part(a, n, nl, pc);
-        gsn[j] = a.gred[gp] != nullptr && n < a.nout;
-        gauxn[j] = (const T*)a.gaux[gp] + nl;
-        gldn[j] = a.ldgaux[gp];
+        for (int j = 0; j < 2; ++j) {
+            const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * 64 + j * 32);
+            const int gp = nb < a.n1 ? 0 : 1;
+            const bool on = a.gred[gp] != nullptr && nb < a.nout;
+            const int n = nb + l31;
+            const int nl = n - (gp ? a.n1 : 0);
+            const int pc = gp ? a.nout - a.n1 : a.n1;
+            // aux through a scalar descriptor and 32-bit offsets (the part is below 4 GiB); zero-length when the group takes no sums
+            const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
+            const unsigned ldab = (unsigned)a.ldgaux[gp] * (unsigned)sizeof(T), nlb = (unsigned)(n < a.nout ? nl : 0) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float q[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 2 * TM * wm + 2 * i + (row >> 4), px = row & 15;
+                    const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
+                    if constexpr (sizeof(T) == 4)
+                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + nlb, 0, 0));
+                    else
+                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, opix * ldab + nlb, 0, 0) << 16);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 2 * TM * wm + 2 * i + (row >> 4), px = row & 15;
+                    const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
+                    if (n < a.nout) {
+                        float v = acc[i][j][r] + bj[j];
+                        const TO vo = (TO)shm_lrelu(v, a.slope);
+                        v = (float)vo;
+                        s1[j] += v;
+                        s2[j] += v * q[r];
+                        if (n < a.n1)
+                            ((TO*)a.y)[opix * a.ldy + n] = vo;
+                        else
+                            ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
+                    }
+                }
+            }
+            if (on) {
+                const int slot = (prem * WGM + wm) % a.gslots;
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (h == 0 && n < a.nout) {
+                    double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
+                    atomicAdd(dst, (double)t1);
+                    atomicAdd(dst + 1, (double)t2);
+                }
+            }
+        }
     }
-    if (!wide) {
+    if (!wide && !gs_any) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -867,14 +981,11 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
                 if (n < a.nout) {
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[n];
+                    float v = acc[i][j][r] + bj[j];
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;
                     s1[j] += v;
-                    float q = v;                         // forward statistics: sum of squares; gsum: sum of v * aux
-                    if (gsn[j]) q = gsum_aux<T>(gauxn[j], opix * (size_t)gldn[j]);
-                    s2[j] += v * q;
+                    s2[j] += v * v;
 #ifdef SHM_ABL_NOSTORE
                     if (v == 123.456f)                  // timing only: keep the value live, store nothing
 #endif
@@ -898,21 +1009,6 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             const int n = n0 + wn * 64 + j * 32 + l31;
             if (h == 0 && n < a.nout) {
                 double* dst = a.stats + (size_t)slot * a.stats_stride + ((size_t)img * a.nout + n) * 2;
-                atomicAdd(dst, (double)t1);
-                atomicAdd(dst + 1, (double)t2);
-            }
-        }
-    } else if (!wide && (a.gred[0] || a.gred[1])) {
-        const int slot = (prem * WGM + wm) % a.gslots;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-            const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            int nl, pc;
-            const int gp = gsum_part(a, n, nl, pc);
-            if (h == 0 && gsn[j]) {
-                double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
                 atomicAdd(dst, (double)t1);
                 atomicAdd(dst + 1, (double)t2);
             }
@@ -1361,10 +1457,14 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
 
     double S1 = 0.0, S2 = 0.0;
     int simg = q0 / ppi;
-    // gsum: this lane's column lies in part gp; aux of the part, null when the part takes no sums
-    int gnl = 0, gpc = 0;
-    const int gp = gsum_part(a, ncol, gnl, gpc);
-    const float* const gaux = GS && a.gred[gp] ? (const float*)a.gaux[gp] + gnl : nullptr;
+    // gsum: the wave's 16 columns lie in one part (n1 % 16 == 0): gp, the pitch and the "this part takes sums" test are scalars
+    const int gp = __builtin_amdgcn_readfirstlane(n0 + wn * 16) < a.n1 ? 0 : 1;
+    const int gpc = gp ? a.nout - a.n1 : a.n1, gnl = ncol - (gp ? a.n1 : 0);
+    const bool gson = GS && a.gred[gp] != nullptr;
+    // (aux has the extent of its output part, which the launcher checked to be below 4 GiB: 32-bit offsets, scalar descriptor)
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, gson ? 0xfffffff0u : 0u, 0x00020000);
+    const unsigned ldab = (unsigned)a.ldgaux[gp] * 4u;
+    const float* const gaux = gson ? (const float*)a.gaux[gp] : nullptr;
     auto flush = [&](int img) {
         double t1 = S1 + __shfl_xor(S1, 16, 64), t2 = S2 + __shfl_xor(S2, 16, 64);
         t1 += __shfl_xor(t1, 32, 64);
@@ -1395,6 +1495,20 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave; everyone is done with the other buffer
         asm volatile("" ::: "memory");
         if (q + 1 < q1) dma(q + 1, buf ^ 1);
+        // gsum: aux at the sixteen output positions of this lane (the same 64-byte segments as the epilogue's stores), issued here so
+        // that their latency passes under the 576 MFMAs of the patch.  A part without sums has a zero-length descriptor: zeros.
+        float gq[4][4];
+        if constexpr (GS) {
+            const int img = q / ppi, prem = q - img * ppi;
+            const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
+                    gq[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + (unsigned)gnl * 4u, 0, 0));
+                }
+        }
 
         f32x4 acc[4];
 #pragma unroll
@@ -1402,13 +1516,18 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][r] = bias;
         const float* Ab = smem + buf * ABUF;
+        // gsum form: the 36 fragment addresses are formed per patch -- hoisted out of the patch loop (as hipcc does) they no longer fit
+        // beside the sixteen aux values, and the spills landed in the DMA issue path (a scratch reload + vmcnt(0) in front of every
+        // halo DMA: the DMAs of a patch ran one after the other, 84 instead of 131 TFLOP/s)
+        int hbq = hb0;
+        if constexpr (GS) asm volatile("" : "+v"(hbq));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // rows of the four M tiles are 18 halo rows apart; the swizzle term (R >> 1) grows by 9 per tile: per-tile addresses
             int fa[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int hrow = hb0 + m * HC + tsh[t];
+                const int hrow = hbq + m * HC + tsh[t];
                 fa[m] = hrow * 16 + (((lq + (hrow >> 1)) & 3) << 2);
             }
 #pragma unroll
@@ -1429,17 +1548,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         if ((GS || a.stats) && img != simg) {
             flush(simg);
             simg = img;
-        }
-        // gsum: aux at the sixteen output positions of this lane (the same 64-byte segments as the stores below)
-        float gq[4][4];
-        if constexpr (GS) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t opix = (size_t)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
-                    gq[m][r] = gaux ? gaux[opix * a.ldgaux[gp]] : 0.f;
-                }
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1462,7 +1570,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         S1 += (double)s1;
         S2 += (double)s2;
         // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush; the gsum
-        // form's aux loads are older than the stores and have been waited for)
+        // form's aux loads were issued right behind the halo and have been consumed: loads return in order)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     if (GS || a.stats) flush(simg);
@@ -1631,7 +1739,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    if (!wide) {
+    if (!wide && a.gred[0] == nullptr) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -1643,6 +1751,50 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
                     const size_t opix = ((size_t)img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw);
                     if (ncol < a.nout) ((TO*)a.y)[opix * a.ldy + ncol] = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
                 }
+    }
+    if (!wide && a.gred[0] != nullptr) {
+        // gsum (fp32 outputs; the launcher does not fuse bf16 ones): the stride-2 input gradient of a discriminator block writes
+        // the gradient at the previous block's InstanceNorm output.  Sixteen aux loads per 32 x 32 tile in front of its stores
+        // (scalar descriptor, 32-bit offsets); the block's 32 x 32 output pixels belong to one image: one pair of atomics per column.
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[0], 0, 0xfffffff0u, 0x00020000);
+        const unsigned ldab = (unsigned)a.ldgaux[0] * (unsigned)sizeof(T), nlb = (unsigned)(ncol < a.nout ? ncol : 0) * (unsigned)sizeof(T);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float q[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
+                    const unsigned opix = (unsigned)((img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw));
+                    if constexpr (sizeof(T) == 4)
+                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + nlb, 0, 0));
+                    else
+                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, opix * ldab + nlb, 0, 0) << 16);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
+                    const size_t opix = ((size_t)img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw);
+                    if (ncol < a.nout) {
+                        const TO vo = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
+                        const float v = (float)vo;
+                        s1 += v;
+                        s2 += v * q[r];
+                        ((TO*)a.y)[opix * a.ldy + ncol] = vo;
+                    }
+                }
+            }
+        const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
+        if (h == 0 && ncol < a.nout) {
+            const int slot = (prem * 4 + wm) % a.gslots;
+            double* dst = a.gred[0] + ((size_t)slot * a.gbatch * a.nout + (size_t)img * a.nout + ncol) * 2;
+            atomicAdd(dst, (double)t1);
+            atomicAdd(dst + 1, (double)t2);
+        }
     }
 }
 
@@ -1762,16 +1914,24 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         for (int p = 0; p < 2; ++p)
             if (a.gred[p]) al = al && (sizeof(TO) == 4 || (a.ldgaux[p] % 8 == 0 && ((size_t)a.gaux[p] & 15) == 0));
         al = al && (a.y2 == nullptr || a.n1 % 32 == 0);
+        const bool small = a.ybytes != 0 && (a.y2 == nullptr || a.y2bytes != 0);        // 32-bit offsets into aux (it has the output's extent)
+        // bf16 outputs: the sums are taken in the LDS-staged 16-byte store path, which has its own alignment conditions
+        const bool wide_ok = sizeof(TO) == 4 || ((a.nout % 8 == 0) && (a.n1 % 8 == 0) && (a.ldy % 8 == 0) && (((size_t)a.y & 15) == 0) &&
+                                                 (a.y2 == nullptr || ((a.ldy2 % 8 == 0) && (((size_t)a.y2 & 15) == 0))));
+        al = al && wide_ok;
         switch (v) {
-        case SHM_TG_HALO128: case SHM_TG_HALO64: case SHM_TG_HALO128_ST: case SHM_TG_HALO64_ST: case SHM_TG_HALO128_PH8:
-            gs_fused = al;
+        case SHM_TG_HALO128_ST: case SHM_TG_HALO64_ST:          // (the other halo forms are forced-only variants: reduce pass)
+            gs_fused = al && small && (a.y2 == nullptr || a.n1 % 64 == 0);
             break;
         case SHM_TG_DMA_128x128: case SHM_TG_DMA_64x128: case SHM_TG_DMA_128x64: case SHM_TG_DMA_64x64: case SHM_TG_DMA_256x64:
         case SHM_TG_DMA_256x128: case SHM_TG_DMA_128x128_BK32: case SHM_TG_DMA_128x128_NST4:
             gs_fused = al && (a.hg * a.wg) % 64 == 0;
             break;
         case SHM_TG_WREG:
-            gs_fused = al && ((wreg_ok && sizeof(TO) == 2) || (wreg32_ok && wreg32_wn == 4 && a.x2 == nullptr));
+            gs_fused = al && small && ((wreg_ok && sizeof(TO) == 2) || (wreg32_ok && wreg32_wn == 4 && a.x2 == nullptr));
+            break;
+        case SHM_TG_PHASE4:                                     // fp32 outputs only (the element-store epilogue)
+            gs_fused = sizeof(TO) == 4 && small && a.gred[1] == nullptr;
             break;
         default:
             break;
@@ -1794,8 +1954,11 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         break;
     case SHM_TG_HALO128_ST:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
-        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
+        if (gs_fused)
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, true>" : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_ST_W4:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps/4 waves needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
@@ -1804,8 +1967,11 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         break;
     case SHM_TG_HALO64_ST:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
-        hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
-        shm_set_last_kernel("tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
+        if (gs_fused)
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, true>" : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_PH8:
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in

@@ -631,6 +631,30 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     }
     const int n = blockIdx.y, hw = k.h * k.w;
     const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    // RAW: the two means of every channel, formed ONCE per block from the slot copies (thread ch sums channel ch's slots: with every
+    // thread summing the slots of its own four channels the pass spent a third of its time re-reading 64 doubles per thread)
+    __shared__ float sm12[RAW ? 2048 : 2];
+    if constexpr (RAW) {
+        for (int ch = threadIdx.x; ch < k.c; ch += 256) {
+            const size_t i = ((size_t)n * k.c + ch) * 2;
+            const size_t sstride = (size_t)gridDim.y * k.c * 2;
+            double sg = 0.0, sga = 0.0, pg = 0.0, pgx = 0.0;
+            for (int sl = 0; sl < k.gslots; ++sl) {
+                sg += k.gred[sl * sstride + i];
+                sga += k.gred[sl * sstride + i + 1];
+            }
+            if (k.gredp) {
+                for (int sl = 0; sl < k.gslots; ++sl) {
+                    pg += k.gredp[sl * sstride + i];
+                    pgx += k.gredp[sl * sstride + i + 1];
+                }
+            }
+            const double bt = k.gredp ? (double)k.beta[ch] : 0.0;
+            sm12[ch * 2] = (float)((sg + pg) / hw);
+            sm12[ch * 2 + 1] = (float)((k.stats[i + 1] * (sga - k.stats[i] * sg) + (pgx - bt * pg)) / hw);
+        }
+        __syncthreads();
+    }
     double v[1][4] = {};
     if (pm.active) {
         float mean[4], inv[4], m1[4], m2[4];
@@ -640,21 +664,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             mean[e] = (float)k.stats[i];
             inv[e] = (float)k.stats[i + 1];
             if constexpr (RAW) {
-                const size_t sstride = (size_t)gridDim.y * k.c * 2;
-                double sg = 0.0, sga = 0.0, pg = 0.0, pgx = 0.0;
-                for (int sl = 0; sl < k.gslots; ++sl) {
-                    sg += k.gred[sl * sstride + i];
-                    sga += k.gred[sl * sstride + i + 1];
-                }
-                if (k.gredp) {
-                    for (int sl = 0; sl < k.gslots; ++sl) {
-                        pg += k.gredp[sl * sstride + i];
-                        pgx += k.gredp[sl * sstride + i + 1];
-                    }
-                }
-                const double bt = k.gredp ? (double)k.beta[pm.cl * 4 + e] : 0.0;
-                m1[e] = (float)((sg + pg) / hw);
-                m2[e] = (float)((k.stats[i + 1] * (sga - k.stats[i] * sg) + (pgx - bt * pg)) / hw);
+                m1[e] = sm12[(pm.cl * 4 + e) * 2];
+                m2[e] = sm12[(pm.cl * 4 + e) * 2 + 1];
             } else {
                 m1[e] = (float)(k.red[i] / hw);
                 m2[e] = (float)(k.red[i + 1] / hw);

@@ -256,6 +256,7 @@ class Generator(_ModelBase):
         self.adt = dtype                                   # activation / MFMA operand dtype
         self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32   # gradient-signal tensors ([G] in the header)
         self.pad = pad_channels(dtype)
+        self.gsum = ops.gsum_default(dtype)                # InstanceNorm-backward sums in the producing epilogues
         assert image_size % 16 == 0 and filter_size % self.pad == 0, \
             f"image_size must be a multiple of 16 and filter_size of {self.pad}"
         self.layers = generator_layers(filter_size)
@@ -465,6 +466,8 @@ class Generator(_ModelBase):
         """(aux, ldaux, red) for the launch that writes the gradient at `rec`'s InstanceNorm output (its epilogue then delivers the
         sums of that block's InstanceNorm backward, ops.conv2d_dgrad(gsum=)).  pooled: the launch writes the gradient of the
         AveragePooling2D output instead; its sums go against the pooled normalised tensor (the next level's input)."""
+        if not self.gsum:
+            return None
         n, c = rec["n"], rec["cout"]
         key = "gredp" if pooled else "gred"
         red = self.arena.get(f"bwd/{key}/L{rec['li']}/{n}", (ops.GSUM_SLOTS * n * c * 2,), torch.float64)
@@ -658,6 +661,7 @@ class Discriminator(_ModelBase):
         self.adt = dtype
         self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32
         self.pad = pad_channels(dtype)
+        self.gsum = ops.gsum_default(dtype)
         self.dropout = dropout
         assert image_size % 32 == 0
         f, s = filter_size, image_size // 32
@@ -838,7 +842,7 @@ class Discriminator(_ModelBase):
                 ldx = rec["ldx"]
                 dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
                 gs = None
-                if i > 0:                  # dprev is the gradient at block i-1's InstanceNorm output: its sums come with it
+                if i > 0 and self.gsum:          # dprev is the gradient at block i-1's InstanceNorm output: its sums come with it
                     gred = A.get(f"d/bwd/gred{i - 1}/{n}", (ops.GSUM_SLOTS * n * cin * 2,), torch.float64)
                     gs = (c["recs"][i - 1]["a"], cin, gred)
                 ops.conv2d_dgrad(dz, cout, self.P.op_vars[i], dprev, None, cin, ldx, 0, n, h, h, cin, cout, 3, 2, gsum=gs)

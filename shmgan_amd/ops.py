@@ -180,6 +180,18 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
 
 
 GSUM_SLOTS = 8              # SHM_GSUM_SLOTS
+# InstanceNorm-backward sums in the producing epilogue (model.py).  Default by activation dtype: ON in float32 -- the convolutions
+# are MFMA bound there and take the extra aux read in their stride: -3.4 ms of reduce passes for +1.3 ms of epilogues per step at
+# BASELINE configs[1] -- OFF in bfloat16, where the same epilogues sit in latency-bound kernels and cost what the reduce passes
+# saved (rocprofv3, profiles/README.md round 3).  SHM_GSUM=0 / 1 overrides both (A/B measurements).
+import os as _os
+
+
+def gsum_default(dtype):
+    env = _os.environ.get("SHM_GSUM")
+    if env is not None:
+        return env not in ("0", "")
+    return dtype == torch.float32
 
 
 def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout, ksize, stride, gsum=None, gsum2=None):

@@ -199,3 +199,24 @@ def test_in_bwd_apply_matches_reduce_plus_apply(dt, pooled, n, h, c):
     scale = host(dz_ref.float().abs()).reshape(-1, c).sum(0)
     assert (np.abs(host(db) - host(db_ref)) / scale).max() < (4e-3 if dt == "bf16" else 2e-6)
     assert float(red.abs().max()) == 0.0 and float(dstage.abs().max()) == 0.0 and (redp is None or float(redp.abs().max()) == 0.0)
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+@pytest.mark.parametrize("S,F,B", [(64, 16, 2), (64, 32, 1)])
+def test_whole_step_with_and_without_gsum(dt, S, F, B):
+    """The same train_step with the InstanceNorm-backward sums taken in the epilogues (model.gsum = True: the float32 default)
+    and by shm_in_bwd's reduce pass (False: the bfloat16 default): identical forward, gradients equal to rounding.  Keeps the
+    non-default combination of either dtype under test (the parity suites run each dtype with its default)."""
+    from oracle import step_torch as st
+    from shmgan_amd import ShmGANwithSSpecSeg
+    res = {}
+    for on in (False, True):
+        m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+        m.G.gsum = m.D.gsum = on
+        m.train_step(*st.make_inputs(B, S), draws=st.make_draws(3, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+        torch.cuda.synchronize()
+        res[on] = (dict(m.losses()), host(m.G.P.grad), host(m.D.P.grad))
+    assert res[False][0] == res[True][0]                          # the forward pass does not depend on it
+    tol = 2e-5 if dt == "float32" else 2e-2
+    for i in (1, 2):
+        assert rel_l2(res[True][i], res[False][i]) < tol, (i, rel_l2(res[True][i], res[False][i]))
