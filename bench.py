@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s (6.29 TB/s is what a float4 copy reaches)
 
 
 def main():
@@ -199,9 +200,13 @@ def main():
             d = summ[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic = None
-            # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py, profiles/README.md)
-            tag = "r02_f32" if args.dtype == "f32" else ("r02_s512_b4_bf16" if (S, B) == (512, 4) else "r02_bf16")
-            tpath = ROOT / "profiles" / f"{tag}_traffic_pmc.json"
+            # HBM-side bytes are PMC counters: they need rocprofv3 --pmc passes of this same command, which cannot run inside the
+            # timed process -- the figure is read from the committed distillate of those passes (tools/profile_round.sh ->
+            # tools/pmc_traffic.py, profiles/README.md); `traffic_source` names the file
+            tags = (["r03_f32", "r02_f32"] if args.dtype == "f32" else
+                    (["r03_s512_b4_bf16", "r02_s512_b4_bf16"] if (S, B) == (512, 4) else ["r03_bf16", "r02_bf16"]))
+            tpath = next((ROOT / "profiles" / f"{t}_traffic_pmc.json" for t in tags if (ROOT / "profiles" / f"{t}_traffic_pmc.json").exists()),
+                         ROOT / "profiles" / "none")
             if tpath.exists():
                 tj = json.loads(tpath.read_text())
                 key = dom.split(" (+")[0].replace(" ", "")
@@ -211,6 +216,8 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": (f"profiles/{tpath.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured "
+                                   "in this run)") if traffic is not None else None,
                 "region": "serialized replay of the timed steps (single stream), same process",
                 "replay_ms_per_step": round(dt_serial / args.steps * 1e3, 3),
                 "whole_step_conv_tflops": round(sum(v["flops"] for v in summ.values()) / args.steps / (ms * 1e-3) / 1e12, 2),
@@ -219,6 +226,20 @@ def main():
                 "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
             }
+            # the HBM-bound side of the step (north star: ">= 70 % of the memory-bandwidth roofline"): the entry point with the most
+            # time among the elementwise passes, algorithmic bytes (every tensor read or written once) over its HIP-event time
+            bs = timer.bytes_summary()
+            if bs:
+                hdom = max(bs, key=lambda k: bs[k]["ms"])
+                hb = bs[hdom]
+                gbs = hb["bytes"] / (hb["ms"] * 1e-3) / 1e9
+                out["roofline_hbm"] = {
+                    "bound": "hbm", "kernel": hdom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": hb["launches"], "ms_per_step": round(hb["ms"] / args.steps, 3),
+                    "bytes_per_launch": hb["bytes"] / hb["launches"], "region": "serialized replay, HIP events around the entry point",
+                    "passes": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                   "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in bs.items()},
+                }
             if args.per_shape:
                 ps = timer.per_shape()
                 rows = [dict(kernel=k[0], shape=k[1], launches=v["launches"], ms_per_step=v["ms"] / args.steps,

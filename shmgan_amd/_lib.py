@@ -99,7 +99,7 @@ def header_functions():
 def build(force=False, verbose=False):
     """Compile csrc/*.hip into libshmgan_hip.so with hipcc (cross-compiles without a GPU)."""
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "common.h", HEADER]
+    deps = srcs + [CSRC / "common.h", CSRC / "ablate.h", HEADER]
     if not force and LIB_PATH.exists():
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:

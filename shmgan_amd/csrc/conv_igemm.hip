@@ -18,6 +18,7 @@
 // 128x64; operands go HBM/L2 -> LDS by DMA three stages deep (tapgemm_dma_kernel), or through an
 // 18x18 LDS halo for unit-stride 3x3 layers (tapgemm_halo_kernel).
 #include "common.h"
+#include "ablate.h"
 
 #include <stdlib.h>
 
@@ -276,12 +277,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             unsigned off = (okm[j] & tbit) ? (second ? rowb2[j] : rowb1[j]) + stepb : 0xffffffffu;
-#ifdef SHM_ABL_FIXADDR
-            off = rowb1[j];                       // timing only: constant address, no per-step work
-#endif
-#ifdef SHM_ABL_SAMELINE
-            off = (okm[j] & tbit) ? (unsigned)(dq * 16 + (off & 0x40u)) : 0xffffffffu;      // timing only
-#endif
+            if constexpr (abl::fixaddr) off = rowb1[j];                       // timing only: constant address, no per-step work
+            if constexpr (abl::sameline) off = (okm[j] & tbit) ? (unsigned)(dq * 16 + (off & 0x40u)) : 0xffffffffu;      // timing only
             if (second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(sa + j * 256), 16, (int)off, 0, 0, 0);
             else
@@ -291,14 +288,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             unsigned off = wrow[j] == 0xffffffffu ? 0xffffffffu : wrow[j] + wbase;
-#if defined(SHM_ABL_FIXADDR) || defined(SHM_ABL_SAMELINE)
-            off = wrow[j] == 0xffffffffu ? 0xffffffffu : (unsigned)(dq * 16);
-#endif
+            if constexpr (abl::fixaddr || abl::sameline) off = wrow[j] == 0xffffffffu ? 0xffffffffu : (unsigned)(dq * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * 256), 16, (int)off, 0, 0, 0);
         }
-#ifndef SHM_ABL_FIXADDR
-        advance();
-#endif
+        if constexpr (!abl::fixaddr) advance();
     };
 
     f32x16 acc[TM][TN];
@@ -344,9 +337,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SHM_LDS_BARRIER();          // all waves: stage s landed, compute(s-1) finished
         asm volatile("" ::: "memory");
-#ifndef SHM_ABL_NODMA
-        if (s + AHEAD < ksteps) dma(nxt);      // overwrites the buffer compute(s-1) was reading
-#endif
+        if constexpr (!abl::nodma)
+            if (s + AHEAD < ksteps) dma(nxt);      // overwrites the buffer compute(s-1) was reading
         compute(cur);
         asm volatile("" ::: "memory");
         cur = (cur == NST - 1) ? 0 : cur + 1;
@@ -685,9 +677,8 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     const int swb = (l31 >> 2) & 3;
     const int fb0 = l31 * 16 + ((0 + h) ^ swb) * 4, fb1 = l31 * 16 + ((2 + h) ^ swb) * 4;
 
-#ifdef SHM_ABL_NOLDS
-    const f32x4 abl_frag = *(const f32x4*)(sA + lane * 4);
-#endif
+    [[maybe_unused]] f32x4 abl_frag = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (abl::nolds) abl_frag = *(const f32x4*)(sA + lane * 4);
     auto compute = [&](int chunk, int tap, int bstage) {
         const float* Ab = sA + (chunk & 1) * ASTG;
         const float* Bb = sB + bstage * BSTG + wn * 64 * 16;
@@ -703,17 +694,17 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f32x4 av[2], bv[2];
-#ifdef SHM_ABL_NOLDS
-            // timing only: fragments from registers (one read per block), MFMAs + barriers + DMA unchanged
-            for (int i = 0; i < 2; ++i) av[i] = abl_frag;
-            for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
-            asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
-#else
+            if constexpr (abl::nolds) {
+                // timing only: fragments from registers (one read per block), MFMAs + barriers + DMA unchanged
+                for (int i = 0; i < 2; ++i) av[i] = abl_frag;
+                for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
+                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(Ab + fa[i][kk]);
+                for (int i = 0; i < 2; ++i) av[i] = *(const f32x4*)(Ab + fa[i][kk]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
-#endif
+                for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+            }
             if constexpr (TM == 2) tap_mfma<T, 2, 2>(av, bv, acc);
         }
     };
@@ -750,30 +741,29 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
                 SHM_LDS_BARRIER();
                 asm volatile("" ::: "memory");
-#ifndef SHM_ABL_NODMA
-                if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
-                if (tap < 7 || chunk + 1 < nch) dma_b();
-#endif
+                if constexpr (!abl::nodma) {
+                    if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
+                    if (tap < 7 || chunk + 1 < nch) dma_b();
+                }
                 const float* Bb = sB + (tap % 3) * BSTG + wn * 64 * 16;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     f32x4 av[TM], bv[2];
-#ifdef SHM_ABL_NOLDS
-                    for (int i = 0; i < TM; ++i) av[i] = abl_frag;
-                    for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
-                    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
-#else
-                    const lds_f4 ap = (lds_f4)(size_t)((Ab + (unsigned)(fs[tap] << 2)) ^ (unsigned)(kk << 5));
+                    if constexpr (abl::nolds) {
+                        for (int i = 0; i < TM; ++i) av[i] = abl_frag;
+                        for (int j = 0; j < 2; ++j) bv[j] = abl_frag;
+                        asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+                    } else {
+                        const lds_f4 ap = (lds_f4)(size_t)((Ab + (unsigned)(fs[tap] << 2)) ^ (unsigned)(kk << 5));
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) av[i] = ap[i * (2 * HC * 4)];               // 36 halo rows of 64 bytes per tile
+                        for (int i = 0; i < TM; ++i) av[i] = ap[i * (2 * HC * 4)];               // 36 halo rows of 64 bytes per tile
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
-#endif
-#ifndef SHM_ABL_NOMFMA
-                    tap_mfma<T, TM, 2>(av, bv, acc);
-#else
-                    asm volatile("" :: "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
-#endif
+                        for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4*)(Bb + j * 512 + (kk ? fb1 : fb0));
+                    }
+                    if constexpr (!abl::nomfma)
+                        tap_mfma<T, TM, 2>(av, bv, acc);
+                    else
+                        asm volatile("" :: "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
                 }
                 asm volatile("" ::: "memory");
             }
@@ -793,13 +783,11 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         }
         SHM_LDS_BARRIER();
         asm volatile("" ::: "memory");
-#ifndef SHM_ABL_NODMA
-        if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
-        if (s + 2 < ksteps) dma_b();
-#endif
-#ifndef SHM_ABL_NOMFMA
-        compute(chunk, tap, bst);
-#endif
+        if constexpr (!abl::nodma) {
+            if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);      // other A stage: last read in the previous chunk
+            if (s + 2 < ksteps) dma_b();
+        }
+        if constexpr (!abl::nomfma) compute(chunk, tap, bst);
         asm volatile("" ::: "memory");
         bst = bst == 2 ? 0 : bst + 1;
         if (++tap == 9) {
@@ -887,14 +875,12 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             const int i = row >> 5, r32 = row & 31;
             const int py = 2 * TM * wm + 2 * i + (r32 >> 4), px = r32 & 15;
             const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
-#ifndef SHM_ABL_NOSTORE
-            if (n < a.nout) {
+            if (!abl::nostore && n < a.nout) {
                 if (n < a.n1)
                     *(u32x4*)((unsigned short*)a.y + opix * a.ldy + n) = v;
                 else
                     *(u32x4*)((unsigned short*)a.y2 + opix * a.ldy2 + (n - a.n1)) = v;
             }
-#endif
             if constexpr (GS) {
                 gsum_wide_accum(v, gav[it], t1, t2);
                 asm volatile("" ::: "memory");             // one row at a time
@@ -986,9 +972,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     v = (float)vo;
                     s1[j] += v;
                     s2[j] += v * v;
-#ifdef SHM_ABL_NOSTORE
-                    if (v == 123.456f)                  // timing only: keep the value live, store nothing
-#endif
+                    if (!abl::nostore || v == 123.456f)         // (timing-only build: keep the value live, store nothing)
                     {
                         if (n < a.n1)
                             ((TO*)a.y)[opix * a.ldy + n] = vo;
@@ -1147,9 +1131,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         const int buf = (q - q0) & 1;
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave (each waited for its own part at the end
         asm volatile("" ::: "memory");                  // of the previous patch); everyone is done with the other buffer
-#ifndef SHM_ABL_NODMA
-        if (q + 1 < q1) dma(q + 1, buf ^ 1);
-#endif
+        if constexpr (!abl::nodma)
+            if (q + 1 < q1) dma(q + 1, buf ^ 1);
 
         f32x16 acc[2];
 #pragma unroll
@@ -1161,9 +1144,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         // beside the epilogue's sums and were spilled INSIDE the MFMA loop (27 scratch reloads per patch)
         int hbq = hb0;
         if constexpr (GS) asm volatile("" : "+v"(hbq));
-#ifdef SHM_WREG_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        if constexpr (abl::wreg_prio) __builtin_amdgcn_s_setprio(1);
         // (An explicit software pipeline -- fragment reads pinned two or three steps ahead of their MFMAs with sched_barrier --
         // was measured: no gain on the forward, 15 % slower input gradients.  With two waves per SIMD the partner's MFMAs cover
         // a wave's LDS latency; hipcc's just-in-time reads keep the VGPR count at the 256 limit.)
@@ -1184,23 +1165,21 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-#ifdef SHM_ABL_NOLDS
-                        f32x4 av = __builtin_bit_cast(f32x4, bw[t][c][kk]);       // timing only: no fragment reads
-                        asm volatile("" : "+v"(av));
-#else
-                        f32x4 av = *(const f32x4*)(Ab + c * ASTG + (fa[i] ^ (kk << 3)));
-#endif
-#ifdef SHM_ABL_NOMFMA
-                        asm volatile("" ::"v"(av), "v"(bw[t][c][kk]));              // timing only: fragment reads without the MFMAs
-#else
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[t][c][kk], acc[i], 0, 0, 0);
-#endif
+                        f32x4 av;
+                        if constexpr (abl::nolds) {
+                            av = __builtin_bit_cast(f32x4, bw[t][c][kk]);         // timing only: no fragment reads
+                            asm volatile("" : "+v"(av));
+                        } else {
+                            av = *(const f32x4*)(Ab + c * ASTG + (fa[i] ^ (kk << 3)));
+                        }
+                        if constexpr (abl::nomfma)
+                            asm volatile("" ::"v"(av), "v"(bw[t][c][kk]));          // timing only: fragment reads without the MFMAs
+                        else
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[t][c][kk], acc[i], 0, 0, 0);
                     }
         }
 
-#ifdef SHM_WREG_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        if constexpr (abl::wreg_prio) __builtin_amdgcn_s_setprio(0);
         // ---- epilogue of patch q
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
@@ -1209,12 +1188,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             simg = img;
         }
         float s1 = 0.f, s2 = 0.f;
-#ifdef SHM_ABL_NOEPI
-        asm volatile("" ::"v"(acc[0]), "v"(acc[1]));                                 // timing only: no epilogue at all
-        if constexpr (false) {
-#else
-        if constexpr (kWide) {
-#endif
+        if constexpr (abl::noepi) asm volatile("" ::"v"(acc[0]), "v"(acc[1]));       // timing only: no epilogue at all
+        if constexpr (kWide && !abl::noepi) {
             // the wave's 64 x 32 tile through LDS (64-byte rows; a 16-lane group of the 16-byte reads below covers four
             // whole rows = all 64 banks once)
 #pragma unroll
@@ -1249,16 +1224,14 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                 const u32x4 v = *(const u32x4*)(tile + row * 32 + (ch << 3));
                 const int py = 4 * wm + (row >> 4), px = row & 15;
                 const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
-#ifdef SHM_ABL_NOSTORE
-                asm volatile("" ::"v"(v), "v"(opix));                               // timing only
-#else
                 // the wave's 32 channels lie in one output part (n1 % 32 == 0): a scalar branch -- a per-lane choice of the buffer
                 // descriptor makes hipcc wrap every store in a readfirstlane (waterfall) loop
-                if (part0)
+                if constexpr (abl::nostore)
+                    asm volatile("" ::"v"(v), "v"(opix));                           // timing only
+                else if (part0)
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy, (opix * (unsigned)a.ldy + (unsigned)n) * 2u, 0, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(n - a.n1)) * 2u, 0, 0);
-#endif
             }
             if constexpr (GS) {
                 if (gaux) {                                               // wave-uniform
@@ -1320,11 +1293,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     }
                 }
             }
-#ifdef SHM_ABL_NOEPI
-        } else if constexpr (false) {
-#else
-        } else {
-#endif
+        } else if constexpr (!abl::noepi) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1348,10 +1317,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         S2 += s2;
         // halo(q + 1) was issued at the top of this patch; the only younger operations of this wave are this epilogue's
         // stores (bf16 outputs: exactly four 16-byte store instructions, plus the rare statistics flush), which stay in flight
-#if defined(SHM_ABL_NOSTORE) || defined(SHM_ABL_NOEPI)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        if constexpr (kWide && GS) {
+        if constexpr (abl::nostore || abl::noepi) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (kWide && GS) {
             if (a.gred[n0 + wn * 32 < a.n1 ? 0 : 1])                 // wave-uniform: four stores and the gsum atomic
                 asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else
@@ -1360,7 +1328,6 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     }
     if (a.stats) flush(simg);
 }
@@ -1891,8 +1858,9 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
             // 256 x 128 tile amortise the per-step barrier and the weight slice over twice the rows (tools/bench_s2.py: bf16 64 -> 128
             // @256x256 n = 40 230 -> 183 us, n = 96 @128x128 135 -> 110; fp32 859 -> 801, 522 -> 490; from K = 256 (fp32) / 512 (bf16) on it loses)
             v = SHM_TG_DMA_256x128;
-        } else if (sizeof(T) == 2 && nphase == 1 && a.nout > 64 && bk32_ok && a.K >= 256) {
-            // bf16, long K: 64 channels per K step -- twice the MFMAs per barrier (256 -> 512 @32x32 n = 96: 109 -> 88 us, 512 -> 1024 @16x16: 108 -> 83)
+        } else if (nphase == 1 && a.nout > 64 && bk32_ok && (sizeof(T) == 2 ? a.K >= 256 : (a.K >= 256 && a.K < 512 && a.is == 2 && tiles128 >= 512))) {
+            // long K: twice the channels per K step -- twice the MFMAs per barrier (bf16 256 -> 512 @32x32 n = 96: 109 -> 88 us, 512 -> 1024
+            // @16x16: 108 -> 83; fp32 stride-2 forward 256 -> 512 @64x64 n = 40: 807 -> 749 us, @32x32 n = 96: 486 -> 462, round 3 tools/bench_s2.py)
             v = SHM_TG_DMA_128x128_BK32;
         } else if (a.nout > 64 && tiles128 < shm_tune(SHM_TUNE_TAPGEMM_SMALL_GRID)) {
             // small grids (16x16 maps, the n = 8 pass of the stride-2 / transposed layers): 64-row tiles double the number of

@@ -14,6 +14,7 @@
 // (9 accumulators).  Partial slabs go to a workspace and are summed in a fixed order by
 // wgrad_reduce_kernel (deterministic, no float atomics).
 #include "common.h"
+#include "ablate.h"
 
 // XCD-aware block order (speed only): the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, each with its
 // own L2, so the blocks that share an operand tile -- same pixels, different (ci, co) tile -- land on eight different L2s and
@@ -142,9 +143,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             unsigned off = (m9 & tbit[j]) ? base + (unsigned)tofb[j] : 0xffffffffu;
-#ifdef SHM_ABL_SAMELINE
-            off = (m9 & tbit[j]) ? (unsigned)(c4 * 16 + (off & 0x300u)) : 0xffffffffu;        // timing only
-#endif
+            if constexpr (abl::sameline) off = (m9 & tbit[j]) ? (unsigned)(c4 * 16 + (off & 0x300u)) : 0xffffffffu;        // timing only
             if (STRADDLE) {
                 u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(second ? 0xffffffffu : off), 0, 0);
                 u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(second ? off : 0xffffffffu), 0, 0);
@@ -198,21 +197,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         sstore(0, rx0, rd0);
         __syncthreads();
         int s = 0;
-#ifdef SHM_ABL_NOBAR
-#define WG_BAR()
-#else
-#define WG_BAR() __syncthreads()
-#endif
-#ifdef SHM_ABL_NOLOAD
-#define WG_GLOAD(a_, b_)
-#else
-#define WG_GLOAD(a_, b_) gload(a_, b_)
-#endif
-#ifdef SHM_ABL_NOSTORE
-#define WG_SSTORE(i_, a_, b_)
-#else
-#define WG_SSTORE(i_, a_, b_) sstore(i_, a_, b_)
-#endif
+#define WG_BAR()                                  \
+    do {                                          \
+        if constexpr (!abl::nobar) __syncthreads(); \
+    } while (0)
+#define WG_GLOAD(a_, b_)                            \
+    do {                                            \
+        if constexpr (!abl::noload) gload(a_, b_);    \
+    } while (0)
+#define WG_SSTORE(i_, a_, b_)                            \
+    do {                                                 \
+        if constexpr (!abl::nostore) sstore(i_, a_, b_);   \
+    } while (0)
         for (; s + 3 < nstages; s += 2) {
             WG_GLOAD(rx0, rd0);
             compute(0);

@@ -378,35 +378,57 @@ class Generator(_ModelBase):
         ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
 
     # -- forward --------------------------------------------------------------------------
-    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, pooled=None, apply=True):
-        """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization.  Returns (ahat, record).
-        pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation.
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, r0, r1, part, pooled=None, apply=True):
+        """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization on the samples [r0, r1) of a batch of n.  x, x2, pooled are
+        FULL-batch tensors (the record describes them: the backward pass runs on the whole batch); the launches take row views.
+        Returns (ahat, record).  pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation.
         apply=False: the consumer normalises on the fly (the head, ops.head_in_fwd): returns the un-normalised tensor."""
         _, _, k, cin, cout = self.layers[li]
         cin_p = _padk(cin, self.pad)
         A = self.arena
+        nb = r1 - r0
         a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
         ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt) if apply else None
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
-        scr = A.get(f"stats_scratch/{n * cout}", (ops.STATS_SLOTS * n * cout * 2,), torch.float64)
-        ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a, cout, n, h, w, cin_p, cout,
-                          k, 1, LRELU, stats, IN_EPS, cin_real=cin, scratch=scr)
+        st = stats[r0 * cout * 2:r1 * cout * 2]
+        # zero-on-return scratch: one per concurrently running part
+        scr = A.get(f"stats_scratch/{nb * cout}/p{part}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
+        ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a[r0:r1], cout, nb, h, w,
+                          cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout)
         if not apply:
             return a, rec
         if pooled is not None:
-            ops.in_apply_pool(a, cout, stats, self.betas[bi], ahat, cout, pooled, cout, n, h, w, cout)
+            ops.in_apply_pool(a[r0:r1], cout, st, self.betas[bi], ahat[r0:r1], cout, pooled[r0:r1], cout, nb, h, w, cout)
         else:
-            ops.in_apply(a, cout, stats, self.betas[bi], ahat, cout, n, h * w, cout)
+            ops.in_apply(a[r0:r1], cout, st, self.betas[bi], ahat[r0:r1], cout, nb, h * w, cout)
         return ahat, rec
 
-    def forward(self, x16, tag, attn=None):
+    def forward(self, x16, tag, attn=None, parts=1):
         """x16: [N,S,S,pad] (10 real channels, zero padded to the 64-byte pitch).  Returns gen_Y [N,S,S,1].
         attn: attention_forward()'s maps ([B,...], N a multiple of B: image i is a copy of sample i % B): added to the four
-        skip tensors, `down_k + attn_k` (SHM.py:290-293); the pooled path keeps the un-augmented tensor."""
-        n, S, F = x16.shape[0], self.S, self.F
+        skip tensors, `down_k + attn_k` (SHM.py:290-293); the pooled path keeps the un-augmented tensor.
+        parts = 2: the batch is evaluated as two halves, the second one on the second stream (samples are independent:
+        InstanceNorm is per sample, so this is exact).  A forward pass is a dependency chain conv -> statistics -> normalise ->
+        conv with nothing beside it: the normalisation passes of one half then run under the other half's convolutions and each
+        half fills the launch tails of the other (rocprofv3 timeline: 2 ms of a 121 ms fp32 step are normalisation passes with no
+        MFMA kernel running)."""
+        n, S = x16.shape[0], self.S
         assert tuple(x16.shape) == (n, S, S, self.pad) and x16.dtype == self.adt
         self.prepare_weights()
+        if parts > 1 and self.lane.stream is not None and n >= 2 * parts and (attn is None or (n // parts) % self._attn_B == 0):
+            cut = n // parts
+            bounds = [(p * cut, n if p == parts - 1 else (p + 1) * cut) for p in range(parts)]
+            for p in range(1, parts):
+                self.lane.submit(lambda p=p: self._forward_rows(x16, tag, attn, bounds[p][0], bounds[p][1], p))
+            y = self._forward_rows(x16, tag, attn, bounds[0][0], bounds[0][1], 0)
+            self.lane.join()
+            return y
+        return self._forward_rows(x16, tag, attn, 0, n, 0)
+
+    def _forward_rows(self, x16, tag, attn, r0, r1, part):
+        n, S, F = x16.shape[0], self.S, self.F
+        nb = r1 - r0
         A = self.arena
         recs = []
         cur, ld, h = x16, self.pad, S
@@ -417,7 +439,7 @@ class Generator(_ModelBase):
             for j in range(2):
                 if j == 1:            # the level's second block: its normalisation pass also writes the pooled tensor
                     pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, self.layers[li][4]), self.adt)
-                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, pooled=pooled)
+                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, pooled=pooled)
                 r["pooled"] = pooled
                 recs.append(r)
                 ld = self.layers[li][4]
@@ -425,13 +447,13 @@ class Generator(_ModelBase):
                 bi += 1
             if attn is not None:
                 skip = A.get(f"{tag}/skip{lvl}", (n, h, h, ld), self.adt)
-                ops.add_bcast(cur, attn[lvl], skip, n, h * h * ld, self._attn_B)
+                ops.add_bcast(cur[r0:r1], attn[lvl], skip[r0:r1], nb, h * h * ld, self._attn_B, r0)
                 downs.append((skip, ld, h))
             else:
                 downs.append((cur, ld, h))
             cur, h = pooled, h // 2
         for _ in range(2):                       # the two 1x1 blocks
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h)
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part)
             recs.append(r)
             li += 1
             bi += 1
@@ -439,26 +461,28 @@ class Generator(_ModelBase):
         for lvl in range(4):
             _, _, _, cin, cout = self.layers[li]
             u = A.get(f"{tag}/u{lvl}", (n, 2 * h, 2 * h, cout), self.adt)
-            ops.conv2d_transpose_fwd(cur, ld, self.P.op_vars[2 * li], self.P.vars[2 * li + 1], u, cout, n, h, h, cin,
+            ops.conv2d_transpose_fwd(cur[r0:r1], ld, self.P.op_vars[2 * li], self.P.vars[2 * li + 1], u[r0:r1], cout, nb, h, h, cin,
                                      cout, LRELU)
             ups.append(dict(li=li, x=cur, ldx=ld, u=u, h=h))
             li += 1
             h *= 2
             skip, sld, sh = downs[3 - lvl]
             assert sh == h
-            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h)   # concat [u, skip]
+            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h, r0, r1, part)   # concat [u, skip]
             recs.append(r)
             ld = self.layers[li][4]
             li += 1
             bi += 1
             # the last block's InstanceNorm is applied by the head kernels (forward and backward) on the fly
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, apply=lvl < 3)
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, apply=lvl < 3)
             recs.append(r)
             li += 1
             bi += 1
         y = A.get(f"{tag}/y", (n, S, S, 1))
-        ops.head_in_fwd(cur, ld, r["stats"], self.betas[r["bi"]], self.P.vars[2 * li], self.P.vars[2 * li + 1], y, n, S * S, ld, LRELU)
-        self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, head_rec=r, y=y, x16=x16, attn=attn is not None)
+        ops.head_in_fwd(cur[r0:r1], ld, r["stats"][r0 * ld * 2:r1 * ld * 2], self.betas[r["bi"]], self.P.vars[2 * li], self.P.vars[2 * li + 1], y[r0:r1],
+                        nb, S * S, ld, LRELU)
+        if part == 0:                 # the records describe full-batch tensors: identical whichever part builds them
+            self.ctx[tag] = dict(n=n, recs=recs, ups=ups, head_x=cur, head_rec=r, y=y, x16=x16, attn=attn is not None)
         return y
 
     # -- backward -------------------------------------------------------------------------
@@ -720,18 +744,21 @@ class Discriminator(_ModelBase):
         self._attn_B = B
         return self.attn.forward(mask, B, self.S)
 
-    def forward(self, xd16, keep_mask=None, mask_rows=(), parts=None, attn=None):
+    def forward(self, xd16, keep_mask=None, mask_rows=(), parts=None, attn=None, join=None):
         """xd16 [N,S,S,16] (rgb + zeros).  keep_mask [len(mask_rows)...] is the Dropout keep mask of
         the `training=True` samples: mask_rows = list of (row_start, nrows, mask_row_start).
         parts: optional list of (row0, row1, run) -- the conv trunk is evaluated per row range (samples
         are independent: InstanceNorm) through `run(fn)`; the trainer uses it to push the real-image
-        half onto the second stream while the generator is still producing the fake half."""
+        half onto the second stream while the generator is still producing the fake half; join() is then
+        called before the heads."""
         n = xd16.shape[0]
         self.start(xd16, keep_mask, mask_rows, attn)
         if parts is None:
             parts = [(0, n, lambda fn: fn())]
         for r0, r1, run in parts:
             run(lambda r0=r0, r1=r1: self.trunk_rows(r0, r1))
+        if join is not None:          # parts that ran on another stream: the heads below read every row
+            join()
         return self.heads()
 
     def start(self, xd16, keep_mask=None, mask_rows=(), attn=None):

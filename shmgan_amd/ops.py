@@ -23,6 +23,7 @@ class KernelTimer:
 
     def __init__(self):
         self.recs = []
+        self.brecs = []          # HBM-bound passes: (entry point, algorithmic bytes, start event, end event)
 
     def wrap(self, sym, flops, fn, label="", fixed=False):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -34,6 +35,25 @@ class KernelTimer:
             k = lib().shm_last_kernel()               # the variant the entry point actually dispatched to
             sym = (k.decode() if k else "?") + sym
         self.recs.append((sym, flops, e0, e1, label))
+
+    def wrap_bytes(self, name, nbytes, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.brecs.append((name, nbytes, e0, e1))
+
+    def bytes_summary(self):
+        """{entry point: dict(launches, ms, bytes)} of the HBM-bound passes (algorithmic bytes: every tensor the pass must read or
+        write, once) -- call after a device synchronize."""
+        out = {}
+        for name, nb, e0, e1 in self.brecs:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nb
+        return out
 
     def per_shape(self):
         """{(symbol, label): dict(launches, ms, flops)} for tuning."""
@@ -64,6 +84,13 @@ def _timed(sym, flops, fn, label=""):
         fn()
     else:
         TIMER.wrap(sym, flops, fn, label)
+
+
+def _timed_bytes(name, nbytes, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.wrap_bytes(name, nbytes, fn)
 
 
 def _p(t):
@@ -252,25 +279,37 @@ def in_stats(a, lda, stats, batch, hw, c, eps):
     check(lib().shm_in_stats(_p(a), lda, _p(stats), batch, hw, c, eps, _dt(a), _stream()), "shm_in_stats")
 
 
+def _tb(t, n_elems):
+    return float(n_elems) * t.element_size()
+
+
 def in_apply_pool(a, lda, stats, beta, out, ldo, pooled, ldp, batch, h, w, c):
-    check(lib().shm_in_apply_pool(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, _p(pooled), ldp, batch, h, w, c, _dt(a), _stream()),
-          "shm_in_apply_pool")
+    e = batch * h * w * c                          # read a, write out, write pooled (a quarter)
+    _timed_bytes("shm_in_apply_pool", _tb(a, 2.25 * e), lambda: check(
+        lib().shm_in_apply_pool(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, _p(pooled), ldp, batch, h, w, c, _dt(a), _stream()),
+        "shm_in_apply_pool"))
 
 
 def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
-    check(lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()),
-          "shm_in_apply")
+    _timed_bytes("shm_in_apply", _tb(a, 2 * batch * hw * c), lambda: check(
+        lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()), "shm_in_apply"))
 
 
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
-    check(lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
-                           batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd")
+    e = batch * h * w * c                          # reduce pass: g1 [+ g2 / 4], a; apply pass: the same + dz
+    nb = 2 * (_tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e)) + _tb(dz, e)
+    _timed_bytes("shm_in_bwd", nb, lambda: check(
+        lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
+                         batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd"))
 
 
 def in_bwd_apply(g1, ldg1, g2, ldg2, a, lda, stats, beta, red, redp, dstage, dz, lddz, dbias, batch, h, w, c, slope):
     """shm_in_bwd without its reduce pass: the sums come from the gsum epilogues of the launches that wrote g1 / g2."""
-    check(lib().shm_in_bwd_apply(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(beta), _p(red), _p(redp), _p(dstage), _p(dz), lddz,
-                                 _p(dbias), batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd_apply")
+    e = batch * h * w * c
+    nb = _tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e) + _tb(dz, e)
+    _timed_bytes("shm_in_bwd_apply", nb, lambda: check(
+        lib().shm_in_bwd_apply(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(beta), _p(red), _p(redp), _p(dstage), _p(dz), lddz,
+                               _p(dbias), batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd_apply"))
 
 
 LRELU_RED_SLOTS = 64        # SHM_LRELU_RED_SLOTS
@@ -409,8 +448,8 @@ def image_losses(gen_rgb, cyc_rgb, cyc_y, cbcr, orig_ptrs, ds_ptrs, flags_mask, 
 
 
 def adam_clip(w, m, v, g, n, alpha, beta1, beta2, eps, gscale):
-    check(lib().shm_adam_clip(_p(w), _p(m), _p(v), _p(g), n, alpha, beta1, beta2, eps, gscale, _stream()),
-          "shm_adam_clip")
+    _timed_bytes("shm_adam_clip", 7.0 * 4 * n, lambda: check(          # read w, m, v, g; write w, m, v
+        lib().shm_adam_clip(_p(w), _p(m), _p(v), _p(g), n, alpha, beta1, beta2, eps, gscale, _stream()), "shm_adam_clip"))
 
 
 # ---- SpecSeg (inference only) ----------------------------------------------------------------

@@ -126,6 +126,10 @@ class ShmGANwithSSpecSeg:
         # test diagnostics: called with no arguments between the last forward pass and the first backward kernel of a step
         # (tests/test_step_gpu.py pins LeakyReLU signs there; never set on the hot path)
         self.before_backward = None
+        # the two big forward passes (cyclic generator pass on 5B images, discriminator on 12B) run as two half batches on the two
+        # streams: samples are independent, and the halves hide each other's normalisation passes and launch tails (model.Generator.forward)
+        import os
+        self.forward_parts = int(os.environ.get("SHM_FORWARD_PARTS", "2"))
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
     # ------------------------------------------------------------------ workspace
@@ -337,7 +341,7 @@ class ShmGANwithSSpecSeg:
         # ---- G(2): cyclic  SHM.py:576-624
         cyc_in = A.get("cyc/in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, gen_Y, fmask, 1, cyc_in, B, npix)
-        cyc_Y = G.forward(cyc_in, "cyc", attn=attn_g)
+        cyc_Y = G.forward(cyc_in, "cyc", attn=attn_g, parts=self.forward_parts)
         cyc_rgb = A.get("cyc/rgb", (5 * B, S, S, 3))
         ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, xd[B:6 * B], 5 * B, B, npix)
         ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
@@ -345,7 +349,10 @@ class ShmGANwithSSpecSeg:
             ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
 
         # ---- D on all 12B images (noise + dropout on the D1 and D2 slices only)
-        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)], attn=attn_d)
+        dparts = None
+        if self.forward_parts > 1 and lane.stream is not None:     # fake half on the main stream, real half on the second one
+            dparts = [(6 * B, 12 * B, lane.submit), (0, 6 * B, lambda fn: fn())]
+        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)], parts=dparts, attn=attn_d, join=lane.join if dparts else None)
         np_ = (S // 32) ** 2
 
         # ---- losses  SHM.py:669-844
@@ -605,7 +612,7 @@ class ShmGANwithSSpecSeg:
         orig_Ych = gen_rgb[..., 0:1].contiguous()              # test.py:252
         cyc_in = A.get("inf/cyc_in", (5 * B, S, S, PAD_C), adt)
         ops.build_gen_input(ys, orig_Ych, 0b11111, 1, cyc_in, B, npix)      # view k zero, the others = orig_Ych
-        cyc_Y = G.forward(cyc_in, "inf5", attn=attn)
+        cyc_Y = G.forward(cyc_in, "inf5", attn=attn, parts=self.forward_parts)
         cyc_rgb = A.get("inf/cyc_rgb", (5 * B, S, S, 3))
         ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, None, 5 * B, B, npix)
         self.gen_input, self.gen_Y, self.gen_rgb = gen_in, gen_Y, gen_rgb
