@@ -50,6 +50,10 @@ class Arena:
             # return" by contract, so they start out zeroed
             alloc = torch.zeros if dtype == torch.float64 else torch.empty
             t = alloc(tuple(shape), dtype=dtype, device=self.device)
+            if dtype == torch.float64:
+                # the zero fill runs on whichever stream is current (a part of a two-stream forward allocates on the second
+                # stream) while slices of the buffer are about to be used on another one: wait for it once, at allocation
+                torch.cuda.current_stream(self.device).synchronize()
             self.t[key] = t
         return t
 
