@@ -19,8 +19,11 @@ import torch
 
 from . import ops
 
+import os
+
 LRELU = 0.2
 IN_EPS = 1e-6
+WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
 
 
@@ -530,14 +533,23 @@ class Generator(_ModelBase):
             self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
         cin_p = _padk(cin, self.pad)
         ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
-        self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
-                                                  self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
-        if self._on_wgrad is not None:
-            self._on_wgrad(li)
+
+        def wgrad():
+            self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
+                                                      self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
+            if self._on_wgrad is not None:
+                self._on_wgrad(li)
+        # WGRAD_AFTER_DGRAD: the weight gradient is released behind the layer's input gradient instead of beside it.  Both are MFMA
+        # bound -- side by side they only share the matrix pipes -- whereas the NEXT thing on the main stream is the InstanceNorm
+        # backward of the layer below, an HBM-bound pass that then runs under this weight gradient instead of alone
+        if not WGRAD_AFTER_DGRAD:
+            wgrad()
         if need_dx:
             lddx = rec["ldx"]
             ops.conv2d_dgrad(dz, cout, self.P.op_vars[2 * li], dx, dx2, n1, lddx, rec["ldx2"], n, h, w, cin, cout, k, 1,
                              gsum=gsum, gsum2=gsum2)
+        if WGRAD_AFTER_DGRAD:
+            wgrad()
         return dz
 
     def backward(self, dy, tag, need_dx=False, on_wgrad=None):
