@@ -98,6 +98,26 @@ class WgradLane:
             torch.cuda.current_stream().wait_event(ev)
 
 
+class _ConvTurns:
+    """Turn taking of two half-batch passes that run on two streams: before(p) makes part p's stream wait for the other part's
+    most recent convolution, after(p) marks part p's convolution.  The host issues the parts alternately, one convolution (and the
+    elementwise passes behind it) at a time, so an event is always recorded before the other part waits on it."""
+
+    def __init__(self, streams):
+        self.streams = streams
+        self.ev = [None, None]
+
+    def before(self, p):
+        ev = self.ev[1 - p]
+        if ev is not None:
+            self.streams[p].wait_event(ev)
+
+    def after(self, p):
+        ev = torch.cuda.Event()
+        ev.record(self.streams[p])
+        self.ev[p] = ev
+
+
 def generator_layers(f):
     """(keras_name, kind, k, cin, cout) in Keras creation order (Generator_summary.txt)."""
     return [
@@ -385,7 +405,7 @@ class Generator(_ModelBase):
         ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
 
     # -- forward --------------------------------------------------------------------------
-    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, r0, r1, part, pooled=None, apply=True):
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, r0, r1, part, pooled=None, apply=True, sync=None):
         """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization on the samples [r0, r1) of a batch of n.  x, x2, pooled are
         FULL-batch tensors (the record describes them: the backward pass runs on the whole batch); the launches take row views.
         Returns (ahat, record).  pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation.
@@ -400,8 +420,12 @@ class Generator(_ModelBase):
         st = stats[r0 * cout * 2:r1 * cout * 2]
         # zero-on-return scratch: one per concurrently running part
         scr = A.get(f"stats_scratch/{nb * cout}/p{part}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
+        if sync is not None:
+            sync.before(part)
         ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a[r0:r1], cout, nb, h, w,
                           cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
+        if sync is not None:
+            sync.after(part)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout)
         if not apply:
             return a, rec
@@ -415,25 +439,48 @@ class Generator(_ModelBase):
         """x16: [N,S,S,pad] (10 real channels, zero padded to the 64-byte pitch).  Returns gen_Y [N,S,S,1].
         attn: attention_forward()'s maps ([B,...], N a multiple of B: image i is a copy of sample i % B): added to the four
         skip tensors, `down_k + attn_k` (SHM.py:290-293); the pooled path keeps the un-augmented tensor.
-        parts = 2: the batch is evaluated as two halves, the second one on the second stream (samples are independent:
-        InstanceNorm is per sample, so this is exact).  A forward pass is a dependency chain conv -> statistics -> normalise ->
-        conv with nothing beside it: the normalisation passes of one half then run under the other half's convolutions and each
-        half fills the launch tails of the other (rocprofv3 timeline: 2 ms of a 121 ms fp32 step are normalisation passes with no
-        MFMA kernel running)."""
+        parts = 2 (experiment, not the trainer's default): the batch is evaluated as two halves, the second one on the second
+        stream, taking turns convolution by convolution (samples are independent: InstanceNorm is per sample, so this is exact).
+        A forward pass is a dependency chain conv -> statistics -> normalise -> conv with nothing beside it (rocprofv3 timeline:
+        2 ms of a 121 ms fp32 step are normalisation passes with no MFMA kernel running); the idea was to run one half's
+        normalisation pass under the other half's convolution.  Measured: +2 ms -- the halves' convolutions no longer overlap
+        and the half-size grids are less efficient than the hidden passes are long."""
         n, S = x16.shape[0], self.S
         assert tuple(x16.shape) == (n, S, S, self.pad) and x16.dtype == self.adt
         self.prepare_weights()
-        if parts > 1 and self.lane.stream is not None and n >= 2 * parts and (attn is None or (n // parts) % self._attn_B == 0):
-            cut = n // parts
-            bounds = [(p * cut, n if p == parts - 1 else (p + 1) * cut) for p in range(parts)]
-            for p in range(1, parts):
-                self.lane.submit(lambda p=p: self._forward_rows(x16, tag, attn, bounds[p][0], bounds[p][1], p))
-            y = self._forward_rows(x16, tag, attn, bounds[0][0], bounds[0][1], 0)
+        if parts == 2 and self.lane.stream is not None and n >= 4 and (attn is None or (n // 2) % self._attn_B == 0):
+            # two half batches, ALTERNATING: a half launches its next convolution only when the other half's previous one has
+            # finished (events), so the halves do not fall into lockstep (conv beside conv, normalisation beside normalisation):
+            # half A's normalisation pass runs under half B's convolution and vice versa
+            cut = n // 2
+            main, second = torch.cuda.current_stream(), self.lane.stream
+            start = torch.cuda.Event()
+            start.record(main)
+            second.wait_event(start)
+            sync = _ConvTurns((main, second))
+            gens = [self._forward_rows(x16, tag, attn, 0, cut, 0, sync), self._forward_rows(x16, tag, attn, cut, n, 1, sync)]
+            live = [True, True]
+            y = None
+            while live[0] or live[1]:
+                for p in (0, 1):
+                    if live[p]:
+                        with torch.cuda.stream(sync.streams[p]):
+                            try:
+                                next(gens[p])
+                            except StopIteration as e:
+                                live[p] = False
+                                y = e.value if p == 0 else y
             self.lane.join()
             return y
-        return self._forward_rows(x16, tag, attn, 0, n, 0)
+        gen = self._forward_rows(x16, tag, attn, 0, n, 0, None)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as e:
+                return e.value
 
-    def _forward_rows(self, x16, tag, attn, r0, r1, part):
+    def _forward_rows(self, x16, tag, attn, r0, r1, part, sync):
+        """Generator: one step = one convolution of the samples [r0, r1) with the elementwise passes behind it."""
         n, S, F = x16.shape[0], self.S, self.F
         nb = r1 - r0
         A = self.arena
@@ -446,9 +493,10 @@ class Generator(_ModelBase):
             for j in range(2):
                 if j == 1:            # the level's second block: its normalisation pass also writes the pooled tensor
                     pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, self.layers[li][4]), self.adt)
-                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, pooled=pooled)
+                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, pooled=pooled, sync=sync)
                 r["pooled"] = pooled
                 recs.append(r)
+                yield
                 ld = self.layers[li][4]
                 li += 1
                 bi += 1
@@ -460,31 +508,39 @@ class Generator(_ModelBase):
                 downs.append((cur, ld, h))
             cur, h = pooled, h // 2
         for _ in range(2):                       # the two 1x1 blocks
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part)
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, sync=sync)
             recs.append(r)
             li += 1
             bi += 1
+            yield
         ups = []
         for lvl in range(4):
             _, _, _, cin, cout = self.layers[li]
             u = A.get(f"{tag}/u{lvl}", (n, 2 * h, 2 * h, cout), self.adt)
+            if sync is not None:
+                sync.before(part)
             ops.conv2d_transpose_fwd(cur[r0:r1], ld, self.P.op_vars[2 * li], self.P.vars[2 * li + 1], u[r0:r1], cout, nb, h, h, cin,
                                      cout, LRELU)
+            if sync is not None:
+                sync.after(part)
+            yield
             ups.append(dict(li=li, x=cur, ldx=ld, u=u, h=h))
             li += 1
             h *= 2
             skip, sld, sh = downs[3 - lvl]
             assert sh == h
-            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h, r0, r1, part)   # concat [u, skip]
+            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h, r0, r1, part, sync=sync)   # concat [u, skip]
             recs.append(r)
             ld = self.layers[li][4]
             li += 1
             bi += 1
+            yield
             # the last block's InstanceNorm is applied by the head kernels (forward and backward) on the fly
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, apply=lvl < 3)
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, apply=lvl < 3, sync=sync)
             recs.append(r)
             li += 1
             bi += 1
+            yield
         y = A.get(f"{tag}/y", (n, S, S, 1))
         ops.head_in_fwd(cur[r0:r1], ld, r["stats"][r0 * ld * 2:r1 * ld * 2], self.betas[r["bi"]], self.P.vars[2 * li], self.P.vars[2 * li + 1], y[r0:r1],
                         nb, S * S, ld, LRELU)

@@ -126,10 +126,12 @@ class ShmGANwithSSpecSeg:
         # test diagnostics: called with no arguments between the last forward pass and the first backward kernel of a step
         # (tests/test_step_gpu.py pins LeakyReLU signs there; never set on the hot path)
         self.before_backward = None
-        # the two big forward passes (cyclic generator pass on 5B images, discriminator on 12B) run as two half batches on the two
-        # streams: samples are independent, and the halves hide each other's normalisation passes and launch tails (model.Generator.forward)
+        # SHM_FORWARD_PARTS=2: the two big forward passes (cyclic generator pass on 5B images, discriminator on 12B) as two half
+        # batches on the two streams (samples are independent).  Measured in round 3 and NOT the default: in lockstep the halves
+        # gain 0.2 ms of a 121 ms fp32 step (within noise), taking turns convolution by convolution (so that one half's normalisation
+        # pass runs under the other's convolution) LOSES 2 ms -- a single stream already fills the launch tails
         import os
-        self.forward_parts = int(os.environ.get("SHM_FORWARD_PARTS", "2"))
+        self.forward_parts = int(os.environ.get("SHM_FORWARD_PARTS", "1"))
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
     # ------------------------------------------------------------------ workspace
