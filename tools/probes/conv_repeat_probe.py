@@ -2,7 +2,7 @@
 python tools/conv_repeat_probe.py [--dt bf16|f32] [--variants a,b] n,h,cin,cout ..."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 from shmgan_amd import ops
 

@@ -1,8 +1,8 @@
 """Per-tensor gradient agreement of the bf16 step with the float64 oracle (diagnostics)."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent / "tests"))
 import numpy as np
 import torch
 from oracle import step_torch as st

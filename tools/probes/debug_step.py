@@ -1,8 +1,8 @@
 """Diagnostic: per-stage error of one train_step against the float64 oracle (GPU box)."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent / "tests"))
 import numpy as np, torch
 from oracle import step_torch as st
 from util import rel_l2, host, cosine

@@ -3,7 +3,7 @@ with a recognisable value (the caching allocator then hands those blocks to the 
 gradient tensors differ.  python tools/poison_probe.py [S] [dtype]"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from oracle import step_torch as st
 from shmgan_amd import ShmGANwithSSpecSeg

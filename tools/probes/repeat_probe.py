@@ -3,7 +3,7 @@ tensor / named loss whose value differs from the first repetition by more than t
 python tools/repeat_probe.py [S] [B] [dtype] [reps]"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from oracle import step_torch as st
 from shmgan_amd import ShmGANwithSSpecSeg

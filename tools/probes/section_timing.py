@@ -1,7 +1,7 @@
 """Where does a train_step spend its time?  Event markers between the sections of the step."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from shmgan_amd import ShmGANwithSSpecSeg, ops
 import shmgan_amd.trainer as T

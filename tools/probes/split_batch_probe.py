@@ -3,7 +3,7 @@
 import sys
 import time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 from shmgan_amd import ShmGANwithSSpecSeg
 
