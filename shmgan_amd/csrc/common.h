@@ -37,7 +37,7 @@ int shm_tune(int id);
 // wave must not enter that barrier with fragment reads of the stage still queued: the MFMAs that consume them are register-only
 // instructions which hipcc is free to sink below the barrier (it does, with the nine taps unrolled), taking the implicit
 // s_waitcnt lgkmcnt with them -- and with the LDS pipe saturated (bf16) a queued ds_read can then be overtaken by the DMA write
-// of another wave (tools/conv_repeat_probe.py: one 16-byte weight chunk stale in 1 of 30 launches).  Hence the explicit wait; a
+// of another wave (tools/probes/conv_repeat_probe.py: one 16-byte weight chunk stale in 1 of 30 launches).  Hence the explicit wait; a
 // __syncthreads() would also drain vmcnt, i.e. the DMA pipeline.
 #define SHM_LDS_BARRIER()                                       \
     do {                                                        \

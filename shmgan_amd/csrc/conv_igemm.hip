@@ -164,7 +164,7 @@ __device__ __forceinline__ void tap_mfma(const f32x4 (&av)[TM], const f32x4 (&bv
 // 16*l of the destination), so rows are unpadded; bank conflicts of the ds_read_b128 fragment
 // reads are removed by an XOR swizzle applied on the SOURCE side: LDS chunk q of row r holds
 // channel chunk q ^ ((r >> 2) & 3).  Out-of-image taps / tail rows use byte offset 0xffffffff:
-// the descriptor's range check makes the DMA write zeros (tools/ldsdma_probe.hip).
+// the descriptor's range check makes the DMA write zeros (tools/probes/ldsdma_probe.hip).
 // Three LDS stages; the DMA of step s+2 is issued right after the barrier of step s, waits are
 // counted (s_waitcnt vmcnt(N)), barriers are raw s_barrier (a __syncthreads would drain vmcnt).
 // T = float or bf16_t.  BK counts 4-byte words per LDS row (16 -> 64-byte rows); a K step covers
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 // with the partner pinned to the epilogue nobody fills those bubbles.)  LDS rows are 64 bytes as in the other kernels (DMA
 // source-side swizzle, 0xffffffff offsets -> zeros for halo pixels outside the image); the chunk swizzle is
 // ((R >> 1) + R / 18) & 3 on the halo row R, which makes every 16-lane group of the fragment reads hit 16 distinct 16-byte
-// bank units for all nine taps (brute-force check: tools/halo_swizzle_check.py).  Its address arithmetic is patch independent
+// bank units for all nine taps (brute-force check: tools/probes/halo_swizzle_check.py).  Its address arithmetic is patch independent
 // here, so unlike in tapgemm_halo_kernel it costs nothing per tap.
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) for bf16 outputs.
 template <typename TO, int NCH, bool GS = false>
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // Outputs are stored straight from the accumulators (lane = channel: 64-byte segments, four pixel rows per instruction);
 // InstanceNorm sums are carried in registers (f64) across the patches of an image.  LDS rows are 64 bytes (16 channels) with
 // the DMA source-side swizzle chunk' = (chunk + (R >> 1)) & 3 on the halo row R: conflict free for this instruction's lane
-// groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/halo_swizzle_check.py).
+// groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/probes/halo_swizzle_check.py).
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs): S2 carries sum(v * aux) instead of sum(v * v).
 template <int NCH, int WN = 4, bool TWO = false, bool GS = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {

@@ -329,7 +329,7 @@ def test_train_step_bf16_vs_oracle(S, F_, B, step, gdt):
     tests/test_step_gpu.py): bf16 rounding of the forward moves ~1 % of the pre-activations across zero,
     where the derivative jumps 5x.  Against the un-pinned oracle the same run gives per-tensor cosines of
     0.88-0.99 (S=64; 0.90-0.997 at S=128) -- a property of evaluating the network in bf16, not of these
-    kernels: pinned, every tensor is >= 0.996 (tools/debug_bf16.py).  gdt="float32" = SHM_BF16_GF32."""
+    kernels: pinned, every tensor is >= 0.996 (tools/probes/debug_bf16.py).  gdt="float32" = SHM_BF16_GF32."""
     m, (g, d, gb, db) = _mk(S, F_, B, gdt)
     inp = st.make_inputs(B, S)
     dr = st.make_draws(step, B, S, F_)

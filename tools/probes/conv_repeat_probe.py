@@ -1,5 +1,5 @@
 """Bitwise run-to-run reproducibility of one convolution entry point under a forced tap-GEMM variant.
-python tools/conv_repeat_probe.py [--dt bf16|f32] [--variants a,b] n,h,cin,cout ..."""
+python tools/probes/conv_repeat_probe.py [--dt bf16|f32] [--variants a,b] n,h,cin,cout ..."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))

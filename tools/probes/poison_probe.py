@@ -1,6 +1,6 @@
 """Does a result depend on what the allocator's blocks held before?  Runs the same step on fresh memory and after filling 20 GB
 with a recognisable value (the caching allocator then hands those blocks to the next model's arena) and reports which outputs /
-gradient tensors differ.  python tools/poison_probe.py [S] [dtype]"""
+gradient tensors differ.  python tools/probes/poison_probe.py [S] [dtype]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))

@@ -1,6 +1,6 @@
 """Run-to-run reproducibility of one train_step (apply=False) on fixed inputs: repeats the step and reports every gradient
 tensor / named loss whose value differs from the first repetition by more than the f64-atomics bound.
-python tools/repeat_probe.py [S] [B] [dtype] [reps]"""
+python tools/probes/repeat_probe.py [S] [B] [dtype] [reps]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
