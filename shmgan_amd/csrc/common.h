@@ -29,6 +29,7 @@ enum ShmTune {
     SHM_TUNE_STATS_FUSION,            // 1 = InstanceNorm statistics in the conv epilogue (default), 0 = separate pass
     SHM_TUNE_ELEM_REVERSE,            // 1 = in_apply / in_bwd_reduce walk the tensor back to front (Infinity-Cache reuse), 0 = front to back
     SHM_TUNE_ELEM_REDUCE_BLOCKS,      // block target of the InstanceNorm-backward reduce pass
+    SHM_TUNE_ELEM_NT,                 // 1 = the InstanceNorm-backward apply pass reads its (dead afterwards) gradient tensor with non-temporal loads
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);
@@ -56,6 +57,19 @@ __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
     r[1] = __uint_as_float(u.x & 0xffff0000u);
     r[2] = __uint_as_float(u.y << 16);
     r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+// the same for data that is dead after this read (a gradient signal consumed by its only reader): non-temporal, so that the
+// stream does not displace tensors the next kernels re-read from L2 / Infinity Cache
+__device__ __forceinline__ f32x4 ld4nt(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
+__device__ __forceinline__ f32x4 ld4nt(const bf16_t* p) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t u = __builtin_nontemporal_load((const u32x2_t*)p);
+    f32x4 r;
+    r[0] = __uint_as_float(u[0] << 16);
+    r[1] = __uint_as_float(u[0] & 0xffff0000u);
+    r[2] = __uint_as_float(u[1] << 16);
+    r[3] = __uint_as_float(u[1] & 0xffff0000u);
     return r;
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }

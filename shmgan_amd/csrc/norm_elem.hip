@@ -50,6 +50,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"stats.fusion", "SHM_STATS_FUSION", 1, 0, 1},
     {"elem.reverse", "SHM_ELEM_REVERSE", 1, 0, 1},
     {"elem.reduce_blocks", "SHM_ELEM_REDUCE_BLOCKS", 0, 0, 1 << 20},
+    {"elem.nt_loads", "SHM_ELEM_NT", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -428,6 +429,7 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     const float* beta;
     double* dstage;
     int gslots;
+    int nt;                      // apply pass: g1 is read for the last time -> non-temporal loads
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -439,7 +441,8 @@ __device__ __forceinline__ f32x4 in_bwd_dout(const InBwdArgs& k, int n, int p, i
         const float d = k.r1_dz[(size_t)n * k.h * k.w + p];
         return wv * d;
     }
-    f32x4 g = ld4((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
+    f32x4 g = k.nt ? ld4nt((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4)
+                   : ld4((const TG*)k.g1 + ((size_t)n * k.h * k.w + p) * k.ldg1 + cl * 4);
     if constexpr (G2) {
         int y = p / k.w, x = p - y * k.w;
         size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
@@ -838,6 +841,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     // block in both dtypes: bf16 step 27.8 -> 27.1 ms, fp32 123.4 -> 122.9.  (The apply pass, one atomic per channel and block, is faster with
     // its 4096 blocks: same grid for both measured +0.15 / +0.6 ms.)
     InBwdArgs kr = k;
+    k.nt = shm_tune(SHM_TUNE_ELEM_NT);          // the apply pass is the last reader of g1
     const int rb = shm_tune(SHM_TUNE_ELEM_REDUCE_BLOCKS);
     kr.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
     dim3 gridr(shm_cdiv(hw, kr.chunk), batch);
@@ -903,7 +907,8 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
     SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "%s: pooled gradient needs even h,w", who);
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
-    InBwdArgs k{g1, g2, a, stats, nullptr, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, 0, nullptr, nullptr, red, redp, beta, dstage, SHM_GSUM_SLOTS};
+    InBwdArgs k{g1, g2, a, stats, nullptr, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, 0, nullptr, nullptr, red, redp, beta, dstage, SHM_GSUM_SLOTS,
+                shm_tune(SHM_TUNE_ELEM_NT)};
     const int hw = h * w;
     k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c));
     const dim3 grid(shm_cdiv(hw, k.chunk), batch);
