@@ -123,3 +123,17 @@ def test_every_pipeline_barrier_waits_for_its_lds_reads():
     i = common.index("#define SHM_LDS_BARRIER()")
     body = common[i:i + 400]
     assert body.index("s_waitcnt lgkmcnt(0)") < body.index("__builtin_amdgcn_s_barrier()")
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_the_launcher():
+    """bench.py --gpus N is the contract the driver computes scaling from: with WORLD_SIZE != N it must not print a line at all
+    (round 2 printed n_gpus: 1 for `--gpus 8` launched as plain python).  The check runs before anything touches the GPU."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE=1" in r.stderr
