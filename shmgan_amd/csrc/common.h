@@ -30,6 +30,7 @@ enum ShmTune {
     SHM_TUNE_ELEM_REVERSE,            // 1 = in_apply / in_bwd_reduce walk the tensor back to front (Infinity-Cache reuse), 0 = front to back
     SHM_TUNE_ELEM_REDUCE_BLOCKS,      // block target of the InstanceNorm-backward reduce pass
     SHM_TUNE_ELEM_NT,                 // 1 = the InstanceNorm-backward apply pass reads its (dead afterwards) gradient tensor with non-temporal loads
+    SHM_TUNE_ELEM_CHUNK_MB,           // shm_in_bwd: reduce + apply per chunk of samples whose tensors fit this many MiB (0 = the whole batch at once)
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);

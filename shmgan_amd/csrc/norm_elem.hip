@@ -51,6 +51,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.reverse", "SHM_ELEM_REVERSE", 1, 0, 1},
     {"elem.reduce_blocks", "SHM_ELEM_REDUCE_BLOCKS", 0, 0, 1 << 20},
     {"elem.nt_loads", "SHM_ELEM_NT", 0, 0, 1},
+    {"elem.chunk_mb", "SHM_ELEM_CHUNK_MB", 0, 0, 1 << 20},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -430,6 +431,7 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     double* dstage;
     int gslots;
     int nt;                      // apply pass: g1 is read for the last time -> non-temporal loads
+    int n0, nbatch;              // sample chunking (in_bwd_impl): this launch covers samples [n0, n0 + gridDim.y) of nbatch
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const InBwdArgs k) {
     if constexpr (R1) {
         if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
     }
-    const int n = k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, hw = k.h * k.w;
+    const int n = k.n0 + (k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y), hw = k.h * k.w;
     const int bx = k.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int p0 = bx * k.chunk, p1 = min(hw, p0 + k.chunk);
     double v[2][4] = {};
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
     const int lanes_c = k.c >> 3, PP = 256 / lanes_c;
     const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
     const bool active = pp < PP;
-    const int n = k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, hw = k.h * k.w;
+    const int n = k.n0 + (k.rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y), hw = k.h * k.w;
     const int bx = k.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int p0 = bx * k.chunk, p1 = min(hw, p0 + k.chunk);
     double v[2][8] = {};
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     if constexpr (R1) {
         if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
     }
-    const int n = blockIdx.y, hw = k.h * k.w;
+    const int n = k.n0 + blockIdx.y, hw = k.h * k.w;
     const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
     // RAW: the two means of every channel, formed ONCE per block from the slot copies (thread ch sums channel ch's slots: with every
     // thread summing the slots of its own four channels the pass spent a third of its time re-reading 64 doubles per thread)
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     if constexpr (RAW) {
         for (int ch = threadIdx.x; ch < k.c; ch += 256) {
             const size_t i = ((size_t)n * k.c + ch) * 2;
-            const size_t sstride = (size_t)gridDim.y * k.c * 2;
+            const size_t sstride = (size_t)k.nbatch * k.c * 2;
             double sg = 0.0, sga = 0.0, pg = 0.0, pgx = 0.0;
             for (int sl = 0; sl < k.gslots; ++sl) {
                 sg += k.gred[sl * sstride + i];
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     }
     // bias gradient: staged per sample in red[2*batch*c + n*c + ch] -- one f64 atomic address per (n, ch)
     // instead of per ch (4096 blocks on 64 addresses cost 90-210 us per launch), folded by dbias_fold_kernel
-    if (k.dbias) block_reduce_atomic<1>(v, pm, (RAW ? k.dstage : k.red + (size_t)gridDim.y * k.c * 2) + (size_t)n * k.c, k.c, true);
+    if (k.dbias) block_reduce_atomic<1>(v, pm, (RAW ? k.dstage : k.red + (size_t)k.nbatch * k.c * 2) + (size_t)n * k.c, k.c, true);
 }
 
 // shm_in_bwd_apply's last launch: fold the staged bias gradient (dbias[ch] += sum over samples) and clear the gsum slot copies the
@@ -831,47 +833,61 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     hipStream_t st = (hipStream_t)stream;
     // `red` is zero on entry by contract and zero again on return (no memset in front of every launch)
     InBwdArgs k{g1, g2, a, stats, red, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, shm_tune(SHM_TUNE_ELEM_REVERSE), r1_dz, r1_w};
-    int hw = h * w;
-    int nch = pix_chunks(hw, batch, c);
-    k.chunk = shm_cdiv(hw, nch);
-    dim3 grid(shm_cdiv(hw, k.chunk), batch);
-    // The reduce pass ends every block with an LDS combine and 2c f64 atomics onto the 2c addresses of its sample: with the
-    // streaming pass's ~4096 blocks a sample's address takes up to 256 serialized adds (n = 8, 256 x 256: 125 us for a pass whose
-    // data moves in 40) and the 512-channel maps issue 1.3 M atomics per launch.  Fewer, longer blocks -- about the same bytes per
-    // block in both dtypes: bf16 step 27.8 -> 27.1 ms, fp32 123.4 -> 122.9.  (The apply pass, one atomic per channel and block, is faster with
-    // its 4096 blocks: same grid for both measured +0.15 / +0.6 ms.)
+    const int hw = h * w;
+    k.nbatch = batch;
     InBwdArgs kr = k;
     k.nt = shm_tune(SHM_TUNE_ELEM_NT);          // the apply pass is the last reader of g1
     const int rb = shm_tune(SHM_TUNE_ELEM_REDUCE_BLOCKS);
-    kr.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
-    dim3 gridr(shm_cdiv(hw, kr.chunk), batch);
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
                        (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
-    if (wide8) {
-        if (r1) {
-            hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false, true>), gridr, dim3(256), 0, st, kr);
-        } else if (dtype == SHM_BF16) {
-            if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, true>), gridr, dim3(256), 0, st, kr);
-            else hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, false>), gridr, dim3(256), 0, st, kr);
-        } else {
-            if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, true>), gridr, dim3(256), 0, st, kr);
-            else hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false>), gridr, dim3(256), 0, st, kr);
-        }
-    } else if (r1) {
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false, true>), gridr, dim3(256), 0, st, kr));
-    } else if (g2) {
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), gridr, dim3(256), 0, st, kr));
-    } else {
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false>), gridr, dim3(256), 0, st, kr));
+    // Sample chunks ("elem.chunk_mb", round 3): the apply pass re-reads what the reduce pass read.  On tensors larger than the 256 MiB
+    // Infinity Cache that second read comes from HBM again (the back-to-front / front-to-back walk only saves the turning point);
+    // run as reduce(chunk), apply(chunk) over chunks whose g + a fit the cache, the second read stays on die.  0 = one chunk.
+    const int esz_a = dtype == SHM_F32 ? 4 : 2, esz_g = dtype == SHM_BF16 ? 2 : 4;
+    const size_t per_sample = (size_t)hw * c * (esz_a + (r1 ? 0 : esz_g)) + (g2 ? (size_t)hw / 4 * c * esz_g : 0);
+    const size_t chunk_bytes = (size_t)shm_tune(SHM_TUNE_ELEM_CHUNK_MB) << 20;
+    int per_chunk = batch;
+    if (chunk_bytes && per_sample * batch > chunk_bytes) {
+        per_chunk = (int)(chunk_bytes / per_sample);
+        if (per_chunk < 1) per_chunk = 1;
     }
-    SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
-    if (r1)
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false, true>), grid, dim3(256), 0, st, k));
-    else if (g2)
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
-    else
-        SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+    for (int n0 = 0; n0 < batch; n0 += per_chunk) {
+        const int nb = min(per_chunk, batch - n0);
+        k.n0 = kr.n0 = n0;
+        // The reduce pass ends every block with an LDS combine and 2c f64 atomics onto the 2c addresses of its sample: with the
+        // streaming pass's ~4096 blocks a sample's address takes up to 256 serialized adds (n = 8, 256 x 256: 125 us for a pass whose
+        // data moves in 40) and the 512-channel maps issue 1.3 M atomics per launch.  Fewer, longer blocks -- about the same bytes per
+        // block in both dtypes: bf16 step 27.8 -> 27.1 ms, fp32 123.4 -> 122.9.  (The apply pass, one atomic per channel and block, is faster with
+        // its 4096 blocks: same grid for both measured +0.15 / +0.6 ms.)
+        k.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c));
+        kr.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
+        const dim3 grid(shm_cdiv(hw, k.chunk), nb), gridr(shm_cdiv(hw, kr.chunk), nb);
+        if (wide8) {
+            if (r1) {
+                hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false, true>), gridr, dim3(256), 0, st, kr);
+            } else if (dtype == SHM_BF16) {
+                if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, true>), gridr, dim3(256), 0, st, kr);
+                else hipLaunchKernelGGL((in_bwd_reduce8_kernel<bf16_t, false>), gridr, dim3(256), 0, st, kr);
+            } else {
+                if (g2) hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, true>), gridr, dim3(256), 0, st, kr);
+                else hipLaunchKernelGGL((in_bwd_reduce8_kernel<float, false>), gridr, dim3(256), 0, st, kr);
+            }
+        } else if (r1) {
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false, true>), gridr, dim3(256), 0, st, kr));
+        } else if (g2) {
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, true>), gridr, dim3(256), 0, st, kr));
+        } else {
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_reduce_kernel<T, TG, false>), gridr, dim3(256), 0, st, kr));
+        }
+        SHM_LAUNCH_CHECK("shm_in_bwd(reduce)");
+        if (r1)
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false, true>), grid, dim3(256), 0, st, k));
+        else if (g2)
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true>), grid, dim3(256), 0, st, k));
+        else
+            SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
+    }
     const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
     SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(apply)", red, red_bytes, st);
     if (dbias) {
@@ -908,7 +924,7 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
     if (batch == 0 || h * w == 0) return SHM_OK;
     hipStream_t st = (hipStream_t)stream;
     InBwdArgs k{g1, g2, a, stats, nullptr, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, 0, nullptr, nullptr, red, redp, beta, dstage, SHM_GSUM_SLOTS,
-                shm_tune(SHM_TUNE_ELEM_NT)};
+                shm_tune(SHM_TUNE_ELEM_NT), 0, batch};
     const int hw = h * w;
     k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c));
     const dim3 grid(shm_cdiv(hw, k.chunk), batch);
