@@ -174,6 +174,42 @@ int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, c
                      int cout, int ksize, int stride, int accumulate, void* workspace,
                      size_t ws_bytes, int dtype, void* stream);
 
+/* ---- The fused block: InstanceNormalization applied by the CONSUMER (SHM.py:244-245 "Conv -> LeakyReLU -> IN", north-star
+ * "IN apply folded into the consumer's load") ------------------------------------------------------------------------
+ * A Conv -> LeakyReLU -> InstanceNorm block stores its un-normalised activation a and its statistics; instead of a pass that reads a
+ * and writes the normalised tensor (shm_in_apply: 2x the activation's bytes), the convolution and the weight gradient that consume
+ * the block's output read a itself and apply (a - mean) * inv + beta to their operand tile in LDS -- the kernels that stage the A
+ * operand as a halo image (unit-stride 3x3 layers on maps that are multiples of 16; *_norm_supported says whether a shape runs on
+ * one).  Out-of-image taps stay zero (zero padding of the NORMALISED tensor) and the arithmetic is shm_in_apply's, so results
+ * are bit-identical to shm_in_apply followed by the plain entry point.
+ *   nt = float [batch][3][c]: per sample the planes mean[c], inv[c], beta[c] of the producing block (c = its channel count = the
+ *   channel count of the source it describes), written by shm_conv2d_in_fwd_norm(nt_out, beta_out) or shm_in_norm_table.
+ *   nt_x / nt_x2: table of source x / x2, or NULL = that source is used as stored; at most one of the two. */
+int shm_in_norm_table(const double* stats, const float* beta, float* nt, int batch, int c, void* stream);
+/* shm_conv2d_in_fwd with (a) sources normalised on the fly and (b) optionally this block's own table as a by-product of the
+ * statistics finalisation (nt_out [batch][3][cout] with beta_out [cout]; NULL = not wanted).  With nt_x == nt_x2 == NULL it is
+ * shm_conv2d_in_fwd.  SHM_E_SHAPE if the kernel chosen for the shape cannot normalise in LDS (never a silent fallback). */
+int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
+                           const void* wk, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin, int cout,
+                           int ksize, int stride, float slope, double* stats, double* scratch, float eps, float* nt_out,
+                           const float* beta_out, int dtype, void* stream);
+/* 1 if shm_conv2d_in_fwd_norm would take a normalised source `norm_part` (0 = x, 1 = x2; c1 = channels of x when there are two
+ * sources, else 0) for this shape, batch and the current tuning knobs; 0 otherwise.  Launches nothing. */
+int shm_conv2d_norm_supported(int batch, int hi, int wi, int cin, int c1, int cout, int ksize, int stride, int norm_part, int dtype);
+/* shm_conv2d_wgrad on sources normalised on the fly, and its query. */
+int shm_conv2d_wgrad_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
+                          const void* dy, int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize,
+                          int stride, int accumulate, void* workspace, size_t ws_bytes, int dtype, void* stream);
+int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
+                                  const void* dy, int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize,
+                                  int stride, void* workspace, size_t ws_bytes, int dtype, int* nsplit_out, void* stream);
+int shm_conv2d_wgrad_norm_supported(int batch, int hi, int wi, int cin, int cin_ld, int c1, int cout, int ksize, int stride,
+                                    int norm_part, int dtype);
+/* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers
+ * normalise a on the fly, only the pool's consumer needs a tensor.  Same bits as shm_in_apply_pool's `pooled`. */
+int shm_in_pool(const void* a, int lda, const double* stats, const float* beta, void* pooled, int ldp, int batch, int h, int w,
+                int c, int dtype, void* stream);
+
 /* ---- InstanceNormalization (tfa, axis=-1, eps, gamma==1, constant beta) -----------
  * SHM.py:245...:388; op chain Generator_summary.txt:9-36.
  * stats = f64 [batch*c*2]; on return (stream order) stats[(n*c+ch)*2] = mean over H*W,

@@ -44,6 +44,13 @@ SIGNATURES = {
     "shm_in_stats": (I, [P, I, P, I, I, I, F, I, P]),
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "shm_in_apply_pool": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "shm_in_norm_table": (I, [P, P, P, I, I, P]),
+    "shm_conv2d_in_fwd_norm": (I, [P, P, I, I, I, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, P, F, P, P, I, P]),
+    "shm_conv2d_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I]),
+    "shm_conv2d_wgrad_norm": (I, [P, P, I, I, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
+    "shm_conv2d_wgrad_partial_norm": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, I, P, Z, I, P, P]),
+    "shm_conv2d_wgrad_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I, I]),
+    "shm_in_pool": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
     "shm_conv2d_dgrad_gsum": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "shm_conv2d_fwd_gsum": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, F, P, I, P, I, P]),

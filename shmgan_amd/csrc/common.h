@@ -163,6 +163,13 @@ static inline void shm_same_pad(int in, int k, int s, int* out, int* before) {
 
 __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// InstanceNormalization apply, (x - mean) * inv + beta, in ONE spelling for the stand-alone pass (shm_in_apply) and for the
+// consumers that normalise their operand tile in LDS ("fused block", shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm): a
+// subtraction and one fused multiply-add, so that both give the same bits.
+__device__ __forceinline__ float shm_in_norm(float x, float mean, float inv, float beta) { return __builtin_fmaf(x - mean, inv, beta); }
+// A block's normalisation table for such consumers: float [batch][3][c] = per sample the planes (mean, inv, beta[c]).
+#define SHM_NT_MAXC 256           // normalised channels a folding consumer keeps in LDS
+
 // wave64 sum via DPP-free shuffles
 __device__ __forceinline__ double shm_wave_sum(double v) {
 #pragma unroll

@@ -61,6 +61,11 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
     int ldgaux[2];
     double* gred[2];
     int gslots, gbatch;
+    // "norm" (shm_conv2d_in_fwd_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation of an InstanceNorm block;
+    // the kernel applies shm_in_norm to that part of the operand tile in LDS, from nt = float [batch][3][ntc] (mean, inv, beta)
+    const float* nt;
+    int ntpart, ntc;
+    unsigned ntbytes;
     TapPhase ph[4];
 };
 
@@ -568,9 +573,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // six fragment reads per eight MFMAs instead of four per four, twice the MFMAs per barrier: the bf16 form, whose K step is 8x shorter).
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) -- an instantiation of its own, so that the forward kernels
 // carry none of its code or registers.
-template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2, bool GS = false>
+// NM: "norm" -- one source is the UN-normalised activation of an InstanceNorm block (TapGemmArgs::nt): every wave applies
+// shm_in_norm to the halo items it DMA'd itself, in LDS, once they have landed and before the barrier that opens the chunk -- the
+// stand-alone normalisation pass (a read and a write of the whole activation) is gone, for 3 ds_read_b128 + 4 fma + 1 ds_write_b128 per
+// 1 KiB item and 2304 (fp32) MFMAs.  Out-of-image halo pixels were DMA'd as zeros and are left alone: zero padding of the
+// NORMALISED tensor, as the layer defines it.  The (mean, inv, beta) planes of the block's image sit in LDS (3 x ntc floats).
+template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2, bool GS = false, bool NM = false>
 __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
     static_assert(TM == 2 || (TM == 4 && ST), "four M tiles per wave: static-tap form only");
+    static_assert(!NM || (ST && TM == 2 && !GS), "norm: static-tap forward form");
     constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;      // channels per 16-byte chunk / per 64-byte row
     constexpr int WGM = PH / (2 * TM), WGN = BN / 64, NW = WGM * WGN;   // waves: PH / (2 TM) (M) x (BN/64) (N)
     constexpr int HC = 18, NIT = PH == 16 ? 24 : 12;  // halo (PH+2) x 18 rows, padded to NIT DMA items of 16 rows
@@ -579,6 +590,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     constexpr int NA = NIT / NW, NB = (BN / 16) / NW; // DMA instructions per wave: A per chunk, B per tap
     static_assert(NIT % NW == 0 && (BN / 16) % NW == 0, "DMA items divide over the waves");
     __shared__ __attribute__((aligned(1024))) float smem[2 * ASTG + 3 * BSTG];
+    __shared__ __attribute__((aligned(1024))) float snt[NM ? 3 * SHM_NT_MAXC : 4];
     float* const sA = smem;
     float* const sB = smem + 2 * ASTG;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -597,6 +609,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+NW, ...
     const int drow = lane >> 2, dq = lane & 3;
     unsigned arow1[NA], arow2[NA];
+    [[maybe_unused]] int nmv[NA];          // NM: first channel (within its 64-byte row) of the lane's 16 bytes of item j, -1 = not an image pixel
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int hrow = 16 * (wave + NW * j) + drow;
@@ -607,6 +620,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         const int coff = (dq ^ (ST ? ((hrow >> 1) + hr) & 3 : (hrow >> 2) & 3)) * CHE;
         arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * (unsigned)ESZ : 0xffffffffu;
         arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * (unsigned)ESZ : 0xffffffffu;
+        nmv[j] = v ? coff : -1;
     }
     unsigned wrow[NB];
 #pragma unroll
@@ -709,10 +723,61 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         }
     };
 
-    // ---- pipeline.  DMA issue order per wave: A(0); B(0); B(1); then at step s: [A(chunk+1) if tap == 0]; B(s+2).
+    // NM: normalise this wave's own items of the A stage of `chunk` in place (they have landed: the caller waited)
+    [[maybe_unused]] auto norm_a = [&](int chunk) {
+        const int c0 = chunk * BKE;
+        const bool second = c0 >= a.c1;
+        if ((int)second != a.ntpart) return;                      // block-uniform: this chunk's source is used as stored
+        const float* tb0 = snt + (second ? c0 - a.c1 : c0);
+        float* dst = sA + (chunk & 1) * ASTG + wave * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            if (nmv[j] >= 0) {
+                const float* tb = tb0 + nmv[j];
+                float* p = dst + j * NW * 256;
+                if constexpr (ESZ == 4) {
+                    f32x4 x = *(const f32x4*)p;
+                    const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], mean[e], inv[e], beta[e]);
+                    *(f32x4*)p = x;
+                } else {
+                    u32x4 x = *(const u32x4*)p;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const f32x4 mean = *(const f32x4*)(tb + 4 * hf), inv = *(const f32x4*)(tb + a.ntc + 4 * hf),
+                                    beta = *(const f32x4*)(tb + 2 * a.ntc + 4 * hf);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const unsigned u = x[2 * hf + e];
+                            const bf16_t lo = (bf16_t)shm_in_norm(__uint_as_float(u << 16), mean[2 * e], inv[2 * e], beta[2 * e]);
+                            const bf16_t hi = (bf16_t)shm_in_norm(__uint_as_float(u & 0xffff0000u), mean[2 * e + 1], inv[2 * e + 1], beta[2 * e + 1]);
+                            x[2 * hf + e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                        }
+                    }
+                    *(u32x4*)p = x;
+                }
+            }
+        }
+    };
+
+    // ---- pipeline.  DMA issue order per wave: [NM: table piece]; A(0); B(0); B(1); then at step s: [A(chunk+1) if tap == 0]; B(s+2).
+    if constexpr (NM) {
+        // the (mean, inv, beta) planes of this block's image, 3 x ntc floats, in 1 KiB pieces (reads past the table give zeros)
+        const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, a.ntbytes, 0x00020000);
+        if (wave < 3)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)(snt + wave * 256), 16,
+                                                     (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)wave * 1024u + (unsigned)lane * 16u), 0, 0, 0);
+    }
     dma_a(0);
     dma_b();
     if (ksteps > 1) dma_b();
+    if constexpr (NM) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");        // table piece and A(0) of this wave
+        SHM_LDS_BARRIER();                                                    // ... the table pieces of every wave
+        asm volatile("" ::: "memory");
+        norm_a(0);
+    }
     if constexpr (ST) {
         // fragment addresses of the nine taps (floats, relative to the A stage): registers for the whole block
         // (tile i sits 2 i patch rows = 36 i halo rows further on: (R >> 1) + R / 18 grows by 20 i, the swizzle does not change, and
@@ -766,6 +831,13 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                         asm volatile("" :: "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
                 }
                 asm volatile("" ::: "memory");
+                // NM: A(chunk + 1) was issued at tap 0 in front of B(2), which this step's wait covered: the wave's own items have
+                // landed; the other waves read them after the barriers of taps 3..8 and of the next chunk's tap 0
+                if constexpr (NM)
+                    if (tap == 2 && chunk + 1 < nch) {
+                        norm_a(chunk + 1);
+                        asm volatile("" ::: "memory");
+                    }
             }
         }
     } else {
@@ -1025,15 +1097,17 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 // bank units for all nine taps (brute-force check: tools/probes/halo_swizzle_check.py).  Its address arithmetic is patch independent
 // here, so unlike in tapgemm_halo_kernel it costs nothing per tap.
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) for bf16 outputs.
-template <typename TO, int NCH, bool GS = false>
+// NM: "norm" (see tapgemm_halo_kernel / tapgemm_wreg_f32_kernel).
+template <typename TO, int NCH, bool GS = false, bool NM = false>
 __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs a, const int npatch) {
     typedef bf16_t T;
     static_assert(!GS || sizeof(TO) == 2, "the gsum epilogue of this kernel is the LDS-staged bf16 one");
+    static_assert(!NM || !GS, "norm: forward form");
     constexpr int PH = 8, HC = 18, NIT = 12;            // halo (PH + 2) x 18 = 180 rows, padded to 12 DMA items of 16 rows
     constexpr int ASTG = NIT * 256;                     // floats per 32-channel chunk
     constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
     static_assert(NIT * NCH % 4 == 0, "DMA items divide over the four waves");
-    __shared__ __attribute__((aligned(1024))) float smem[2 * ABUF + 4 * 1024];       // + 4 KB store staging per wave
+    __shared__ __attribute__((aligned(1024))) float smem[2 * ABUF + 4 * 1024 + (NM ? 4 * 256 : 0)];       // + 4 KB store staging per wave (+ NM: 1 KB table)
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const TapPhase& P = a.ph[0];
@@ -1074,10 +1148,14 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     static_assert(NIT == 12, "three DMA items per wave and chunk");
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const unsigned pixb = (unsigned)a.ldx * 2u;
+    float* const tbl = smem + 2 * ABUF + 4 * 1024 + wave * 256;     // NM: this wave's copy of the planes of the image of the halo in flight
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, NM ? a.ntbytes : 0u, 0x00020000);
     auto dma = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF + wave * 256;
+        if constexpr (NM)              // 3 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
         int dr = drow;
         asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
 #pragma unroll
@@ -1091,6 +1169,43 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             for (int c = 0; c < NCH; ++c)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + c * ASTG + j * 4 * 256), 16,
                                                          (int)(v ? off + 64u * c : 0xffffffffu), 0, 0, 0);
+        }
+    };
+
+    // NM: normalise this wave's items of halo(q) in buffer buf (landed: the caller waited)
+    [[maybe_unused]] auto norm_a = [&](int q, int buf) {
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        float* dst = smem + buf * ABUF + wave * 256 + lane * 4;
+        int dr = drow;
+        asm volatile("" : "+v"(dr));        // as in dma(): nothing of this is kept across the MFMA loop
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int hrow = 16 * (wave + 4 * j) + dr;
+            const int hr = hrow / HC, hc = hrow - hr * HC;
+            const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+            if (hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+                const int g8 = (dq ^ (((hrow >> 1) + hr) & 3)) << 3;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float* tb = tbl + c * 32 + g8;
+                    float* p = dst + c * ASTG + j * 4 * 256;
+                    u32x4 x = *(const u32x4*)p;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const f32x4 mean = *(const f32x4*)(tb + 4 * hf), inv = *(const f32x4*)(tb + a.ntc + 4 * hf),
+                                    beta = *(const f32x4*)(tb + 2 * a.ntc + 4 * hf);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const unsigned u = x[2 * hf + e];
+                            const bf16_t lo = (bf16_t)shm_in_norm(__uint_as_float(u << 16), mean[2 * e], inv[2 * e], beta[2 * e]);
+                            const bf16_t hi = (bf16_t)shm_in_norm(__uint_as_float(u & 0xffff0000u), mean[2 * e + 1], inv[2 * e + 1], beta[2 * e + 1]);
+                            x[2 * hf + e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                        }
+                    }
+                    *(u32x4*)p = x;
+                }
+            }
         }
     };
 
@@ -1127,6 +1242,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     // (Starting the block in the odd HW wave slot of its SIMDs half a patch late, to put the two blocks of a CU in anti-phase,
     // was measured with delays of 1300-5800 clocks: no effect.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NM) norm_a(q0, 0);
     for (int q = q0; q < q1; ++q) {
         const int buf = (q - q0) & 1;
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave (each waited for its own part at the end
@@ -1328,6 +1444,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NM)
+            if (q + 1 < q1) norm_a(q + 1, buf ^ 1);
     }
     if (a.stats) flush(simg);
 }
@@ -1346,8 +1464,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // the DMA source-side swizzle chunk' = (chunk + (R >> 1)) & 3 on the halo row R: conflict free for this instruction's lane
 // groups (pixel = lane & 15, chunk = lane >> 4) over all nine taps (tools/probes/halo_swizzle_check.py).
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs): S2 carries sum(v * aux) instead of sum(v * v).
-template <int NCH, int WN = 4, bool TWO = false, bool GS = false>
+// NM: "norm" (see tapgemm_halo_kernel) -- the source is the un-normalised activation of an InstanceNorm block; a wave normalises
+// the halo items it DMA'd itself at the end of the patch in front (they have landed by then), from its own 1 KiB copy of the
+// image's (mean, inv, beta) planes, which travels with the halo DMA.
+template <int NCH, int WN = 4, bool TWO = false, bool GS = false, bool NM = false>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
+    static_assert(!NM || (!TWO && !GS), "norm: one source, forward form");
     // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
     // patches of 8 / 16 / 32 rows -- the narrow forms serve SpecSeg's 16- and 32-channel layers without idle N waves
     constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, NIT = ((PH + 2) * HC + 15) / 16;     // halo (PH + 2) x 18 rows in DMA items of 16 rows
@@ -1389,10 +1511,14 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     const unsigned pixb = (unsigned)a.ldx * 4u, pixb2 = (unsigned)a.ldx2 * 4u;
     const int nc1 = a.c1 >> 4;                           // TWO: chunks [0, nc1) come from x, the rest from x2 (Concatenate)
+    float* const tbl = smem + 2 * ABUF + wave * 256;     // NM: this wave's copy of the planes of the image of the halo in flight
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, NM ? a.ntbytes : 0u, 0x00020000);
     auto dma = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF;
+        if constexpr (NM)              // 3 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int it = wave + 8 * j;                 // wave-uniform
@@ -1411,6 +1537,34 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 } else {
                     const unsigned off = v ? pix * pixb2 + (unsigned)((c - nc1) * 64) + sw : 0xffffffffu;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // NM: normalise this wave's items of halo(q) in buffer buf (landed: the caller waited)
+    [[maybe_unused]] auto norm_a = [&](int q, int buf) {
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));        // recompute the lane's coordinates per call: hoisted out of the patch loop they would stay live across the MFMAs
+        const int drow = ln >> 2, dq = ln & 3;
+        float* dst = smem + buf * ABUF + ln * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int it = wave + 8 * j;
+            if (it < NITEM) {
+                const int c = it / NIT, ri = it - c * NIT;
+                const int hrow = 16 * ri + drow;
+                const int hr = hrow / HC, hc = hrow - hr * HC;
+                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+                if (hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+                    const float* tb = tbl + c * 16 + (((dq - (hrow >> 1)) & 3) << 2);
+                    f32x4 x = *(const f32x4*)(dst + it * 256);
+                    const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], mean[e], inv[e], beta[e]);
+                    *(f32x4*)(dst + it * 256) = x;
                 }
             }
         }
@@ -1457,6 +1611,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
 
     dma(q0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NM) norm_a(q0, 0);
     for (int q = q0; q < q1; ++q) {
         const int buf = (q - q0) & 1;
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave; everyone is done with the other buffer
@@ -1539,6 +1694,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush; the gsum
         // form's aux loads were issued right behind the halo and have been consumed: loads return in order)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (NM)
+            if (q + 1 < q1) norm_a(q + 1, buf ^ 1);
     }
     if (GS || a.stats) flush(simg);
 }
@@ -1778,6 +1935,15 @@ struct GsumReq {
 static thread_local GsumReq g_gsum = {};
 static thread_local bool g_gsum_fused = false;
 
+// norm request of shm_conv2d_in_fwd_norm around its launch (TapGemmArgs::nt); query = shm_conv2d_norm_supported's dry run: the
+// launcher goes through its variant choice, records whether that kernel can normalise its source in LDS, and launches nothing
+struct NormReq {
+    const float* nt;
+    int part, c;
+    bool query, query_ok;
+};
+static thread_local NormReq g_norm = {};
+
 // Variant choice.  `forced` (shm_set_tuning("tapgemm.variant", SHM_TG_*)) overrides the automatic choice; a forced
 // variant the shape is not eligible for is an error (SHM_E_SHAPE), so a parity test that forces a variant knows it ran.
 template <typename T, typename TO>
@@ -1907,6 +2073,33 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         if (!gs_fused) a.gred[0] = a.gred[1] = nullptr;
     }
     g_gsum_fused = gs_fused;
+    // norm: the kernels that stage the A operand as a halo image in LDS (static-tap halo blocks, weights-in-registers kernels) can
+    // normalise it there; the part's channels must fit the LDS table and be whole 64-byte rows
+    const bool want_nm = a.nt != nullptr;
+    if (want_nm) {
+        const int pc = a.ntpart ? a.K - a.c1 : a.c1;
+        bool ok = !want_gs && nphase == 1 && a.ntc == pc && pc % BKE == 0 && pc <= SHM_NT_MAXC && (a.ntpart == 0 || a.x2 != nullptr);
+        switch (v) {
+        case SHM_TG_HALO128_ST: case SHM_TG_HALO64_ST:
+            ok = ok && halo_ok && sizeof(TO) == sizeof(T);
+            break;
+        case SHM_TG_WREG:           // one source; its planes travel as one 1 KiB DMA piece per wave
+            ok = ok && a.ntpart == 0 && pc <= 64 && ((wreg_ok && sizeof(TO) == 2) || (wreg32_ok && wreg32_wn == 4 && a.x2 == nullptr));
+            break;
+        default:
+            ok = false;
+        }
+        if (g_norm.query) {
+            g_norm.query_ok = ok;
+            return SHM_OK;
+        }
+        SHM_REQUIRE(ok, SHM_E_SHAPE,
+                    "%s: the kernel this shape runs on (tapgemm variant %d) cannot normalise its source in LDS (unit-stride 3x3 on a map that is a "
+                    "multiple of 16, normalised part of at most %d channels; ask shm_conv2d_norm_supported) -- use shm_in_apply", who, v, SHM_NT_MAXC);
+    } else if (g_norm.query) {
+        g_norm.query_ok = false;
+        return SHM_OK;
+    }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     const int npatch = batch * (a.hi / 16) * (a.wi / 16);
     switch (v) {
@@ -1924,9 +2117,13 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         if (gs_fused)
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
-        else
+        else if (want_nm) {
+            if constexpr (sizeof(T) == sizeof(TO))
+                hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, false, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+        } else
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
-        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, true>" : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
+        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, true>"
+                            : want_nm ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, false, true>" : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_ST_W4:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps/4 waves needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
@@ -1937,9 +2134,13 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo64/static-taps needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
         if (gs_fused)
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
-        else
+        else if (want_nm) {
+            if constexpr (sizeof(T) == sizeof(TO))
+                hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, false, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+        } else
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
-        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, true>" : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
+        shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, true>"
+                            : want_nm ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, false, true>" : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_PH8:
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
@@ -1982,12 +2183,19 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
                 else if (gs_fused)
                     hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             }
-            if (gs_fused) {
+            if constexpr (sizeof(TO) == 2) {
+                if (want_nm && a.K == 64)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2, false, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                else if (want_nm)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, false, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+            }
+            if (gs_fused || want_nm) {
             } else if (a.K == 64)
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             else
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
-            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>" : "tapgemm_wreg_kernel<%s, %d>", ton, a.K / 32);
+            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>" : want_nm ? "tapgemm_wreg_kernel<%s, %d, false, true>" : "tapgemm_wreg_kernel<%s, %d>",
+                                ton, a.K / 32);
         } else if constexpr (sizeof(TO) == 4) {
             // one 8-wave block per CU; patches of 8 (64 channels per block), 16 (32) or 32 (16) rows
             const int ph = 32 / wreg32_wn, npw = batch * (a.hi / ph) * (a.wi / 16), nyw = a.nout / (16 * wreg32_wn);
@@ -1995,7 +2203,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
             if (gx < 1) gx = 1;
             if (gx > npw) gx = npw;
             const int nch = a.K / 16;
-            const unsigned lds = 2u * (unsigned)nch * (unsigned)(((ph + 2) * 18 + 15) / 16) * 1024u;      // two halo buffers
+            const unsigned lds = 2u * (unsigned)nch * (unsigned)(((ph + 2) * 18 + 15) / 16) * 1024u + (want_nm ? 8u * 1024u : 0u);      // two halo buffers (+ norm: 1 KiB of planes per wave)
             hipError_t attr = hipSuccess;
 #define SHM_WREG32_LAUNCH2(NCH_, WN_, TWO_)                                                                                              \
     do {                                                                                                                                 \
@@ -2015,7 +2223,18 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         if (attr == hipSuccess)                                                                                                          \
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);           \
     } while (0)
-            if (gs_fused && nch == 4) SHM_WREG32_LAUNCH_GS(4);
+#define SHM_WREG32_LAUNCH_NM(NCH_)                                                                                                       \
+    do {                                                                                                                                 \
+        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, false, true>,             \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * 12 * 1024 + 8 * 1024);  \
+        attr = at_;                                                                                                                      \
+        if (attr == hipSuccess)                                                                                                          \
+            hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);    \
+    } while (0)
+            if (want_nm && nch == 4) SHM_WREG32_LAUNCH_NM(4);
+            else if (want_nm && nch == 2) SHM_WREG32_LAUNCH_NM(2);
+            else if (want_nm) SHM_WREG32_LAUNCH_NM(1);
+            else if (gs_fused && nch == 4) SHM_WREG32_LAUNCH_GS(4);
             else if (gs_fused && nch == 2) SHM_WREG32_LAUNCH_GS(2);
             else if (gs_fused) SHM_WREG32_LAUNCH_GS(1);
             else if (wreg32_wn == 4 && nch == 4) SHM_WREG32_LAUNCH(4, 4);
@@ -2029,8 +2248,10 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
 #undef SHM_WREG32_LAUNCH2
 #undef SHM_WREG32_LAUNCH
 #undef SHM_WREG32_LAUNCH_GS
+#undef SHM_WREG32_LAUNCH_NM
             SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, lds, hipGetErrorString(attr));
-            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_f32_kernel<%d, %d, %s, true>" : "tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn,
+            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_f32_kernel<%d, %d, %s, true>"
+                                : want_nm ? "tapgemm_wreg_f32_kernel<%d, %d, %s, false, true>" : "tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn,
                                 a.x2 ? "true" : "false");
         }
         break;
@@ -2088,6 +2309,10 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
     }
     a.gslots = SHM_GSUM_SLOTS;
     a.gbatch = batch;
+    a.nt = g_norm.nt;
+    a.ntpart = g_norm.part;
+    a.ntc = g_norm.c;
+    a.ntbytes = (unsigned)((size_t)batch * 3 * g_norm.c * sizeof(float));
     g_gsum_fused = false;
     if (a.gred[0] || a.gred[1]) {
         SHM_REQUIRE(a.stats == nullptr, SHM_E_SHAPE, "%s: fused forward statistics and gsum are exclusive", who);
@@ -2127,6 +2352,7 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
     else
         rc = launch_tapgemm_t<float, float>(a, batch, nphase, st, who);
     if (rc) return rc;
+    if (g_norm.query) return SHM_OK;
     SHM_LAUNCH_CHECK(who);
     return SHM_OK;
 }
@@ -2275,21 +2501,66 @@ extern "C" int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, in
     return launch_tapgemm(a, batch, 1, dtype, (hipStream_t)stream, "shm_conv2d_fwd");
 }
 
-int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, hipStream_t st);
+int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, float* nt, const float* beta, int c, hipStream_t st);
 
 extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                                  const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                                  int cout, int ksize, int stride, float slope, double* stats, double* scratch,
                                  float eps, int dtype, void* stream) {
+    return shm_conv2d_in_fwd_norm(x, x2, c1, ldx, ldx2, nullptr, nullptr, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, scratch,
+                                  eps, nullptr, nullptr, dtype, stream);
+}
+
+// Does the kernel that shm_conv2d_in_fwd_norm would run for this shape normalise its source in LDS?  A dry run of the launcher's
+// variant choice (which depends on the shape, the batch and the tuning knobs): nothing is launched.
+extern "C" int shm_conv2d_norm_supported(int batch, int hi, int wi, int cin, int c1, int cout, int ksize, int stride, int norm_part, int dtype) {
+    if (dtype != SHM_F32 && dtype != SHM_BF16) return 0;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || batch <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (norm_part != 0 && norm_part != 1) return 0;
+    const bool two = c1 > 0 && c1 < cin;
+    if (norm_part == 1 && !two) return 0;
+    // operands are never dereferenced in a dry run; any aligned non-null address serves
+    static const __attribute__((aligned(256))) char dummy[256] = {};
+    const void* px = dummy;
+    g_norm.nt = (const float*)dummy;
+    g_norm.part = norm_part;
+    g_norm.c = two ? (norm_part ? cin - c1 : c1) : cin;
+    g_norm.query = true;
+    g_norm.query_ok = false;
+    const int r = shm_conv2d_fwd(px, two ? px : nullptr, two ? c1 : 0, two ? c1 : cin, two ? cin - c1 : 0, px, nullptr, (void*)dummy, cout, batch, hi, wi, cin, cout,
+                                 ksize, stride, 0.2f, dtype, nullptr);
+    const bool ok = r == SHM_OK && g_norm.query_ok;
+    g_norm = NormReq{};
+    return ok ? 1 : 0;
+}
+
+extern "C" int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* wk,
+                                      const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin, int cout, int ksize, int stride, float slope,
+                                      double* stats, double* scratch, float eps, float* nt_out, const float* beta_out, int dtype, void* stream) {
     SHM_REQUIRE(stats, SHM_E_SHAPE, "shm_conv2d_in_fwd: null stats");
+    SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: at most one source can be normalised on the fly");
+    SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: nt_x2 without a second source");
+    SHM_REQUIRE(!nt_out || beta_out, SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: nt_out needs beta_out");
     int ho, wo, pt;
     shm_same_pad(hi, ksize, stride, &ho, &pt);
     shm_same_pad(wi, ksize, stride, &wo, &pt);
     const int hw = ho * wo;
+    const bool norm_in = nt_x || nt_x2;
+    struct NormScope {             // the request lives for the conv launch of this call only
+        ~NormScope() { g_norm = NormReq{}; }
+    } norm_scope;
+    if (norm_in) {
+        g_norm.nt = nt_x ? nt_x : nt_x2;
+        g_norm.part = nt_x ? 0 : 1;
+        g_norm.c = x2 ? (nt_x ? c1 : cin - c1) : cin;
+    }
     if (!shm_tune(SHM_TUNE_STATS_FUSION) || hw % 64 != 0) {       // tiny maps: separate statistics pass
         int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
+        g_norm = NormReq{};
         if (r) return r;
-        return shm_in_stats(y, ldy, stats, batch, hw, cout, eps, dtype, stream);
+        r = shm_in_stats(y, ldy, stats, batch, hw, cout, eps, dtype, stream);
+        if (r == SHM_OK && nt_out) r = shm_in_norm_table(stats, beta_out, nt_out, batch, cout, stream);
+        return r;
     }
     // Every wave tile of a sample adds its column sums with f64 atomics: on one copy that is hw/64 atomics
     // per address, a serial chain worth ~100 us at 256x256 whatever the batch (measured, bf16 and fp32).
@@ -2306,7 +2577,8 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
     r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);
     g_conv_stats = nullptr;
     g_conv_slots = 1;
-    if (r == SHM_OK) r = shm_in_finalize_internal(stats, scratch, slots, batch * cout, hw, (double)eps, (hipStream_t)stream);
+    g_norm = NormReq{};
+    if (r == SHM_OK) r = shm_in_finalize_internal(stats, scratch, slots, batch * cout, hw, (double)eps, nt_out, beta_out, cout, (hipStream_t)stream);
     // "zero on entry, zero on return" also on the error path: a failed launch must not leave sums behind
     if (r != SHM_OK && scratch) (void)hipMemsetAsync(scratch, 0, (size_t)SHM_STATS_SLOTS * batch * cout * 2 * sizeof(double), (hipStream_t)stream);
     return r;

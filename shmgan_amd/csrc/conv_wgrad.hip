@@ -464,8 +464,26 @@ struct WgradHaloArgs {
     int h, w, cin_ld, cin, cout;
     int npatch, patches_per_split;
     unsigned xbytes, x2bytes, dybytes;
+    // "norm" (shm_conv2d_wgrad_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation of an InstanceNorm block; the
+    // kernels apply shm_in_norm to its halo pixels in LDS, from nt = float [batch][3][ntc] (mean, inv, beta): see tapgemm_halo_kernel
+    const float* nt;
+    int ntpart, ntc;
 };
 
+// A 16-byte global load the COMPILER does not see as a vector-memory operation (inline asm, drained on the spot).  The table
+// registers of the NM kernels are re-read when a block moves on to the next image, i.e. under a branch: as plain loads hipcc has
+// to assume them outstanding at every later use and puts s_waitcnt vmcnt(0) in front of each normalisation -- which also waits
+// for the LDS-DMA of the stage just issued, in the middle of the MFMA stream (measured: +6-10 % on the kernel).
+__device__ __forceinline__ f32x4 load16_drained(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// NM: a wave normalises the halo items it DMA'd itself, one stage ahead of their use.  A lane's four channels are the same for
+// every item and patch (no swizzle in this image), so their (mean, inv, beta) live in registers and are re-read when the image
+// changes (at most a few times per block).
+template <bool NM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs a) {
     constexpr int PW = 16, HC = PW + 2;                 // patch 2 x 16, halo 4 x 18
     constexpr int NHP = 4 * HC, NPX = 2 * PW;           // 72 halo pixels, 32 output pixels
@@ -549,6 +567,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
         }
     };
 
+    // NM: coordinates of the next stage to normalise (they run one stage behind dma()'s), the lane's table entries and their image
+    const bool nm_on = NM && a.nt != nullptr && (int)second == a.ntpart;        // block-uniform
+    [[maybe_unused]] int n2 = n, pr2 = pr, pc2 = pc, nimg = -1;
+    [[maybe_unused]] f32x4 nmean = {0.f, 0.f, 0.f, 0.f}, ninv = nmean, nbeta = nmean;
+    // One straight-line piece per stage (interior patches: no per-lane tests).
+    [[maybe_unused]] auto norm_x = [&](int stage) {
+        if (n2 != nimg) {                                   // block-uniform
+            nimg = n2;
+            if (xvalid) {
+                const float* t = a.nt + (size_t)n2 * 3 * a.ntc + ccX;
+                nmean = load16_drained(t);
+                ninv = load16_drained(t + a.ntc);
+                nbeta = load16_drained(t + 2 * a.ntc);
+            }
+        }
+        float* sx = smem + stage * STAGE + lane * 4;
+        // interior patch (the whole 4 x 18 halo inside the image) of a full 64-channel tile: every lane of every item normalises, no
+        // per-lane tests -- block-uniform, 7 of 8 patches of a 256 x 256 map
+        if (pr2 > 0 && pr2 + 2 < a.h && pc2 > 0 && pc2 + PW < a.w && ci0 + 64 <= a.cin_ld) {
+            f32x4 x[5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = *(const f32x4*)(sx + (wave + 4 * j) * 256);
+            if (wave < 2) x[4] = *(const f32x4*)(sx + (wave + 16) * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[j][e] = shm_in_norm(x[j][e], nmean[e], ninv[e], nbeta[e]);
+                *(f32x4*)(sx + (wave + 4 * j) * 256) = x[j];
+            }
+            if (wave < 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[4][e] = shm_in_norm(x[4][e], nmean[e], ninv[e], nbeta[e]);
+                *(f32x4*)(sx + (wave + 16) * 256) = x[4];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int item = wave + 4 * j;
+                if (item < 18) {
+                    const int iy = pr2 - 1 + hr[j], ix = pc2 - 1 + hc[j];
+                    if (xvalid && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w) {
+                        f32x4 x = *(const f32x4*)(sx + item * 256);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], nmean[e], ninv[e], nbeta[e]);
+                        *(f32x4*)(sx + item * 256) = x;
+                    }
+                }
+            }
+        }
+        pc2 += PW;
+        if (pc2 == a.w) {
+            pc2 = 0;
+            pr2 += 2;
+            if (pr2 == a.h) {
+                pr2 = 0;
+                ++n2;
+            }
+        }
+    };
+
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -572,19 +650,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
         }
     };
 
+    // wait until this wave's DMA items of every stage but the youngest one in flight have landed
+    auto wait_older = [&](bool younger_in_flight) {
+        if (younger_in_flight) {
+            if (wave < 2)
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
     if (nstages > 0) {
         dma(0);
         if (nstages > 1) dma(1);
+        if constexpr (NM)
+            if (nm_on) {
+                wait_older(nstages > 1);
+                norm_x(0);
+            }
         int cur = 0, nxt2 = 2;
         for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {
-                if (wave < 2)
-                    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            wait_older(s + 1 < nstages);
             SHM_LDS_BARRIER();
             asm volatile("" ::: "memory");
             if (s + 2 < nstages) dma(nxt2);
@@ -592,6 +679,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
             asm volatile("" ::: "memory");
             cur = (cur == NST - 1) ? 0 : cur + 1;
             nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+            // NM: stage s + 1 (issued before the stage in flight): every wave normalises its own items of it behind this stage's last
+            // MFMA (issued, not finished: they and the partner block's keep the matrix pipe busy); the barrier of step s + 1 publishes
+            // them.  The MFMA loop itself stays the plain kernel's: with the normalisation inside it (one piece at K step 8, or an
+            // item per K step) the loop falls into basic blocks -- 47-63 s_waitcnt instead of 20, +5-7 % on the kernel even for
+            // blocks that normalise nothing.
+            if constexpr (NM)
+                if (nm_on && s + 1 < nstages) {
+                    wait_older(s + 2 < nstages);
+                    norm_x(cur);
+                    asm volatile("" ::: "memory");
+                }
         }
     }
 
@@ -765,7 +863,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
 // R = pixel rows per stage (2 or 4).  The x fragment of tap row kh at K step (pixel row) q is the fragment of tap row 0 at
 // q + kh, so a stage of R rows needs (R + 2) x 3 fragment reads for 9 R MFMAs (hipcc keeps the shared ones in registers):
 // R = 4 reads 22 fragments per 36 MFMAs where two R = 2 stages read 28, with half the barriers and 3/4 of the halo bytes.
-template <int R>
+// NM: as in wgrad_halo_kernel (a lane's eight channels are the same for every item and patch: 24 table registers).
+template <int R, bool NM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
     constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
     constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows (14 KiB); R = 4: 120 + 64 (23 KiB)
@@ -850,6 +949,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         }
     };
 
+    const bool nm_on = NM && a.nt != nullptr && (int)second == a.ntpart;        // block-uniform
+    [[maybe_unused]] int n2 = n, pr2 = pr, pc2 = pc, nimg = -1;
+    [[maybe_unused]] f32x4 nmean[2] = {}, ninv[2] = {}, nbeta[2] = {};
+    [[maybe_unused]] auto norm_x = [&](int stage) {
+        if (n2 != nimg) {                                   // block-uniform
+            nimg = n2;
+            if (xvalid) {
+                const float* t = a.nt + (size_t)n2 * 3 * a.ntc + ccX;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    nmean[hf] = load16_drained(t + 4 * hf);
+                    ninv[hf] = load16_drained(t + a.ntc + 4 * hf);
+                    nbeta[hf] = load16_drained(t + 2 * a.ntc + 4 * hf);
+                }
+            }
+        }
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        unsigned short* sx = smem + stage * STAGE + lane * 8;
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int item = wave + 4 * j;
+            if (item < NXI) {
+                const int iy = pr2 - 1 + hr[j], ix = pc2 - 1 + hc[j];
+                if (xvalid && hc[j] < PW + 2 && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w) {
+                    u32x4_t x = *(const u32x4_t*)(sx + item * 512);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const unsigned u = x[2 * hf + e];
+                            const bf16_t lo = (bf16_t)shm_in_norm(__uint_as_float(u << 16), nmean[hf][2 * e], ninv[hf][2 * e], nbeta[hf][2 * e]);
+                            const bf16_t hi = (bf16_t)shm_in_norm(__uint_as_float(u & 0xffff0000u), nmean[hf][2 * e + 1], ninv[hf][2 * e + 1], nbeta[hf][2 * e + 1]);
+                            x[2 * hf + e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                        }
+                    *(u32x4_t*)(sx + item * 512) = x;
+                }
+            }
+        }
+        pc2 += PW;
+        if (pc2 == a.w) {
+            pc2 = 0;
+            pr2 += R;
+            if (pr2 == a.h) {
+                pr2 = 0;
+                ++n2;
+            }
+        }
+    };
+
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -882,19 +1030,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         }
     };
 
+    // wait until this wave's DMA items of every stage but the youngest one in flight (NJ or NJ - 1 instructions) have landed
+    auto wait_older = [&](bool younger_in_flight) {
+        if (younger_in_flight) {
+            if (NIT % 4 == 0 || wave < NIT % 4)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
     if (nstages > 0) {
         dma(0);
         if (nstages > 1) dma(1);
+        if constexpr (NM)
+            if (nm_on) {
+                wait_older(nstages > 1);
+                norm_x(0);
+            }
         int cur = 0, nxt2 = 2;
         for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {                 // one younger stage in flight: NJ or NJ - 1 DMA instructions of this wave
-                if (NIT % 4 == 0 || wave < NIT % 4)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ - 1) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            wait_older(s + 1 < nstages);
             SHM_LDS_BARRIER();
             asm volatile("" ::: "memory");
             if (s + 2 < nstages) dma(nxt2);
@@ -902,6 +1059,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
             asm volatile("" ::: "memory");
             cur = (cur == NST - 1) ? 0 : cur + 1;
             nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+            // NM: see wgrad_halo_kernel
+            if constexpr (NM)
+                if (nm_on && s + 1 < nstages) {
+                    wait_older(s + 2 < nstages);
+                    norm_x(cur);
+                    asm volatile("" ::: "memory");
+                }
         }
     }
 
@@ -989,6 +1153,14 @@ extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin,
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
 
+// norm request of shm_conv2d_wgrad_norm around its launch (WgradHaloArgs::nt); query = shm_conv2d_wgrad_norm_supported's dry run
+struct WNormReq {
+    const float* nt;
+    int part, c;
+    bool query, query_ok;
+};
+static thread_local WNormReq g_wnorm = {};
+
 // Phase 1 of shm_conv2d_wgrad: the MFMA kernel; *nsplit_out receives the number of partial slabs written.
 extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,
                                         int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout,
@@ -1056,6 +1228,19 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     // thin first layers: (tap, ci) pairs packed into the MFMA rows; patches of 2 x 16 OUTPUT pixels
     const bool thin_ok = !no_thin && !no_halo && ksize == 3 && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16 && wo % 16 == 0 && ho % 2 == 0 &&
                          hi % stride == 0 && wi % stride == 0;
+    // norm: the halo-image kernels normalise their x halo in LDS (a block's 64 input channels lie in one source: no straddle)
+    const bool want_nm = g_wnorm.nt != nullptr;
+    if (want_nm || g_wnorm.query) {
+        const int pc = x2 ? (g_wnorm.part ? cin_ld - c1 : c1) : cin_ld;
+        const bool ok = want_nm && halo_ok && (dtype == SHM_BF16 || !thin_ok) && g_wnorm.c == pc && (g_wnorm.part == 0 || x2 != nullptr) && pc % vec == 0;
+        if (g_wnorm.query) {
+            g_wnorm.query_ok = ok;
+            return SHM_OK;
+        }
+        SHM_REQUIRE(ok, SHM_E_SHAPE,
+                    "shm_conv2d_wgrad_norm: the kernel this shape runs on cannot normalise its source in LDS (unit-stride 3x3, map width a multiple of "
+                    "16, concat split a multiple of 64; ask shm_conv2d_wgrad_norm_supported) -- use shm_in_apply");
+    }
     if (dtype == SHM_BF16 && halo_ok) {
         WgradHaloArgs hgs{};
         hgs.x = x;
@@ -1079,16 +1264,26 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.xbytes = a.xbytes;
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
+        hgs.nt = g_wnorm.nt;
+        hgs.ntpart = g_wnorm.part;
+        hgs.ntc = g_wnorm.c;
         ns = nsh;
         if (rows == 4) {
             constexpr unsigned kLds = 3u * (6 * 20 + 4 * 16) * 128u;      // 69 KiB
             static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-            SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s", hipGetErrorString(attr));
-            hipLaunchKernelGGL(wgrad_halo_bf16_kernel<4>, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
+            static const hipError_t attrn = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            SHM_REQUIRE(attr == hipSuccess && attrn == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s",
+                        hipGetErrorString(attr == hipSuccess ? attrn : attr));
+            if (want_nm)
+                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
+            else
+                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
+        } else if (want_nm) {
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
         } else {
-            hipLaunchKernelGGL(wgrad_halo_bf16_kernel<2>, dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
         }
-        shm_set_last_kernel("wgrad_halo_bf16_kernel<%d>", rows);
+        shm_set_last_kernel(want_nm ? "wgrad_halo_bf16_kernel<%d, true>" : "wgrad_halo_bf16_kernel<%d>", rows);
     } else if (dtype == SHM_BF16) {
         dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
         if (ksize == 3) {
@@ -1162,8 +1357,14 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
             shm_set_last_kernel("wgrad_halo_thin_kernel<3, 1>");
         } else {
         dim3 gridh(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
-        hipLaunchKernelGGL(wgrad_halo_kernel, gridh, dim3(256), 0, st, hgs);
-        shm_set_last_kernel("wgrad_halo_kernel");
+        hgs.nt = g_wnorm.nt;
+        hgs.ntpart = g_wnorm.part;
+        hgs.ntc = g_wnorm.c;
+        if (want_nm)
+            hipLaunchKernelGGL(wgrad_halo_kernel<true>, gridh, dim3(256), 0, st, hgs);
+        else
+            hipLaunchKernelGGL(wgrad_halo_kernel<false>, gridh, dim3(256), 0, st, hgs);
+        shm_set_last_kernel(want_nm ? "wgrad_halo_kernel<true>" : "wgrad_halo_kernel");
         }
     } else {
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
@@ -1197,6 +1398,61 @@ extern "C" int shm_conv2d_wgrad_reduce(const void* workspace, float* dw, size_t 
                            accumulate);
     SHM_LAUNCH_CHECK("shm_conv2d_wgrad(reduce)");
     return SHM_OK;
+}
+
+// Would shm_conv2d_wgrad_norm run on a kernel that normalises its source in LDS?  A dry run of the variant choice; nothing is launched.
+extern "C" int shm_conv2d_wgrad_norm_supported(int batch, int hi, int wi, int cin, int cin_ld, int c1, int cout, int ksize, int stride, int norm_part, int dtype) {
+    if (dtype != SHM_F32 && dtype != SHM_BF16) return 0;
+    if (norm_part != 0 && norm_part != 1) return 0;
+    const bool two = c1 > 0 && c1 < cin_ld;
+    if (norm_part == 1 && !two) return 0;
+    static const __attribute__((aligned(256))) char dummy[256] = {};
+    const size_t ws = shm_conv2d_wgrad_workspace(batch, hi, wi, cin, cout, ksize) * 2;
+    g_wnorm.nt = (const float*)dummy;
+    g_wnorm.part = norm_part;
+    g_wnorm.c = two ? (norm_part ? cin_ld - c1 : c1) : cin_ld;
+    g_wnorm.query = true;
+    g_wnorm.query_ok = false;
+    int ns = 0;
+    const int r = shm_conv2d_wgrad_partial(dummy, two ? dummy : nullptr, two ? c1 : 0, two ? c1 : cin_ld, two ? cin_ld - c1 : 0, dummy, cout, batch, hi, wi, cin,
+                                           cin_ld, cout, ksize, stride, (void*)dummy, ws, dtype, &ns, nullptr);
+    const bool ok = r == SHM_OK && g_wnorm.query_ok;
+    g_wnorm = WNormReq{};
+    return ok ? 1 : 0;
+}
+
+extern "C" int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* dy,
+                                             int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride, void* workspace,
+                                             size_t ws_bytes, int dtype, int* nsplit_out, void* stream) {
+    SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_wgrad_norm: at most one source can be normalised on the fly");
+    SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: nt_x2 without a second source");
+    if (nt_x || nt_x2) {
+        g_wnorm.nt = nt_x ? nt_x : nt_x2;
+        g_wnorm.part = nt_x ? 0 : 1;
+        g_wnorm.c = x2 ? (nt_x ? c1 : cin_ld - c1) : cin_ld;
+    }
+    const int r = shm_conv2d_wgrad_partial(x, x2, c1, ldx, ldx2, dy, lddy, batch, hi, wi, cin, cin_ld, cout, ksize, stride, workspace, ws_bytes, dtype,
+                                           nsplit_out, stream);
+    g_wnorm = WNormReq{};
+    return r;
+}
+
+// shm_conv2d_wgrad on a source that is the UN-normalised activation of an InstanceNorm block (nt_x / nt_x2: that block's table, at
+// most one of the two)
+extern "C" int shm_conv2d_wgrad_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* dy, int lddy,
+                                     float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride, int accumulate,
+                                     void* workspace, size_t ws_bytes, int dtype, void* stream) {
+    SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_wgrad_norm: at most one source can be normalised on the fly");
+    SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: nt_x2 without a second source");
+    if (nt_x || nt_x2) {
+        g_wnorm.nt = nt_x ? nt_x : nt_x2;
+        g_wnorm.part = nt_x ? 0 : 1;
+        g_wnorm.c = x2 ? (nt_x ? c1 : cin_ld - c1) : cin_ld;
+    }
+    const int r = shm_conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride, accumulate, workspace, ws_bytes, dtype,
+                                   stream);
+    g_wnorm = WNormReq{};
+    return r;
 }
 
 extern "C" int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* dy,

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ a, 
 
 // part != null: the sums were accumulated over `nslot` slot copies part[slot][total][2]; the copies are zeroed
 // again as they are consumed, so the scratch is zero whenever no call is in flight (no memset per launch)
-__global__ void in_finalize_kernel(double* __restrict__ stats, double* __restrict__ part, int nslot, int total, int hw, double eps) {
+// nt != null: also the float table [batch][3][c] = (mean, inv, beta) of the consumers that normalise on the fly (common.h)
+__global__ void in_finalize_kernel(double* __restrict__ stats, double* __restrict__ part, int nslot, int total, int hw, double eps, float* __restrict__ nt,
+                                   const float* __restrict__ beta, int c) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     double s, q;
@@ -240,13 +242,41 @@ __global__ void in_finalize_kernel(double* __restrict__ stats, double* __restric
     double mean = s / hw;
     double var = q / hw - mean * mean;
     if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + eps);
     stats[2 * i] = mean;
-    stats[2 * i + 1] = 1.0 / sqrt(var + eps);
+    stats[2 * i + 1] = inv;
+    if (nt) {
+        const int n = i / c, ch = i - n * c;
+        float* t = nt + (size_t)n * 3 * c + ch;
+        t[0] = (float)mean;
+        t[c] = (float)inv;
+        t[2 * c] = beta[ch];
+    }
 }
 
-int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, hipStream_t st) {
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, part, nslot, total, hw, eps);
+int shm_in_finalize_internal(double* stats, double* part, int nslot, int total, int hw, double eps, float* nt, const float* beta, int c, hipStream_t st) {
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)total, 256)), dim3(256), 0, st, stats, part, nslot, total, hw, eps, nt, beta, c);
     SHM_LAUNCH_CHECK("shm_in_finalize");
+    return SHM_OK;
+}
+
+// the table alone, from finalized statistics (mean, inv)
+__global__ void in_norm_table_kernel(const double* __restrict__ stats, const float* __restrict__ beta, float* __restrict__ nt, int total, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / c, ch = i - n * c;
+    float* t = nt + (size_t)n * 3 * c + ch;
+    t[0] = (float)stats[2 * i];
+    t[c] = (float)stats[2 * i + 1];
+    t[2 * c] = beta[ch];
+}
+
+extern "C" int shm_in_norm_table(const double* stats, const float* beta, float* nt, int batch, int c, void* stream) {
+    SHM_REQUIRE(stats && beta && nt, SHM_E_SHAPE, "shm_in_norm_table: null pointer");
+    SHM_REQUIRE(c % 4 == 0 && c > 0, SHM_E_SHAPE, "shm_in_norm_table: channels %d must be a positive multiple of 4", c);
+    if (batch == 0) return SHM_OK;
+    hipLaunchKernelGGL(in_norm_table_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, (hipStream_t)stream, stats, beta, nt, batch * c, c);
+    SHM_LAUNCH_CHECK("shm_in_norm_table");
     return SHM_OK;
 }
 
@@ -262,7 +292,8 @@ extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, in
     SHM_DISPATCH(dtype, "shm_in_stats",
                  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, (const T*)a, lda, stats, hw, c, chunk));
     SHM_LAUNCH_CHECK("shm_in_stats");
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, (double*)nullptr, 0, batch * c, hw, (double)eps);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(shm_cdiv((long)batch * c, 256)), dim3(256), 0, st, stats, (double*)nullptr, 0, batch * c, hw, (double)eps,
+                       (float*)nullptr, (const float*)nullptr, c);
     SHM_LAUNCH_CHECK("shm_in_stats(finalize)");
     return SHM_OK;
 }
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ a, 
         for (int u = 0; u < U; ++u) {
             f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (x[u][e] - mean[e]) * inv[e] + bt[e];
+            for (int e = 0; e < 4; ++e) y[e] = shm_in_norm(x[u][e], mean[e], inv[e], bt[e]);
             st4(ob + (size_t)(p + u * pm.PP) * ldo, y);
         }
     }
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ a, 
         f32x4 x = ld4(base + (size_t)p * lda);
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (x[e] - mean[e]) * inv[e] + bt[e];
+        for (int e = 0; e < 4; ++e) y[e] = shm_in_norm(x[e], mean[e], inv[e], bt[e]);
         st4(ob + (size_t)p * ldo, y);
     }
 }
@@ -330,7 +361,9 @@ extern "C" int shm_in_apply(const void* a, int lda, const double* stats, const f
 // pool): a thread normalises the four pixels of a 2 x 2 quad for its four channels, writes them, and writes their mean -- the
 // pooled tensor is formed from the values as stored (rounded to T), in avgpool2_kernel's order, so it is bit-identical to
 // shm_in_apply followed by shm_avgpool2_fwd; the separate pooling pass (a full read of the normalised tensor) is gone.
-template <typename T>
+// OUT = false (shm_in_pool): only the pooled tensor is written -- the skip connection's consumers normalise the stored activation
+// on the fly (shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm); the pooled values are the same bits as with OUT = true.
+template <typename T, bool OUT = true>
 __global__ __launch_bounds__(256) void in_apply_pool_kernel(const T* __restrict__ a, int lda, const double* __restrict__ stats, const float* __restrict__ beta,
                                                             T* __restrict__ out, int ldo, T* __restrict__ pooled, int ldp, int h, int w, int c, int chunk,
                                                             int rev) {
@@ -367,11 +400,13 @@ __global__ __launch_bounds__(256) void in_apply_pool_kernel(const T* __restrict_
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[t][e] = rnd_as((const T*)nullptr, (x[t][e] - mean[e]) * inv[e] + bt[e]);
-        st4(ob + p * ldo, y[0]);
-        st4(ob + (p + 1) * ldo, y[1]);
-        st4(ob + (p + w) * ldo, y[2]);
-        st4(ob + (p + w + 1) * ldo, y[3]);
+            for (int e = 0; e < 4; ++e) y[t][e] = rnd_as((const T*)nullptr, shm_in_norm(x[t][e], mean[e], inv[e], bt[e]));
+        if constexpr (OUT) {
+            st4(ob + p * ldo, y[0]);
+            st4(ob + (p + 1) * ldo, y[1]);
+            st4(ob + (p + w) * ldo, y[2]);
+            st4(ob + (p + w + 1) * ldo, y[3]);
+        }
         s = ((y[0] + y[1]) + y[2]) + y[3];
         st4(pb + (size_t)q * ldp, s * 0.25f);
     };
@@ -401,9 +436,26 @@ extern "C" int shm_in_apply_pool(const void* a, int lda, const double* stats, co
     int nch = pix_chunks(hq, batch, c);
     int chunk = shm_cdiv(hq, nch);
     SHM_DISPATCH(dtype, "shm_in_apply_pool",
-                 hipLaunchKernelGGL(in_apply_pool_kernel<T>, dim3(shm_cdiv(hq, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats, beta,
+                 hipLaunchKernelGGL((in_apply_pool_kernel<T, true>), dim3(shm_cdiv(hq, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats, beta,
                                     (T*)out, ldo, (T*)pooled, ldp, h, w, c, chunk, shm_tune(SHM_TUNE_ELEM_REVERSE)));
     SHM_LAUNCH_CHECK("shm_in_apply_pool");
+    return SHM_OK;
+}
+
+extern "C" int shm_in_pool(const void* a, int lda, const double* stats, const float* beta, void* pooled, int ldp, int batch, int h, int w, int c, int dtype,
+                           void* stream) {
+    SHM_CHECK_C(c, "shm_in_pool");
+    SHM_REQUIRE(lda % 4 == 0 && ldp % 4 == 0, SHM_E_SHAPE, "shm_in_pool: bad pitch");
+    SHM_REQUIRE(h % 2 == 0 && w % 2 == 0, SHM_E_SHAPE, "shm_in_pool: odd size %dx%d", h, w);
+    SHM_REQUIRE(a && stats && beta && pooled, SHM_E_SHAPE, "shm_in_pool: null pointer");
+    if (batch == 0 || h * w == 0) return SHM_OK;
+    const int hq = (h / 2) * (w / 2);
+    int nch = pix_chunks(hq, batch, c);
+    int chunk = shm_cdiv(hq, nch);
+    SHM_DISPATCH(dtype, "shm_in_pool",
+                 hipLaunchKernelGGL((in_apply_pool_kernel<T, false>), dim3(shm_cdiv(hq, chunk), batch), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, stats,
+                                    beta, (T*)nullptr, 0, (T*)pooled, ldp, h, w, c, chunk, shm_tune(SHM_TUNE_ELEM_REVERSE)));
+    SHM_LAUNCH_CHECK("shm_in_pool");
     return SHM_OK;
 }
 

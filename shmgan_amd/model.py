@@ -14,15 +14,25 @@ Dense [in,out]).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
 from . import ops
 
-import os
-
 LRELU = 0.2
 IN_EPS = 1e-6
+# The fused block: the InstanceNorm apply of a block whose consumers stage their operand as an LDS halo image can be done by those
+# consumers (ops.conv2d_in_fwd(nt_x=) / ops.conv2d_wgrad(nt_x=)); the normalised tensor is then never written.  Results are the
+# same bits either way, so where to fold is a matter of measured time (tools/bench_fold.py):
+#   "auto" (default)  fold where it pays: float32 blocks whose consumer is the weights-in-registers kernel (one source of at most
+#                     64 channels, i.e. the 256 x 256 level at filter_size 64: the pass it removes costs 265 us per n = 40 tensor,
+#                     the consumers' extra work -20 .. +50 us).  On the halo kernels the in-LDS pass costs about what the stand-alone
+#                     pass does at 128 x 128 and more below; in bfloat16, whose MFMA loops are 6 x shorter, it costs 2-4 x the pass.
+#   "all"             fold wherever the kernels can (tests, A/B measurements)
+#   "0"               never
+NORM_FOLD = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all"}[os.environ.get("SHM_NORM_FOLD", "auto")]
 WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
 
@@ -284,6 +294,8 @@ class Generator(_ModelBase):
         self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32   # gradient-signal tensors ([G] in the header)
         self.pad = pad_channels(dtype)
         self.gsum = ops.gsum_default(dtype)                # InstanceNorm-backward sums in the producing epilogues
+        self.fold = NORM_FOLD                              # InstanceNorm apply folded into the consumers: False / "auto" / "all" (see NORM_FOLD)
+        self._plans = {}
         assert image_size % 16 == 0 and filter_size % self.pad == 0, \
             f"image_size must be a multiple of 16 and filter_size of {self.pad}"
         self.layers = generator_layers(filter_size)
@@ -405,17 +417,54 @@ class Generator(_ModelBase):
         ops.cvt_f64_f32(self.acc, self.P.grad[self.acc_off:], self.acc_n, 0)
 
     # -- forward --------------------------------------------------------------------------
-    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, r0, r1, part, pooled=None, apply=True, sync=None):
+    def _fold_plan(self, nb, n, attn):
+        """{layer index of an InstanceNorm block: True} for the blocks whose normalisation is applied by their consumers: every
+        convolution that reads the block's output, and that convolution's weight gradient, must run on a kernel that normalises its
+        operand in LDS for this batch (the launcher's variant choice depends on it: ops.conv2d_norm_supported).  Encoder block 1 of a
+        level feeds the next block; block 2 feeds the pool (ops.in_pool) and, as the skip, the decoder's Concatenate convolution
+        (its second source); the Concatenate block feeds the decoder level's second block.  That block's own output goes to a
+        Conv2DTranspose (or the head, which has normalised on the fly since round 2) and the bottleneck is 1x1: not folded.
+        Live attention adds its maps to the normalised skips, which therefore have to exist: nothing is folded."""
+        key = (nb, n, bool(attn), self.fold)            # nb: samples per forward launch (a part of a two-part forward), n: per backward launch
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        plan = {}
+        if self.fold and not attn:
+            dt, L = self.adt, self.layers
+
+            def ok(h, cin, c1, cout, part):
+                cin_p = _padk(cin, self.pad)
+                if self.fold != "all" and not (dt == torch.float32 and c1 == 0 and cin_p <= 64):
+                    return False                               # "auto": only where it is measured to pay
+                return (ops.conv2d_norm_supported(nb, h, h, cin_p, c1, cout, 3, 1, part, dt) and
+                        ops.conv2d_wgrad_norm_supported(n, h, h, cin, cin_p, c1, cout, 3, 1, part, dt))
+            for lvl in range(4):
+                h = self.S >> lvl
+                li0, li1 = 2 * lvl, 2 * lvl + 1
+                plan[li0] = ok(h, L[li0][4], 0, L[li1][4], 0)
+                lic = 11 + 3 * (3 - lvl)                       # the decoder level's Concatenate convolution: sources [u, skip]
+                cu = L[lic - 1][4]
+                plan[li1] = ok(h, L[lic][3], cu, L[lic][4], 1)
+                plan[lic] = ok(h, L[lic][4], 0, L[lic + 1][4], 0)
+        self._plans[key] = plan
+        return plan
+
+    def _cnl_fwd(self, tag, li, bi, x, x2, c1, ldx, ldx2, n, h, w, r0, r1, part, pooled=None, apply=True, sync=None, ntx=None, ntx2=None,
+                 fold=False):
         """Conv2D(k, s1, bias, LeakyReLU) -> InstanceNormalization on the samples [r0, r1) of a batch of n.  x, x2, pooled are
         FULL-batch tensors (the record describes them: the backward pass runs on the whole batch); the launches take row views.
         Returns (ahat, record).  pooled: AveragePooling2D(2) of the result, written by the same pass as the normalisation.
-        apply=False: the consumer normalises on the fly (the head, ops.head_in_fwd): returns the un-normalised tensor."""
+        apply=False: the consumer normalises on the fly (the head, ops.head_in_fwd): returns the un-normalised tensor.
+        ntx / ntx2: x / x2 is the un-normalised output of a folded block and this is its table.  fold: this block's output is
+        normalised by its consumers -- returns the un-normalised tensor, record["nt"] is the table they need."""
         _, _, k, cin, cout = self.layers[li]
         cin_p = _padk(cin, self.pad)
         A = self.arena
         nb = r1 - r0
         a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
-        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt) if apply else None
+        ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt) if apply and not fold else None
+        nt = A.get(f"{tag}/nt{li}", (n, 3, cout), torch.float32) if fold else None
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
         st = stats[r0 * cout * 2:r1 * cout * 2]
         # zero-on-return scratch: one per concurrently running part
@@ -423,11 +472,17 @@ class Generator(_ModelBase):
         if sync is not None:
             sync.before(part)
         ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a[r0:r1], cout, nb, h, w,
-                          cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr)
+                          cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr,
+                          nt_x=None if ntx is None else ntx[r0:r1], nt_x2=None if ntx2 is None else ntx2[r0:r1],
+                          nt_out=None if nt is None else nt[r0:r1], beta_out=self.betas[bi] if fold else None)
         if sync is not None:
             sync.after(part)
-        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout)
+        rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout, ntx=ntx, ntx2=ntx2, nt=nt)
         if not apply:
+            return a, rec
+        if fold:
+            if pooled is not None:
+                ops.in_pool(a[r0:r1], cout, st, self.betas[bi], pooled[r0:r1], cout, nb, h, w, cout)
             return a, rec
         if pooled is not None:
             ops.in_apply_pool(a[r0:r1], cout, st, self.betas[bi], ahat[r0:r1], cout, pooled[r0:r1], cout, nb, h, w, cout)
@@ -485,7 +540,8 @@ class Generator(_ModelBase):
         nb = r1 - r0
         A = self.arena
         recs = []
-        cur, ld, h = x16, self.pad, S
+        plan = self._fold_plan(nb, n, attn is not None)
+        cur, cur_nt, ld, h = x16, None, self.pad, S      # cur_nt: cur is the un-normalised output of a folded block, with this table
         li = bi = 0
         downs = []
         for lvl in range(4):
@@ -493,7 +549,9 @@ class Generator(_ModelBase):
             for j in range(2):
                 if j == 1:            # the level's second block: its normalisation pass also writes the pooled tensor
                     pooled = A.get(f"{tag}/p{lvl}", (n, h // 2, h // 2, self.layers[li][4]), self.adt)
-                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, pooled=pooled, sync=sync)
+                cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, pooled=pooled, sync=sync, ntx=cur_nt,
+                                       fold=plan.get(li, False))
+                cur_nt = r["nt"]
                 r["pooled"] = pooled
                 recs.append(r)
                 yield
@@ -503,10 +561,10 @@ class Generator(_ModelBase):
             if attn is not None:
                 skip = A.get(f"{tag}/skip{lvl}", (n, h, h, ld), self.adt)
                 ops.add_bcast(cur[r0:r1], attn[lvl], skip[r0:r1], nb, h * h * ld, self._attn_B, r0)
-                downs.append((skip, ld, h))
+                downs.append((skip, ld, h, None))
             else:
-                downs.append((cur, ld, h))
-            cur, h = pooled, h // 2
+                downs.append((cur, ld, h, cur_nt))
+            cur, cur_nt, h = pooled, None, h // 2
         for _ in range(2):                       # the two 1x1 blocks
             cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, sync=sync)
             recs.append(r)
@@ -527,16 +585,18 @@ class Generator(_ModelBase):
             ups.append(dict(li=li, x=cur, ldx=ld, u=u, h=h))
             li += 1
             h *= 2
-            skip, sld, sh = downs[3 - lvl]
+            skip, sld, sh, skip_nt = downs[3 - lvl]
             assert sh == h
-            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h, r0, r1, part, sync=sync)   # concat [u, skip]
+            cur, r = self._cnl_fwd(tag, li, bi, u, skip, cout, cout, sld, n, h, h, r0, r1, part, sync=sync, ntx2=skip_nt,
+                                   fold=plan.get(li, False))                                                  # concat [u, skip]
+            cur_nt = r["nt"]
             recs.append(r)
             ld = self.layers[li][4]
             li += 1
             bi += 1
             yield
             # the last block's InstanceNorm is applied by the head kernels (forward and backward) on the fly
-            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, apply=lvl < 3, sync=sync)
+            cur, r = self._cnl_fwd(tag, li, bi, cur, None, 0, ld, 0, n, h, h, r0, r1, part, apply=lvl < 3, sync=sync, ntx=cur_nt)
             recs.append(r)
             li += 1
             bi += 1
@@ -592,7 +652,8 @@ class Generator(_ModelBase):
 
         def wgrad():
             self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
-                                                      self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws))
+                                                      self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws,
+                                                      nt_x=rec["ntx"], nt_x2=rec["ntx2"]))
             if self._on_wgrad is not None:
                 self._on_wgrad(li)
         # WGRAD_AFTER_DGRAD: the weight gradient is released behind the layer's input gradient instead of beside it.  Both are MFMA

@@ -194,16 +194,40 @@ STATS_SLOTS = 16            # SHM_STATS_SLOTS
 
 
 def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, eps,
-                  cin_real=None, scratch=None):
+                  cin_real=None, scratch=None, nt_x=None, nt_x2=None, nt_out=None, beta_out=None):
     """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std).
-    scratch: optional f64 [STATS_SLOTS * batch * cout * 2] (spreads the statistics atomics)."""
+    scratch: optional f64 [STATS_SLOTS * batch * cout * 2] (spreads the statistics atomics).
+    nt_x / nt_x2: x / x2 is the UN-normalised activation of an InstanceNorm block and this is that block's table
+    (shm_conv2d_in_fwd_norm: the kernel normalises its operand tile in LDS); nt_out (+ beta_out): this block's own table."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
+    label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
+    if nt_x is None and nt_x2 is None and nt_out is None:
+        _timed("", flops, lambda: check(
+            lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                                    cin, cout, ksize, stride, slope, _p(stats), _p(scratch), eps, _dt(x), _stream()),
+            "shm_conv2d_in_fwd"), label)
+        return
     _timed("", flops, lambda: check(
-        lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
-                                cin, cout, ksize, stride, slope, _p(stats), _p(scratch), eps, _dt(x), _stream()),
-        "shm_conv2d_in_fwd"),
-           f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}")
+        lib().shm_conv2d_in_fwd_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+                                     cin, cout, ksize, stride, slope, _p(stats), _p(scratch), eps, _p(nt_out), _p(beta_out), _dt(x), _stream()),
+        "shm_conv2d_in_fwd_norm"), label + (" +norm" if (nt_x is not None or nt_x2 is not None) else ""))
+
+
+def conv2d_norm_supported(batch, hi, wi, cin, c1, cout, ksize, stride, norm_part, dtype):
+    """Would conv2d_in_fwd(nt_x= / nt_x2=) run on a kernel that normalises source `norm_part` in LDS?  (c1: channels of x when
+    there are two sources, else 0; dtype: torch dtype of the activations.)"""
+    dt = 1 if dtype == torch.bfloat16 else 0
+    return bool(lib().shm_conv2d_norm_supported(batch, hi, wi, cin, c1, cout, ksize, stride, norm_part, dt))
+
+
+def conv2d_wgrad_norm_supported(batch, hi, wi, cin, cin_ld, c1, cout, ksize, stride, norm_part, dtype):
+    dt = 1 if dtype == torch.bfloat16 else 0
+    return bool(lib().shm_conv2d_wgrad_norm_supported(batch, hi, wi, cin, cin_ld, c1, cout, ksize, stride, norm_part, dt))
+
+
+def in_norm_table(stats, beta, nt, batch, c):
+    check(lib().shm_in_norm_table(_p(stats), _p(beta), _p(nt), batch, c, _stream()), "shm_in_norm_table")
 
 
 GSUM_SLOTS = 8              # SHM_GSUM_SLOTS
@@ -253,11 +277,16 @@ def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
 
 
 def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride,
-                 accumulate, ws):
+                 accumulate, ws, nt_x=None, nt_x2=None):
+    """nt_x / nt_x2: x / x2 is the un-normalised activation of an InstanceNorm block, normalised in LDS (shm_conv2d_wgrad_norm)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
     label = f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}"
     wsb = ws.numel() * ws.element_size()
+    if (nt_x is not None or nt_x2 is not None) and TIMER is None:
+        check(lib().shm_conv2d_wgrad_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
+                                          cout, ksize, stride, int(accumulate), _p(ws), wsb, _dt(x), _stream()), "shm_conv2d_wgrad_norm")
+        return
     if TIMER is None:
         check(lib().shm_conv2d_wgrad(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
                                      cout, ksize, stride, int(accumulate), _p(ws), wsb, _dt(x), _stream()),
@@ -266,10 +295,16 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
     # timing mode: the two phases as separate calls, so the MFMA kernel's events hold nothing else
     import ctypes
     ns = ctypes.c_int(0)
-    TIMER.wrap("", flops, lambda: check(
-        lib().shm_conv2d_wgrad_partial(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
-                                       ksize, stride, _p(ws), wsb, _dt(x), ctypes.addressof(ns), _stream()),
-        "shm_conv2d_wgrad_partial"), label)
+    if nt_x is not None or nt_x2 is not None:
+        TIMER.wrap("", flops, lambda: check(
+            lib().shm_conv2d_wgrad_partial_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
+                                                ksize, stride, _p(ws), wsb, _dt(x), ctypes.addressof(ns), _stream()),
+            "shm_conv2d_wgrad_partial_norm"), label + " +norm")
+    else:
+        TIMER.wrap("", flops, lambda: check(
+            lib().shm_conv2d_wgrad_partial(_p(x), _p(x2), c1, ldx, ldx2, _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
+                                           ksize, stride, _p(ws), wsb, _dt(x), ctypes.addressof(ns), _stream()),
+            "shm_conv2d_wgrad_partial"), label)
     TIMER.wrap("wgrad_reduce_kernel", 0.0, lambda: check(
         lib().shm_conv2d_wgrad_reduce(_p(ws), _p(dw), ksize * ksize * cin * cout, ns.value, int(accumulate), _stream()),
         "shm_conv2d_wgrad_reduce"), label, fixed=True)
@@ -288,6 +323,13 @@ def in_apply_pool(a, lda, stats, beta, out, ldo, pooled, ldp, batch, h, w, c):
     _timed_bytes("shm_in_apply_pool", _tb(a, 2.25 * e), lambda: check(
         lib().shm_in_apply_pool(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, _p(pooled), ldp, batch, h, w, c, _dt(a), _stream()),
         "shm_in_apply_pool"))
+
+
+def in_pool(a, lda, stats, beta, pooled, ldp, batch, h, w, c):
+    """pooled = AveragePooling2D(2)(IN apply(a)) without writing the normalised tensor (its other consumers normalise on the fly)."""
+    e = batch * h * w * c                          # read a, write pooled (a quarter)
+    _timed_bytes("shm_in_pool", _tb(a, 1.25 * e), lambda: check(
+        lib().shm_in_pool(_p(a), lda, _p(stats), _p(beta), _p(pooled), ldp, batch, h, w, c, _dt(a), _stream()), "shm_in_pool"))
 
 
 def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):

@@ -1,0 +1,280 @@
+"""The fused block's forward (round 3): InstanceNormalization applied by the CONSUMER (SHM.py:244-245, Conv -> LeakyReLU -> IN;
+include/shmgan_hip.h: shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm / shm_in_pool / *_norm_supported).
+
+The kernels that stage their A operand as an LDS halo image normalise it there, from the producing block's (mean, inv, beta)
+table, so the normalised tensor is never written.  The arithmetic is shm_in_apply's (common.h: shm_in_norm) and out-of-image
+taps stay zero, hence every check here is BITWISE against the two-pass path (shm_in_apply, then the plain entry point):
+  * every folding forward kernel, forced through shm_set_tuning, one source and the Concatenate form (second source folded),
+    maps with 1..4 patches per side (every border case of the 3x3 halo), several samples (the per-sample table);
+  * both weight-gradient kernels (fp32, bf16 with 2 and 4 pixel rows per stage);
+  * shm_in_pool against shm_in_apply_pool's pooled output, shm_in_norm_table against the by-product of shm_conv2d_in_fwd_norm;
+  * shapes the chosen kernel cannot fold are refused (SHM_E_SHAPE), never silently mis-computed, and the *_supported queries
+    agree with what the entry points then do;
+  * the whole train_step with the fold on and off: same losses and gradients to the run-to-run bound of a step (the statistics
+    sums are float64 atomics, whose order is not fixed: tests/test_train_loop_gpu.py::test_step_is_reproducible_run_to_run).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_torch as st
+from util import host, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPS = 1e-6
+
+
+def _ops():
+    from shmgan_amd import ops
+    return ops
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    yield
+    _ops().set_tuning("reset", 0)
+
+
+def _t(a, dt):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return t.to(BF) if dt == "bf16" else t
+
+
+def _adt(dt):
+    return BF if dt == "bf16" else torch.float32
+
+
+def _block(rng, n, h, c, dt):
+    """An un-normalised activation, its finalized statistics, beta, its table and its normalised tensor (shm_in_apply)."""
+    ops = _ops()
+    a = _t(rng.standard_normal((n, h, h, c)) * rng.uniform(0.5, 2.0, (n, 1, 1, c)) + rng.uniform(-1, 1, (n, 1, 1, c)), dt)
+    beta = _t(rng.uniform(-0.5, 0.5, c), "f32")
+    stats = torch.zeros(n * c * 2, dtype=torch.float64, device="cuda")
+    ops.in_stats(a, c, stats, n, h * h, c, EPS)
+    nt = torch.full((n, 3, c), 9.0, dtype=torch.float32, device="cuda")
+    ops.in_norm_table(stats, beta, nt, n, c)
+    ahat = torch.empty_like(a)
+    ops.in_apply(a, c, stats, beta, ahat, c, n, h * h, c)
+    return a, stats, beta, nt, ahat
+
+
+def _wk(rng, cin, cout, dt):
+    """K-contiguous weights [tap][cout][cin] as the forward kernels read them."""
+    return _t(rng.standard_normal((9, cout, cin)) * 0.1, dt)
+
+
+def _same_stats(s0, s1):
+    """statistics of two launches over identical outputs: float64 atomics, i.e. equal up to the order of the adds"""
+    return torch.allclose(s0, s1, rtol=1e-12, atol=1e-13)
+
+
+def _in_fwd(x, x2, c1, wk, bias, n, h, cin, cout, dt, **kw):
+    ops = _ops()
+    y = torch.full((n, h, h, cout), 7.0, device="cuda", dtype=_adt(dt))
+    stats = torch.zeros(n * cout * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+    ldx = x.shape[-1]
+    ldx2 = 0 if x2 is None else x2.shape[-1]
+    ops.conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, EPS, scratch=scr, **kw)
+    torch.cuda.synchronize()
+    assert float(scr.abs().max()) == 0.0
+    return y, stats, ops.last_kernel()
+
+
+FWD_CASES = [
+    # variant, n, h, cin (c1 = 0: one source), cout
+    ("wreg", 3, 16, 64, 64),
+    ("wreg", 2, 48, 64, 128),
+    ("wreg", 2, 32, 32, 64),
+    ("halo64_st", 3, 16, 64, 64),
+    ("halo64_st", 2, 32, 128, 64),
+    ("halo128_st", 2, 16, 128, 128),
+    ("halo128_st", 3, 32, 256, 128),
+    ("halo128_st", 1, 64, 128, 256),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant,n,h,cin,cout", FWD_CASES)
+def test_forward_fold_is_bit_identical(variant, n, h, cin, cout, dt):
+    ops = _ops()
+    if variant == "wreg" and dt == "f32" and cin == 32 and cout != 64:
+        pytest.skip("fp32 wreg: 64 output channels per block")
+    rng = np.random.default_rng(11)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cin, dt)
+    wk, bias = _wk(rng, cin, cout, dt), _t(rng.standard_normal(cout) * 0.1, "f32")
+    ops.set_tuning("tapgemm.variant", variant)
+    y0, s0, k0 = _in_fwd(ahat, None, 0, wk, bias, n, h, cin, cout, dt)
+    nt_out = torch.full((n, 3, cout), 5.0, dtype=torch.float32, device="cuda")
+    beta_out = _t(rng.uniform(-1, 1, cout), "f32")
+    y1, s1, k1 = _in_fwd(a, None, 0, wk, bias, n, h, cin, cout, dt, nt_x=nt, nt_out=nt_out, beta_out=beta_out)
+    assert k1 != k0 and "true" in k1.rsplit(",", 1)[-1], (k0, k1)            # the norm instantiation ran
+    assert torch.equal(y0, y1), (k1, float((y0.float() - y1.float()).abs().max()))
+    assert _same_stats(s0, s1)
+    # this block's own table, a by-product of the statistics finalisation, equals shm_in_norm_table's
+    ref = torch.empty_like(nt_out)
+    ops.in_norm_table(s1, beta_out, ref, n, cout)
+    assert torch.equal(ref, nt_out)
+    st64 = s1.view(n, cout, 2)
+    assert torch.equal(nt_out[:, 0], st64[..., 0].float()) and torch.equal(nt_out[:, 1], st64[..., 1].float())
+    assert torch.equal(nt_out[:, 2], beta_out.expand(n, cout))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant,n,h,cu,cs,cout", [
+    ("halo64_st", 2, 32, 64, 64, 64),            # the generator's top decoder level: [u, skip] -> 64
+    ("halo128_st", 2, 16, 128, 128, 128),
+    ("halo128_st", 1, 32, 256, 256, 256),        # 256 folded channels: the LDS table's limit
+])
+def test_concat_fold_second_source(variant, n, h, cu, cs, cout, dt):
+    """Concatenate([u, skip]): u (a Conv2DTranspose output) is used as stored, the skip is normalised in LDS."""
+    ops = _ops()
+    rng = np.random.default_rng(12)
+    u = _t(rng.standard_normal((n, h, h, cu)), dt)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cs, dt)
+    cin = cu + cs
+    wk, bias = _wk(rng, cin, cout, dt), _t(rng.standard_normal(cout) * 0.1, "f32")
+    ops.set_tuning("tapgemm.variant", variant)
+    y0, s0, _ = _in_fwd(u, ahat, cu, wk, bias, n, h, cin, cout, dt)
+    y1, s1, k1 = _in_fwd(u, a, cu, wk, bias, n, h, cin, cout, dt, nt_x2=nt)
+    assert torch.equal(y0, y1) and _same_stats(s0, s1), k1
+    # ... and the first source folded instead (not a generator case, same code path with part 0)
+    y2, s2, _ = _in_fwd(ahat, u, cs, wk, bias, n, h, cin, cout, dt)
+    y3, s3, k3 = _in_fwd(a, u, cs, wk, bias, n, h, cin, cout, dt, nt_x=nt)
+    assert torch.equal(y2, y3) and _same_stats(s2, s3), k3
+
+
+def _wgrad(x, x2, c1, dy, n, h, cin, cout, **kw):
+    ops = _ops()
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 16, device="cuda")
+    dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+    ldx = x.shape[-1]
+    ldx2 = 0 if x2 is None else x2.shape[-1]
+    ops.conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, cout, dw, n, h, h, cin, cin, cout, 3, 1, 0, ws, **kw)
+    torch.cuda.synchronize()
+    return dw, ops.last_kernel()
+
+
+@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2)])
+@pytest.mark.parametrize("n,h,cin,cout,blocks", [
+    (3, 16, 64, 64, 0),
+    (2, 32, 128, 64, 0),
+    (5, 16, 64, 128, 7),              # few slabs: a block walks several images (the lane's table registers are re-read)
+    (2, 48, 64, 64, 0),
+])
+def test_wgrad_fold_is_bit_identical(dt, rows, n, h, cin, cout, blocks):
+    ops = _ops()
+    rng = np.random.default_rng(13)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cin, dt)
+    dy = _t(rng.standard_normal((n, h, h, cout)), dt)
+    if rows:
+        ops.set_tuning("wgrad.bf16_rows", rows)
+    if blocks:
+        ops.set_tuning("wgrad.blocks", blocks)
+    dw0, k0 = _wgrad(ahat, None, 0, dy, n, h, cin, cout)
+    dw1, k1 = _wgrad(a, None, 0, dy, n, h, cin, cout, nt_x=nt)
+    assert "true" in k1 and k1 != k0, (k0, k1)
+    assert torch.equal(dw0, dw1), (k1, float((dw0 - dw1).abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_wgrad_fold_concat(dt):
+    ops = _ops()
+    rng = np.random.default_rng(14)
+    n, h, cu, cs, cout = 2, 32, 64, 128, 64
+    u = _t(rng.standard_normal((n, h, h, cu)), dt)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cs, dt)
+    dy = _t(rng.standard_normal((n, h, h, cout)), dt)
+    dw0, _ = _wgrad(u, ahat, cu, dy, n, h, cu + cs, cout)
+    dw1, k1 = _wgrad(u, a, cu, dy, n, h, cu + cs, cout, nt_x2=nt)
+    assert torch.equal(dw0, dw1), k1
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_in_pool_matches_in_apply_pool(dt):
+    ops = _ops()
+    rng = np.random.default_rng(15)
+    n, h, c = 3, 32, 64
+    a, stats, beta, nt, ahat = _block(rng, n, h, c, dt)
+    out = torch.empty_like(a)
+    p0 = torch.empty((n, h // 2, h // 2, c), device="cuda", dtype=a.dtype)
+    p1 = torch.full_like(p0, 3.0)
+    ops.in_apply_pool(a, c, stats, beta, out, c, p0, c, n, h, h, c)
+    ops.in_pool(a, c, stats, beta, p1, c, n, h, h, c)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ahat) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_unsupported_shapes_are_refused(dt):
+    """A kernel that cannot normalise in LDS is never given an un-normalised source: the query says no and the call fails."""
+    from shmgan_amd._lib import ShmError
+    ops = _ops()
+    rng = np.random.default_rng(16)
+    adt = _adt(dt)
+    n, h = 2, 16
+    # (a) a forced DMA tile; (b) stride 2; (c) more folded channels than the LDS table holds
+    for variant, cin, cout, stride in (("dma128x128", 64, 128, 1), ("auto", 64, 128, 2), ("halo128_st", 512, 128, 1)):
+        ops.set_tuning("tapgemm.variant", variant)
+        assert not ops.conv2d_norm_supported(n, h, h, cin, 0, cout, 3, stride, 0, adt), (variant, cin)
+        a, stats, beta, nt, ahat = _block(rng, n, h, cin, dt)
+        wk = _wk(rng, cin, cout, dt)
+        y = torch.empty((n, h // stride, h // stride, cout), device="cuda", dtype=adt)
+        s = torch.zeros(n * cout * 2, dtype=torch.float64, device="cuda")
+        with pytest.raises(ShmError, match="cannot normalise"):
+            ops.conv2d_in_fwd(a, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, stride, 0.2, s, EPS, nt_x=nt)
+    ops.set_tuning("reset", 0)
+    # queries follow the automatic choice: the generator's big layers fold, a map that is not a multiple of 16 does not
+    assert ops.conv2d_norm_supported(8, 256, 256, 64, 0, 64, 3, 1, 0, adt)
+    assert ops.conv2d_norm_supported(8, 128, 128, 256, 128, 128, 3, 1, 1, adt)
+    assert not ops.conv2d_norm_supported(8, 24, 24, 64, 0, 64, 3, 1, 0, adt)
+    assert ops.conv2d_wgrad_norm_supported(8, 256, 256, 64, 64, 0, 64, 3, 1, 0, adt)
+    assert not ops.conv2d_wgrad_norm_supported(8, 256, 256, 64, 64, 0, 64, 3, 2, 0, adt)
+    assert not ops.conv2d_wgrad_norm_supported(8, 128, 128, 192, 192, 96, 64, 3, 1, 1, adt)      # a 64-channel block would straddle the sources
+    # wgrad refuses as well
+    a, stats, beta, nt, ahat = _block(rng, n, h, 64, dt)
+    dy = _t(rng.standard_normal((n, h // 2, h // 2, 64)), dt)
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, 64, 64, 3) // 4 + 16, device="cuda")
+    dw = torch.zeros((3, 3, 64, 64), device="cuda")
+    with pytest.raises(ShmError, match="cannot normalise"):
+        ops.conv2d_wgrad(a, None, 0, 64, 0, dy, 64, dw, n, h, h, 64, 64, 64, 3, 2, 0, ws, nt_x=nt)
+
+
+def _step(S, F, B, dt, fold, seed=0):
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
+    m.G.fold = fold
+    m.G._plans.clear()
+    inp = st.make_inputs(B, S)
+    dr = st.make_draws(seed, B, S, F)
+    m.train_step(*inp, draws=dr, style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    plans = {k: dict(v) for k, v in m.G._plans.items()}
+    return dict(m.losses()), m.G.P.grad.clone(), m.D.P.grad.clone(), plans
+
+
+@pytest.mark.parametrize("S,F,B,dt", [(64, 64, 2, "float32"), (64, 64, 2, "bfloat16"), (128, 64, 1, "float32"), (64, 32, 2, "bfloat16")])
+def test_train_step_is_bit_identical_with_and_without_the_fold(S, F, B, dt):
+    l0, g0, d0, p0 = _step(S, F, B, dt, fold=False)
+    l1, g1, d1, p1 = _step(S, F, B, dt, fold="all")
+    assert not any(any(v.values()) for v in p0.values())
+    folded = sorted({li for v in p1.values() for li, on in v.items() if on})
+    assert folded, "no block was folded: the test would compare a path with itself"
+    tol = 1e-6 if dt == "float32" else 2e-3      # bf16: a last-bit difference in a statistic can move a rounded activation
+    for k, v in l0.items():
+        if k != "ssim":
+            assert abs(l1[k] - v) <= tol * max(1.0, abs(v)), (k, v, l1[k])
+    assert rel_l2(host(g1), host(g0)) <= tol, (folded, rel_l2(host(g1), host(g0)))
+    assert rel_l2(host(d1), host(d0)) <= tol
+
+
+def test_default_policy_folds_the_float32_wreg_consumers():
+    """"auto": at filter_size 64 the two blocks of the 256 x 256 level whose consumer is the fp32 weights-in-registers kernel are
+    folded (encoder block 1 -> conv2d_1, the top Concatenate block -> conv2d_25), nothing in bfloat16."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    for dt, want in (("float32", [0, 20]), ("bfloat16", [])):
+        m = ShmGANwithSSpecSeg(image_size=64, filter_size=64, batch_size=1, compute_dtype=dt).build()
+        assert m.G.fold == "auto"
+        plan = m.G._fold_plan(5, 5, False)
+        assert sorted(li for li, on in plan.items() if on) == want, (dt, plan)
