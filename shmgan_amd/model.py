@@ -32,7 +32,8 @@ IN_EPS = 1e-6
 #                     pass does at 128 x 128 and more below; in bfloat16, whose MFMA loops are 6 x shorter, it costs 2-4 x the pass.
 #   "all"             fold wherever the kernels can (tests, A/B measurements)
 #   "0"               never
-NORM_FOLD = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all"}[os.environ.get("SHM_NORM_FOLD", "auto")]
+NORM_FOLD = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all", "fake": "all"}[os.environ.get("SHM_NORM_FOLD", "auto")]
+_FAKE_FOLD = os.environ.get("SHM_NORM_FOLD") == "fake"      # timing only (WRONG results): the folded tensors are consumed un-normalised by the plain kernels
 WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
 
@@ -473,7 +474,7 @@ class Generator(_ModelBase):
             sync.before(part)
         ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a[r0:r1], cout, nb, h, w,
                           cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr,
-                          nt_x=None if ntx is None else ntx[r0:r1], nt_x2=None if ntx2 is None else ntx2[r0:r1],
+                          nt_x=None if (ntx is None or _FAKE_FOLD) else ntx[r0:r1], nt_x2=None if (ntx2 is None or _FAKE_FOLD) else ntx2[r0:r1],
                           nt_out=None if nt is None else nt[r0:r1], beta_out=self.betas[bi] if fold else None)
         if sync is not None:
             sync.after(part)
@@ -653,7 +654,7 @@ class Generator(_ModelBase):
         def wgrad():
             self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
                                                       self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws,
-                                                      nt_x=rec["ntx"], nt_x2=rec["ntx2"]))
+                                                      nt_x=None if _FAKE_FOLD else rec["ntx"], nt_x2=None if _FAKE_FOLD else rec["ntx2"]))
             if self._on_wgrad is not None:
                 self._on_wgrad(li)
         # WGRAD_AFTER_DGRAD: the weight gradient is released behind the layer's input gradient instead of beside it.  Both are MFMA
