@@ -182,29 +182,49 @@ int shm_conv2d_wgrad(const void* x, const void* x2, int c1, int ldx, int ldx2, c
  * operand as a halo image (unit-stride 3x3 layers on maps that are multiples of 16; *_norm_supported says whether a shape runs on
  * one).  Out-of-image taps stay zero (zero padding of the NORMALISED tensor) and the arithmetic is shm_in_apply's, so results
  * are bit-identical to shm_in_apply followed by the plain entry point.
- *   nt = float [batch][3][c]: per sample the planes mean[c], inv[c], beta[c] of the producing block (c = its channel count = the
- *   channel count of the source it describes), written by shm_conv2d_in_fwd_norm(nt_out, beta_out) or shm_in_norm_table.
+ *   nt = float [batch][4][c]: per sample the planes mean[c], inv[c], beta[c], ring[c] = mean - beta / inv (the raw value whose
+ *   normalised image is 0) of the producing block (c = its channel count = the channel count of the source it describes), written
+ *   by shm_conv2d_in_fwd_norm(nt_out, beta_out) or shm_in_norm_table.
+ *   norm_mode SHM_NORM_EXACT / SHM_NORM_SCALED (below); with SHM_NORM_SCALED `wk` and `bias` are shm_conv2d_norm_prepare's wk_n, bias_n.
  *   nt_x / nt_x2: table of source x / x2, or NULL = that source is used as stored; at most one of the two. */
+#define SHM_NORM_EXACT 0       /* the kernel applies (a - mean) * inv + beta to its operand tile in LDS: bit-identical to shm_in_apply + plain call */
+#define SHM_NORM_SCALED 1      /* the normalisation is in the operands: per-sample weights w * inv and bias rows (shm_conv2d_norm_prepare);
+                                  the kernels only write `ring` over out-of-image taps.  Same result to rounding, no per-element work in
+                                  the MFMA kernels */
 int shm_in_norm_table(const double* stats, const float* beta, float* nt, int batch, int c, void* stream);
+/* SHM_NORM_SCALED operands: wk_n [batch][taps][cout][cin] (activation dtype) = wk with the channels [part_lo, part_lo + c) of the
+ * folded source scaled by that sample's inv, bias_n [batch][cout] = bias + sum wk * (beta - mean * inv) over those channels.  nt is the
+ * folded source's table, c its channel count. */
+int shm_conv2d_norm_prepare(const void* wk, const float* bias, const float* nt, int c, int part_lo, void* wk_n, float* bias_n,
+                            int batch, int cin, int cout, int ksize, int dtype, void* stream);
 /* shm_conv2d_in_fwd with (a) sources normalised on the fly and (b) optionally this block's own table as a by-product of the
- * statistics finalisation (nt_out [batch][3][cout] with beta_out [cout]; NULL = not wanted).  With nt_x == nt_x2 == NULL it is
+ * statistics finalisation (nt_out [batch][4][cout] with beta_out [cout]; NULL = not wanted).  With nt_x == nt_x2 == NULL it is
  * shm_conv2d_in_fwd.  SHM_E_SHAPE if the kernel chosen for the shape cannot normalise in LDS (never a silent fallback). */
 int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
-                           const void* wk, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin, int cout,
-                           int ksize, int stride, float slope, double* stats, double* scratch, float eps, float* nt_out,
+                           int norm_mode, const void* wk, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
+                           int cout, int ksize, int stride, float slope, double* stats, double* scratch, float eps, float* nt_out,
                            const float* beta_out, int dtype, void* stream);
 /* 1 if shm_conv2d_in_fwd_norm would take a normalised source `norm_part` (0 = x, 1 = x2; c1 = channels of x when there are two
  * sources, else 0) for this shape, batch and the current tuning knobs; 0 otherwise.  Launches nothing. */
 int shm_conv2d_norm_supported(int batch, int hi, int wi, int cin, int c1, int cout, int ksize, int stride, int norm_part, int dtype);
-/* shm_conv2d_wgrad on sources normalised on the fly, and its query. */
+/* shm_conv2d_wgrad on sources normalised on the fly, and its query.  SHM_NORM_SCALED: the kernels compute
+ * inv * sum a_ext * dz (a_ext = a inside the image, `ring` outside) per sample -- the workspace must then hold
+ * shm_conv2d_wgrad_norm_workspace() bytes (splits on sample boundaries) -- and the caller completes the gradient with
+ * shm_conv2d_wgrad_norm_finish: dw[tap][part_lo + k][co] += sum_n (beta[k] - mean_n[k] * inv_n[k]) * dzsum[n][co], dzsum = float64
+ * [batch][cout] per-sample channel sums of dz = what shm_in_bwd_keep_dz_sums(dst) makes the NEXT shm_in_bwd / shm_in_bwd_apply /
+ * shm_in_bwd_rank1 call of the thread copy out of its bias-gradient staging (one-shot; that call must take a bias gradient). */
 int shm_conv2d_wgrad_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
-                          const void* dy, int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize,
-                          int stride, int accumulate, void* workspace, size_t ws_bytes, int dtype, void* stream);
+                          int norm_mode, const void* dy, int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout,
+                          int ksize, int stride, int accumulate, void* workspace, size_t ws_bytes, int dtype, void* stream);
 int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2,
-                                  const void* dy, int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize,
-                                  int stride, void* workspace, size_t ws_bytes, int dtype, int* nsplit_out, void* stream);
+                                  int norm_mode, const void* dy, int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout,
+                                  int ksize, int stride, void* workspace, size_t ws_bytes, int dtype, int* nsplit_out, void* stream);
 int shm_conv2d_wgrad_norm_supported(int batch, int hi, int wi, int cin, int cin_ld, int c1, int cout, int ksize, int stride,
                                     int norm_part, int dtype);
+size_t shm_conv2d_wgrad_norm_workspace(int batch, int hi, int wi, int cin, int cout, int ksize, int dtype);
+int shm_conv2d_wgrad_norm_finish(float* dw, const float* nt, const double* dzsum, int batch, int c, int part_lo, int cin, int cout,
+                                 int ksize, void* stream);
+int shm_in_bwd_keep_dz_sums(double* dst);
 /* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers
  * normalise a on the fly, only the pool's consumer needs a tensor.  Same bits as shm_in_apply_pool's `pooled`. */
 int shm_in_pool(const void* a, int lda, const double* stats, const float* beta, void* pooled, int ldp, int batch, int h, int w,

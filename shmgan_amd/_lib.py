@@ -45,10 +45,14 @@ SIGNATURES = {
     "shm_in_apply": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "shm_in_apply_pool": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "shm_in_norm_table": (I, [P, P, P, I, I, P]),
-    "shm_conv2d_in_fwd_norm": (I, [P, P, I, I, I, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, P, F, P, P, I, P]),
+    "shm_conv2d_in_fwd_norm": (I, [P, P, I, I, I, P, P, I, P, P, P, I, I, I, I, I, I, I, I, F, P, P, F, P, P, I, P]),
+    "shm_conv2d_norm_prepare": (I, [P, P, P, I, I, P, P, I, I, I, I, I, P]),
     "shm_conv2d_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I]),
-    "shm_conv2d_wgrad_norm": (I, [P, P, I, I, I, P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
-    "shm_conv2d_wgrad_partial_norm": (I, [P, P, I, I, I, P, P, P, I, I, I, I, I, I, I, I, I, P, Z, I, P, P]),
+    "shm_conv2d_wgrad_norm": (I, [P, P, I, I, I, P, P, I, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P]),
+    "shm_conv2d_wgrad_partial_norm": (I, [P, P, I, I, I, P, P, I, P, I, I, I, I, I, I, I, I, I, P, Z, I, P, P]),
+    "shm_conv2d_wgrad_norm_workspace": (Z, [I, I, I, I, I, I, I]),
+    "shm_conv2d_wgrad_norm_finish": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "shm_in_bwd_keep_dz_sums": (I, [P]),
     "shm_conv2d_wgrad_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I, I]),
     "shm_in_pool": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),

@@ -167,7 +167,9 @@ __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.
 // consumers that normalise their operand tile in LDS ("fused block", shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm): a
 // subtraction and one fused multiply-add, so that both give the same bits.
 __device__ __forceinline__ float shm_in_norm(float x, float mean, float inv, float beta) { return __builtin_fmaf(x - mean, inv, beta); }
-// A block's normalisation table for such consumers: float [batch][3][c] = per sample the planes (mean, inv, beta[c]).
+// A block's normalisation table for such consumers: float [batch][4][c] = per sample the planes mean, inv, beta[c] and
+// ring = mean - beta / inv, the RAW value whose normalised image is 0 (what an out-of-image tap has to read in SHM_NORM_SCALED mode).
+#define SHM_NT_PLANES 4
 #define SHM_NT_MAXC 256           // normalised channels a folding consumer keeps in LDS
 
 // wave64 sum via DPP-free shuffles

@@ -61,11 +61,16 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
     int ldgaux[2];
     double* gred[2];
     int gslots, gbatch;
-    // "norm" (shm_conv2d_in_fwd_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation of an InstanceNorm block;
-    // the kernel applies shm_in_norm to that part of the operand tile in LDS, from nt = float [batch][3][ntc] (mean, inv, beta)
+    // "norm" (shm_conv2d_in_fwd_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation of an InstanceNorm block,
+    // nt = float [batch][4][ntc] its table (mean, inv, beta, ring).  ntmode SHM_NORM_EXACT: the kernel applies shm_in_norm to that part
+    // of the operand tile in LDS.  SHM_NORM_SCALED: the normalisation is in the operands -- w holds one weight copy per sample,
+    // [batch][taps][nout][K] with the part's input channels scaled by inv (wimg = bytes per copy), bias one row per sample
+    // [batch][nout] = bias + sum w * (beta - mean * inv) (bias_img = nout) -- and the kernel only writes `ring` over the out-of-image
+    // entries of the tile (the raw value that normalises to 0: zero padding of the NORMALISED tensor)
     const float* nt;
-    int ntpart, ntc;
-    unsigned ntbytes;
+    int ntpart, ntc, ntmode;
+    unsigned ntbytes, wimg;
+    int bias_img;
     TapPhase ph[4];
 };
 
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (mv && n < a.nout) ? (float)vo : 0.f;          // statistics of the value as stored
                     s1[j] += v;
-                    s2[j] += v * v;
+                    s2[j] = __builtin_fmaf(v, v, s2[j]);          // (an explicit fma: left to hipcc, one instantiation contracts and another does not)
                     const int col = j * 32 + l31;
                     tile[row * WTN + ((((col >> 3) ^ (row & (CW - 1))) << 3) | (col & 7))] = __builtin_bit_cast(unsigned short, vo);
                 }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;                       // statistics of the value as stored
                     s1[j] += v;
-                    s2[j] += v * v;
+                    s2[j] = __builtin_fmaf(v, v, s2[j]);          // (an explicit fma: left to hipcc, one instantiation contracts and another does not)
                     if (n < a.n1)
                         ((TO*)a.y)[opix * a.ldy + n] = vo;
                     else
@@ -578,7 +583,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
 // stand-alone normalisation pass (a read and a write of the whole activation) is gone, for 3 ds_read_b128 + 4 fma + 1 ds_write_b128 per
 // 1 KiB item and 2304 (fp32) MFMAs.  Out-of-image halo pixels were DMA'd as zeros and are left alone: zero padding of the
 // NORMALISED tensor, as the layer defines it.  The (mean, inv, beta) planes of the block's image sit in LDS (3 x ntc floats).
-template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2, bool GS = false, bool NM = false>
+// NM = 0: none; 1: SHM_NORM_EXACT (above); 2: SHM_NORM_SCALED (TapGemmArgs: per-sample weights and bias rows, `ring` over the out-of-image entries).
+template <typename T, typename TO, int BN, int PH = 16, bool ST = false, int TM = 2, bool GS = false, int NM = 0>
 __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) void tapgemm_halo_kernel(const TapGemmArgs a) {
     static_assert(TM == 2 || (TM == 4 && ST), "four M tiles per wave: static-tap form only");
     static_assert(!NM || (ST && TM == 2 && !GS), "norm: static-tap forward form");
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     constexpr int NA = NIT / NW, NB = (BN / 16) / NW; // DMA instructions per wave: A per chunk, B per tap
     static_assert(NIT % NW == 0 && (BN / 16) % NW == 0, "DMA items divide over the waves");
     __shared__ __attribute__((aligned(1024))) float smem[2 * ASTG + 3 * BSTG];
-    __shared__ __attribute__((aligned(1024))) float snt[NM ? 3 * SHM_NT_MAXC : 4];
+    __shared__ __attribute__((aligned(1024))) float snt[NM ? SHM_NT_PLANES * SHM_NT_MAXC : 4];
     float* const sA = smem;
     float* const sB = smem + 2 * ASTG;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -609,7 +615,9 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+NW, ...
     const int drow = lane >> 2, dq = lane & 3;
     unsigned arow1[NA], arow2[NA];
-    [[maybe_unused]] int nmv[NA];          // NM: first channel (within its 64-byte row) of the lane's 16 bytes of item j, -1 = not an image pixel
+    // NM: c = first channel (within its 64-byte row) of the lane's 16 bytes of item j: c for an image pixel, -1 - c for a halo pixel
+    // outside the image, INT_MIN for the unused tail rows of the last item
+    [[maybe_unused]] int nmv[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int hrow = 16 * (wave + NW * j) + drow;
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         const int coff = (dq ^ (ST ? ((hrow >> 1) + hr) & 3 : (hrow >> 2) & 3)) * CHE;
         arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * (unsigned)ESZ : 0xffffffffu;
         arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * (unsigned)ESZ : 0xffffffffu;
-        nmv[j] = v ? coff : -1;
+        nmv[j] = v ? coff : hrow < (PH + 2) * HC ? -1 - coff : (int)0x80000000;
     }
     unsigned wrow[NB];
 #pragma unroll
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     int ld_tap = 0, ld_chunk = 0, ld_stage = 0;    // position of the next weight DMA
     auto dma_b = [&]() {
         const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
-        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + ld_chunk * BKE) * (unsigned)ESZ;
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + ld_chunk * BKE) * (unsigned)ESZ + (NM == 2 ? (unsigned)img * a.wimg : 0u);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const unsigned off = wrow[j] == 0xffffffffu ? wrow[j] : wrow[j] + wbase;
@@ -730,6 +738,34 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         if ((int)second != a.ntpart) return;                      // block-uniform: this chunk's source is used as stored
         const float* tb0 = snt + (second ? c0 - a.c1 : c0);
         float* dst = sA + (chunk & 1) * ASTG + wave * 256 + lane * 4;
+        if constexpr (NM == 2) {
+            // SHM_NORM_SCALED: only a patch on the image border has anything to do -- its out-of-image halo entries (DMA'd as zeros) get
+            // `ring`; (w * inv) * ring + w * (beta - mean * inv) = 0, the tap's contribution under zero padding of the normalised tensor
+            if (!(y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)) return;          // block-uniform
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int m = nmv[j];
+                if (m < 0 && m != (int)0x80000000) {
+                    const float* tb = tb0 + (-1 - m) + 3 * a.ntc;
+                    float* p = dst + j * NW * 256;
+                    if constexpr (ESZ == 4) {
+                        *(f32x4*)p = *(const f32x4*)tb;
+                    } else {
+                        const f32x4 r0 = *(const f32x4*)tb, r1 = *(const f32x4*)(tb + 4);
+                        u32x4 x;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            x[e] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r0[2 * e]) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r0[2 * e + 1]) << 16);
+                            x[2 + e] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r1[2 * e]) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r1[2 * e + 1]) << 16);
+                        }
+                        *(u32x4*)p = x;
+                    }
+                }
+            }
+            return;
+        } else {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             if (nmv[j] >= 0) {
@@ -759,15 +795,16 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                 }
             }
         }
+        }
     };
 
     // ---- pipeline.  DMA issue order per wave: [NM: table piece]; A(0); B(0); B(1); then at step s: [A(chunk+1) if tap == 0]; B(s+2).
     if constexpr (NM) {
-        // the (mean, inv, beta) planes of this block's image, 3 x ntc floats, in 1 KiB pieces (reads past the table give zeros)
+        // the (mean, inv, beta, ring) planes of this block's image, 4 x ntc floats, in 1 KiB pieces (reads past the table give zeros)
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, a.ntbytes, 0x00020000);
-        if (wave < 3)
+        if (wave < SHM_NT_PLANES)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)(snt + wave * 256), 16,
-                                                     (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)wave * 1024u + (unsigned)lane * 16u), 0, 0, 0);
+                                                     (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)wave * 1024u + (unsigned)lane * 16u), 0, 0, 0);
     }
     dma_a(0);
     dma_b();
@@ -878,7 +915,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;
-        bj[j] = (a.bias && n < a.nout) ? a.bias[n] : 0.f;
+        bj[j] = (a.bias && n < a.nout) ? a.bias[(NM == 2 ? (size_t)img * a.bias_img : (size_t)0) + n] : 0.f;
         asm volatile("" : "+v"(bj[j]));           // waited for here, once (see tapgemm_dma_kernel)
     }
     // bf16 outputs: the MFMA accumulator layout gives each lane one 2-byte element per row, i.e. 64 two-byte
@@ -903,7 +940,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = n < a.nout ? (float)vo : 0.f;
                     s1[j] += v;
-                    s2[j] += v * v;
+                    s2[j] = __builtin_fmaf(v, v, s2[j]);          // (an explicit fma: left to hipcc, one instantiation contracts and another does not)
                     // 16-byte chunk c of row `row` lives at chunk c ^ (row & 7): conflict-free 16-byte reads below
                     const int col = j * 32 + l31;
                     tile[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = __builtin_bit_cast(unsigned short, vo);
@@ -1043,7 +1080,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     const TO vo = (TO)shm_lrelu(v, a.slope);
                     v = (float)vo;
                     s1[j] += v;
-                    s2[j] += v * v;
+                    s2[j] = __builtin_fmaf(v, v, s2[j]);          // (an explicit fma: left to hipcc, one instantiation contracts and another does not)
                     if (!abl::nostore || v == 123.456f)         // (timing-only build: keep the value live, store nothing)
                     {
                         if (n < a.n1)
@@ -1098,7 +1135,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
 // here, so unlike in tapgemm_halo_kernel it costs nothing per tap.
 // GS: the gsum epilogue (input-gradient launches, see TapGemmArgs) for bf16 outputs.
 // NM: "norm" (see tapgemm_halo_kernel / tapgemm_wreg_f32_kernel).
-template <typename TO, int NCH, bool GS = false, bool NM = false>
+template <typename TO, int NCH, bool GS = false, int NM = 0>
 __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs a, const int npatch) {
     typedef bf16_t T;
     static_assert(!GS || sizeof(TO) == 2, "the gsum epilogue of this kernel is the LDS-staged bf16 one");
@@ -1126,8 +1163,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     // ---- weights -> registers: lane (l31, h) holds W[tap][n][c*32 + kk*16 + 8h .. +7] for its column n
     const int ncol = n0 + wn * 32 + l31;
     bf16x8 bw[9][NCH][2];
-    {
-        const bf16_t* wp = (const bf16_t*)a.w;
+    float bias;
+    // (NM, SHM_NORM_SCALED: the weight copy and the bias row of image `img`, see tapgemm_wreg_f32_kernel)
+    auto load_w = [&](int img) {
+        const bf16_t* wp = (const bf16_t*)a.w + (NM == 2 ? (size_t)img * (a.wimg >> 1) : (size_t)0);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1138,8 +1177,9 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     if (ncol < a.nout) v = *(const bf16x8*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * 32 + kk * 16 + h * 8);
                     bw[t][c][kk] = v;
                 }
-    }
-    const float bias = (a.bias && ncol < a.nout) ? a.bias[ncol] : 0.f;
+        bias = (a.bias && ncol < a.nout) ? a.bias[(NM == 2 ? (size_t)img * a.bias_img : (size_t)0) + ncol] : 0.f;
+    };
+    load_w(NM == 2 ? q0 / ppi : 0);
 
     // ---- halo DMA: item it (0 .. NIT*NCH-1) = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w+4, ...
     // NIT / 4 = 3 items per wave and chunk: item j of chunk c covers halo rows 16 (wave + 4 j) + drow, so the lane keeps
@@ -1154,8 +1194,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF + wave * 256;
-        if constexpr (NM)              // 3 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
+        if constexpr (NM)              // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
         int dr = drow;
         asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
 #pragma unroll
@@ -1176,6 +1216,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     [[maybe_unused]] auto norm_a = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        if (NM == 2 && !(y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)) return;       // block-uniform: no out-of-image halo entry
         float* dst = smem + buf * ABUF + wave * 256 + lane * 4;
         int dr = drow;
         asm volatile("" : "+v"(dr));        // as in dma(): nothing of this is kept across the MFMA loop
@@ -1184,7 +1225,26 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             const int hrow = 16 * (wave + 4 * j) + dr;
             const int hr = hrow / HC, hc = hrow - hr * HC;
             const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-            if (hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+            const bool inside = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+            if constexpr (NM == 2) {                // SHM_NORM_SCALED: `ring` over the out-of-image entries (see tapgemm_halo_kernel)
+                if (hrow < (PH + 2) * HC && !inside) {
+                    const int g8 = (dq ^ (((hrow >> 1) + hr) & 3)) << 3;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float* tb = tbl + 3 * a.ntc + c * 32 + g8;
+                        const f32x4 r0 = *(const f32x4*)tb, r1 = *(const f32x4*)(tb + 4);
+                        u32x4 x;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            x[e] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r0[2 * e]) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r0[2 * e + 1]) << 16);
+                            x[2 + e] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r1[2 * e]) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)r1[2 * e + 1]) << 16);
+                        }
+                        *(u32x4*)(dst + c * ASTG + j * 4 * 256) = x;
+                    }
+                }
+            } else if (hrow < (PH + 2) * HC && inside) {
                 const int g8 = (dq ^ (((hrow >> 1) + hr) & 3)) << 3;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -1243,7 +1303,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     // was measured with delays of 1300-5800 clocks: no effect.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (NM) norm_a(q0, 0);
-    for (int q = q0; q < q1; ++q) {
+    auto patch = [&](const int q) {
         const int buf = (q - q0) & 1;
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave (each waited for its own part at the end
         asm volatile("" ::: "memory");                  // of the previous patch); everyone is done with the other buffer
@@ -1317,7 +1377,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     const bf16_t vo = (bf16_t)fmaxf(u, u * a.slope);      // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                     const float v = (float)vo;
                     s1 += v;
-                    s2 += v * v;
+                    s2 = __builtin_fmaf(v, v, s2);
                     tile[row * 32 + l31] = __builtin_bit_cast(unsigned short, vo);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same-wave LDS hand-off
@@ -1420,7 +1480,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     const float u = acc[i][r];
                     const float v = fmaxf(u, u * a.slope);
                     s1 += v;
-                    s2 += v * v;
+                    s2 = __builtin_fmaf(v, v, s2);
                     if (__builtin_amdgcn_readfirstlane(n0 + wn * 32) < a.n1) {        // wave-uniform (n1 % 32 == 0): no waterfall loop
                         if (ncol < a.nout)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
@@ -1446,6 +1506,16 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (NM)
             if (q + 1 < q1) norm_a(q + 1, buf ^ 1);
+    };
+    if constexpr (NM == 2) {                 // one weight copy per image -> one segment of the patch range per image
+        int q = q0;
+        while (q < q1) {
+            const int qe = min(q1, (q / ppi + 1) * ppi);
+            if (q != q0) load_w(q / ppi);
+            for (; q < qe; ++q) patch(q);
+        }
+    } else {
+        for (int q = q0; q < q1; ++q) patch(q);
     }
     if (a.stats) flush(simg);
 }
@@ -1467,7 +1537,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // NM: "norm" (see tapgemm_halo_kernel) -- the source is the un-normalised activation of an InstanceNorm block; a wave normalises
 // the halo items it DMA'd itself at the end of the patch in front (they have landed by then), from its own 1 KiB copy of the
 // image's (mean, inv, beta) planes, which travels with the halo DMA.
-template <int NCH, int WN = 4, bool TWO = false, bool GS = false, bool NM = false>
+template <int NCH, int WN = 4, bool TWO = false, bool GS = false, int NM = 0>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
     static_assert(!NM || (!TWO && !GS), "norm: one source, forward form");
     // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
@@ -1496,14 +1566,18 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     // contracts channel 4 k' + e of the chunk over k' = lane >> 4 (the same permutation on the A side)
     const int ncol = n0 + wn * 16 + l15;
     f32x4 bw[9][NCH];
-    {
-        const float* wp = (const float*)a.w;
+    float bias;
+    // (NM = 2, SHM_NORM_SCALED: the weight copy and the bias row of image `img`, re-read when the block's patch range moves on to the
+    // next image -- outside the patch loop, so that hipcc's waitcnt pass drains these loads in the loop's preheader, not at every use)
+    auto load_w = [&](int img) {
+        const float* wp = (const float*)a.w + (NM == 2 ? (size_t)img * (a.wimg >> 2) : (size_t)0);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) bw[t][c] = *(const f32x4*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * 16 + lq * 4);
-    }
-    const float bias = a.bias ? a.bias[ncol] : 0.f;
+        bias = a.bias ? a.bias[(NM == 2 ? (size_t)img * a.bias_img : (size_t)0) + ncol] : 0.f;
+    };
+    load_w(NM == 2 ? q0 / ppi : 0);
 
     // ---- halo DMA: item it = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w + 8, ...
     const int drow = lane >> 2, dq = lane & 3;
@@ -1517,8 +1591,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF;
-        if constexpr (NM)              // 3 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 12u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
+        if constexpr (NM)              // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int it = wave + 8 * j;                 // wave-uniform
@@ -1546,6 +1620,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     [[maybe_unused]] auto norm_a = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+        if (NM == 2 && !(y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)) return;       // block-uniform: no out-of-image halo entry
         int ln = lane;
         asm volatile("" : "+v"(ln));        // recompute the lane's coordinates per call: hoisted out of the patch loop they would stay live across the MFMAs
         const int drow = ln >> 2, dq = ln & 3;
@@ -1558,7 +1633,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 const int hrow = 16 * ri + drow;
                 const int hr = hrow / HC, hc = hrow - hr * HC;
                 const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-                if (hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+                const bool inside = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+                if constexpr (NM == 2) {            // SHM_NORM_SCALED: `ring` over the out-of-image entries (see tapgemm_halo_kernel)
+                    if (hrow < (PH + 2) * HC && !inside) *(f32x4*)(dst + it * 256) = *(const f32x4*)(tbl + 3 * a.ntc + c * 16 + (((dq - (hrow >> 1)) & 3) << 2));
+                } else if (hrow < (PH + 2) * HC && inside) {
                     const float* tb = tbl + c * 16 + (((dq - (hrow >> 1)) & 3) << 2);
                     f32x4 x = *(const f32x4*)(dst + it * 256);
                     const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
@@ -1612,7 +1690,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     dma(q0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (NM) norm_a(q0, 0);
-    for (int q = q0; q < q1; ++q) {
+    auto patch = [&](const int q) {
         const int buf = (q - q0) & 1;
         SHM_LDS_BARRIER();                   // halo(q) landed for every wave; everyone is done with the other buffer
         asm volatile("" ::: "memory");
@@ -1680,7 +1758,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 const float v = fmaxf(u, u * a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                 s1 += v;
                 if constexpr (GS) s2 += v * gq[m][r];
-                else s2 += v * v;
+                else s2 = __builtin_fmaf(v, v, s2);
                 const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
                 // the wave's 16 channels lie in one output part (n1 % 16 == 0): a scalar branch -- a per-lane choice of the buffer
                 // descriptor makes hipcc wrap every store in a readfirstlane (waterfall) loop
@@ -1696,6 +1774,16 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         if constexpr (NM)
             if (q + 1 < q1) norm_a(q + 1, buf ^ 1);
+    };
+    if constexpr (NM == 2) {                 // one weight copy per image -> one segment of the patch range per image
+        int q = q0;
+        while (q < q1) {
+            const int qe = min(q1, (q / ppi + 1) * ppi);
+            if (q != q0) load_w(q / ppi);
+            for (; q < qe; ++q) patch(q);
+        }
+    } else {
+        for (int q = q0; q < q1; ++q) patch(q);
     }
     if (GS || a.stats) flush(simg);
 }
@@ -1939,7 +2027,7 @@ static thread_local bool g_gsum_fused = false;
 // launcher goes through its variant choice, records whether that kernel can normalise its source in LDS, and launches nothing
 struct NormReq {
     const float* nt;
-    int part, c;
+    int part, c, mode;
     bool query, query_ok;
 };
 static thread_local NormReq g_norm = {};
@@ -2118,12 +2206,17 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         if (gs_fused)
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
         else if (want_nm) {
-            if constexpr (sizeof(T) == sizeof(TO))
-                hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, false, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+            if constexpr (sizeof(T) == sizeof(TO)) {
+                if (a.ntmode)
+                    hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, false, 2>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+                else
+                    hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true, 2, false, 1>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
+            }
         } else
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 128, 16, true>), dim3(npatch, shm_cdiv(a.nout, 128), 1), dim3(512), 0, st, a);
         shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, true>"
-                            : want_nm ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, false, true>" : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
+                            : want_nm ? (a.ntmode ? "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, false, 2>" : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2, false, 1>")
+                                      : "tapgemm_halo_kernel<%s, %s, 128, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_ST_W4:
         SHM_REQUIRE(halo_ok, SHM_E_SHAPE, "%s: forced variant halo128/static-taps/4 waves needs a unit-stride 3x3 layer on a map that is a multiple of 16", who);
@@ -2135,12 +2228,17 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         if (gs_fused)
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
         else if (want_nm) {
-            if constexpr (sizeof(T) == sizeof(TO))
-                hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, false, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+            if constexpr (sizeof(T) == sizeof(TO)) {
+                if (a.ntmode)
+                    hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, false, 2>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true, 2, false, 1>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
+            }
         } else
             hipLaunchKernelGGL((tapgemm_halo_kernel<T, TO, 64, 16, true>), dim3(npatch, shm_cdiv(a.nout, 64), 1), dim3(256), 0, st, a);
         shm_set_last_kernel(gs_fused ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, true>"
-                            : want_nm ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, false, true>" : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
+                            : want_nm ? (a.ntmode ? "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, false, 2>" : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2, false, 1>")
+                                      : "tapgemm_halo_kernel<%s, %s, 64, 16, true, 2>", tn, ton);
         break;
     case SHM_TG_HALO128_PH8:
         // 8-row patches (3 four-wave blocks per CU, 4-wave barriers): measured equal or slower than 16-row patches in
@@ -2184,17 +2282,22 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
                     hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             }
             if constexpr (sizeof(TO) == 2) {
-                if (want_nm && a.K == 64)
-                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2, false, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                if (want_nm && a.K == 64 && a.ntmode)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2, false, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                else if (want_nm && a.K == 64)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2, false, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                else if (want_nm && a.ntmode)
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, false, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
                 else if (want_nm)
-                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, false, true>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+                    hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, false, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             }
             if (gs_fused || want_nm) {
             } else if (a.K == 64)
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             else
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
-            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>" : want_nm ? "tapgemm_wreg_kernel<%s, %d, false, true>" : "tapgemm_wreg_kernel<%s, %d>",
+            shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>"
+                                : want_nm ? (a.ntmode ? "tapgemm_wreg_kernel<%s, %d, false, 2>" : "tapgemm_wreg_kernel<%s, %d, false, 1>") : "tapgemm_wreg_kernel<%s, %d>",
                                 ton, a.K / 32);
         } else if constexpr (sizeof(TO) == 4) {
             // one 8-wave block per CU; patches of 8 (64 channels per block), 16 (32) or 32 (16) rows
@@ -2223,17 +2326,20 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         if (attr == hipSuccess)                                                                                                          \
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);           \
     } while (0)
-#define SHM_WREG32_LAUNCH_NM(NCH_)                                                                                                       \
+#define SHM_WREG32_LAUNCH_NM(NCH_, MODE_)                                                                                                \
     do {                                                                                                                                 \
-        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, false, true>,             \
+        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, false, MODE_>,            \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * 12 * 1024 + 8 * 1024);  \
         attr = at_;                                                                                                                      \
         if (attr == hipSuccess)                                                                                                          \
-            hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);    \
+            hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, false, MODE_>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);   \
     } while (0)
-            if (want_nm && nch == 4) SHM_WREG32_LAUNCH_NM(4);
-            else if (want_nm && nch == 2) SHM_WREG32_LAUNCH_NM(2);
-            else if (want_nm) SHM_WREG32_LAUNCH_NM(1);
+            if (want_nm && nch == 4 && a.ntmode) SHM_WREG32_LAUNCH_NM(4, 2);
+            else if (want_nm && nch == 4) SHM_WREG32_LAUNCH_NM(4, 1);
+            else if (want_nm && nch == 2 && a.ntmode) SHM_WREG32_LAUNCH_NM(2, 2);
+            else if (want_nm && nch == 2) SHM_WREG32_LAUNCH_NM(2, 1);
+            else if (want_nm && a.ntmode) SHM_WREG32_LAUNCH_NM(1, 2);
+            else if (want_nm) SHM_WREG32_LAUNCH_NM(1, 1);
             else if (gs_fused && nch == 4) SHM_WREG32_LAUNCH_GS(4);
             else if (gs_fused && nch == 2) SHM_WREG32_LAUNCH_GS(2);
             else if (gs_fused) SHM_WREG32_LAUNCH_GS(1);
@@ -2251,7 +2357,8 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
 #undef SHM_WREG32_LAUNCH_NM
             SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, lds, hipGetErrorString(attr));
             shm_set_last_kernel(gs_fused ? "tapgemm_wreg_f32_kernel<%d, %d, %s, true>"
-                                : want_nm ? "tapgemm_wreg_f32_kernel<%d, %d, %s, false, true>" : "tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn,
+                                : want_nm ? (a.ntmode ? "tapgemm_wreg_f32_kernel<%d, %d, %s, false, 2>" : "tapgemm_wreg_f32_kernel<%d, %d, %s, false, 1>")
+                                          : "tapgemm_wreg_f32_kernel<%d, %d, %s>", nch, wreg32_wn,
                                 a.x2 ? "true" : "false");
         }
         break;
@@ -2312,7 +2419,10 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
     a.nt = g_norm.nt;
     a.ntpart = g_norm.part;
     a.ntc = g_norm.c;
-    a.ntbytes = (unsigned)((size_t)batch * 3 * g_norm.c * sizeof(float));
+    a.ntmode = g_norm.mode;
+    a.ntbytes = (unsigned)((size_t)batch * SHM_NT_PLANES * g_norm.c * sizeof(float));
+    a.wimg = 0;
+    a.bias_img = 0;
     g_gsum_fused = false;
     if (a.gred[0] || a.gred[1]) {
         SHM_REQUIRE(a.stats == nullptr, SHM_E_SHAPE, "%s: fused forward statistics and gsum are exclusive", who);
@@ -2335,6 +2445,12 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
                 size_t e = (size_t)(a.ph[p].widx[t] + 1) * a.nout * a.K * esz;
                 if (e > wb) wb = e;
             }
+        if (a.nt && a.ntmode) {                   // SHM_NORM_SCALED: one weight copy and one bias row per sample
+            SHM_REQUIRE(nphase == 1 && a.bias, SHM_E_SHAPE, "%s: SHM_NORM_SCALED takes per-sample weights AND per-sample bias rows", who);
+            a.wimg = (unsigned)((size_t)a.ph[0].ntaps * a.nout * a.K * esz);
+            a.bias_img = a.nout;
+            wb = (size_t)batch * a.wimg;
+        }
         SHM_REQUIRE(xb < lim && x2b < lim && wb < lim, SHM_E_SHAPE, "%s: operand larger than 4 GiB (32-bit buffer offsets)", who);
         a.xbytes = (unsigned)xb;
         a.x2bytes = (unsigned)x2b;
@@ -2457,6 +2573,53 @@ extern "C" int shm_transpose_taps_multi(int count, const void* const* w, void* c
 }
 
 // ------------------------------------------------------------------------------------
+// SHM_NORM_SCALED operands of a convolution whose source part [part_lo, part_lo + c) is the un-normalised activation a of an
+// InstanceNorm block with table nt (common.h): conv(w, (a - mean) * inv + beta) = conv(w * inv, a) + sum w * (beta - mean * inv) inside
+// the image, so per sample n
+//   wk_n[n][tap][co][k] = wk[tap][co][k] * inv_n[k - part_lo]  (k in the part; the other channels are copied)
+//   bias_n[n][co]       = bias[co] + sum_{tap, k in part} wk[tap][co][k] * (beta[k'] - mean_n[k'] * inv_n[k'])
+// (the kernels write `ring` over out-of-image taps, whose product with the scaled weight cancels that tap's share of bias_n).
+// One block per (co, sample).
+template <typename T>
+__global__ __launch_bounds__(256) void norm_prepare_kernel(const T* __restrict__ wk, const float* __restrict__ bias, const float* __restrict__ nt, int c,
+                                                           int part_lo, T* __restrict__ wk_n, float* __restrict__ bias_n, int ntaps, int cout, int K) {
+    const int co = blockIdx.x, n = blockIdx.y;
+    const float* mean = nt + (size_t)n * SHM_NT_PLANES * c;
+    const float *inv = mean + c, *beta = mean + 2 * c;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < ntaps * K; i += 256) {
+        const int tap = i / K, k = i - tap * K;
+        const size_t src = ((size_t)tap * cout + co) * K + k;
+        const float w = (float)wk[src];
+        float o = w;
+        const int kp = k - part_lo;
+        if (kp >= 0 && kp < c) {
+            o = w * inv[kp];
+            acc += w * (beta[kp] - mean[kp] * inv[kp]);
+        }
+        wk_n[(size_t)n * ntaps * cout * K + src] = (T)o;
+    }
+    __shared__ float red[4];
+    acc = shm_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bias_n[(size_t)n * cout + co] = (bias ? bias[co] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+extern "C" int shm_conv2d_norm_prepare(const void* wk, const float* bias, const float* nt, int c, int part_lo, void* wk_n, float* bias_n, int batch,
+                                       int cin, int cout, int ksize, int dtype, void* stream) {
+    SHM_REQUIRE(wk && nt && wk_n && bias_n, SHM_E_SHAPE, "shm_conv2d_norm_prepare: null pointer");
+    SHM_REQUIRE(ksize == 1 || ksize == 3, SHM_E_SHAPE, "shm_conv2d_norm_prepare: ksize %d not in {1,3}", ksize);
+    SHM_REQUIRE(c > 0 && part_lo >= 0 && part_lo + c <= cin, SHM_E_SHAPE, "shm_conv2d_norm_prepare: part [%d, %d) outside %d channels", part_lo, part_lo + c, cin);
+    if (batch == 0 || cout == 0) return SHM_OK;
+    SHM_DISPATCH(dtype, "shm_conv2d_norm_prepare",
+                 hipLaunchKernelGGL(norm_prepare_kernel<T>, dim3(cout, batch), dim3(256), 0, (hipStream_t)stream, (const T*)wk, bias, nt, c, part_lo, (T*)wk_n,
+                                    bias_n, ksize * ksize, cout, cin));
+    SHM_LAUNCH_CHECK("shm_conv2d_norm_prepare");
+    return SHM_OK;
+}
+
+// ------------------------------------------------------------------------------------
 extern "C" int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                               const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                               int cout, int ksize, int stride, float slope, int dtype, void* stream) {
@@ -2507,8 +2670,8 @@ extern "C" int shm_conv2d_in_fwd(const void* x, const void* x2, int c1, int ldx,
                                  const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                                  int cout, int ksize, int stride, float slope, double* stats, double* scratch,
                                  float eps, int dtype, void* stream) {
-    return shm_conv2d_in_fwd_norm(x, x2, c1, ldx, ldx2, nullptr, nullptr, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, scratch,
-                                  eps, nullptr, nullptr, dtype, stream);
+    return shm_conv2d_in_fwd_norm(x, x2, c1, ldx, ldx2, nullptr, nullptr, SHM_NORM_EXACT, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats,
+                                  scratch, eps, nullptr, nullptr, dtype, stream);
 }
 
 // Does the kernel that shm_conv2d_in_fwd_norm would run for this shape normalise its source in LDS?  A dry run of the launcher's
@@ -2534,10 +2697,12 @@ extern "C" int shm_conv2d_norm_supported(int batch, int hi, int wi, int cin, int
     return ok ? 1 : 0;
 }
 
-extern "C" int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* wk,
-                                      const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin, int cout, int ksize, int stride, float slope,
-                                      double* stats, double* scratch, float eps, float* nt_out, const float* beta_out, int dtype, void* stream) {
+extern "C" int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, int norm_mode,
+                                      const void* wk, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin, int cout, int ksize,
+                                      int stride, float slope, double* stats, double* scratch, float eps, float* nt_out, const float* beta_out, int dtype,
+                                      void* stream) {
     SHM_REQUIRE(stats, SHM_E_SHAPE, "shm_conv2d_in_fwd: null stats");
+    SHM_REQUIRE(norm_mode == SHM_NORM_EXACT || norm_mode == SHM_NORM_SCALED, SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: norm_mode %d", norm_mode);
     SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: at most one source can be normalised on the fly");
     SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: nt_x2 without a second source");
     SHM_REQUIRE(!nt_out || beta_out, SHM_E_SHAPE, "shm_conv2d_in_fwd_norm: nt_out needs beta_out");
@@ -2553,6 +2718,7 @@ extern "C" int shm_conv2d_in_fwd_norm(const void* x, const void* x2, int c1, int
         g_norm.nt = nt_x ? nt_x : nt_x2;
         g_norm.part = nt_x ? 0 : 1;
         g_norm.c = x2 ? (nt_x ? c1 : cin - c1) : cin;
+        g_norm.mode = norm_mode;
     }
     if (!shm_tune(SHM_TUNE_STATS_FUSION) || hw % 64 != 0) {       // tiny maps: separate statistics pass
         int r = shm_conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, dtype, stream);

@@ -464,8 +464,12 @@ struct WgradHaloArgs {
     int h, w, cin_ld, cin, cout;
     int npatch, patches_per_split;
     unsigned xbytes, x2bytes, dybytes;
-    // "norm" (shm_conv2d_wgrad_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation of an InstanceNorm block; the
-    // kernels apply shm_in_norm to its halo pixels in LDS, from nt = float [batch][3][ntc] (mean, inv, beta): see tapgemm_halo_kernel
+    // "norm" (shm_conv2d_wgrad_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation a of an InstanceNorm block with
+    // table nt = float [batch][4][ntc] (mean, inv, beta, ring).  SHM_NORM_EXACT (kernels <1>): shm_in_norm on its halo pixels in LDS, see
+    // tapgemm_halo_kernel.  SHM_NORM_SCALED (kernels <2>): sum x_hat * dz = inv * sum a_ext * dz + (beta - mean * inv) * sum dz with
+    // a_ext = a inside the image and `ring` outside -- the kernels write `ring` over the out-of-image halo entries of border patches and
+    // scale the rows of their slab by inv (a block's patches lie in ONE sample: the launcher cuts the splits that way); the second
+    // term is shm_conv2d_wgrad_norm_finish's.
     const float* nt;
     int ntpart, ntc;
 };
@@ -483,7 +487,7 @@ __device__ __forceinline__ f32x4 load16_drained(const float* p) {
 // NM: a wave normalises the halo items it DMA'd itself, one stage ahead of their use.  A lane's four channels are the same for
 // every item and patch (no swizzle in this image), so their (mean, inv, beta) live in registers and are re-read when the image
 // changes (at most a few times per block).
-template <bool NM = false>
+template <int NM = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs a) {
     constexpr int PW = 16, HC = PW + 2;                 // patch 2 x 16, halo 4 x 18
     constexpr int NHP = 4 * HC, NPX = 2 * PW;           // 72 halo pixels, 32 output pixels
@@ -572,17 +576,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
     [[maybe_unused]] int n2 = n, pr2 = pr, pc2 = pc, nimg = -1;
     [[maybe_unused]] f32x4 nmean = {0.f, 0.f, 0.f, 0.f}, ninv = nmean, nbeta = nmean;
     // One straight-line piece per stage (interior patches: no per-lane tests).
+    const int n_blk = n;                                    // NM = 2: the sample of this block's patches
     [[maybe_unused]] auto norm_x = [&](int stage) {
         if (n2 != nimg) {                                   // block-uniform
             nimg = n2;
             if (xvalid) {
-                const float* t = a.nt + (size_t)n2 * 3 * a.ntc + ccX;
-                nmean = load16_drained(t);
-                ninv = load16_drained(t + a.ntc);
-                nbeta = load16_drained(t + 2 * a.ntc);
+                const float* t = a.nt + (size_t)n2 * SHM_NT_PLANES * a.ntc + ccX;
+                if constexpr (NM == 2) {
+                    nbeta = load16_drained(t + 3 * a.ntc);              // ring
+                } else {
+                    nmean = load16_drained(t);
+                    ninv = load16_drained(t + a.ntc);
+                    nbeta = load16_drained(t + 2 * a.ntc);
+                }
             }
         }
         float* sx = smem + stage * STAGE + lane * 4;
+        if constexpr (NM == 2) {
+            // SHM_NORM_SCALED: `ring` over the out-of-image halo entries of a border patch; nothing to do inside the image
+            if (!(pr2 > 0 && pr2 + 2 < a.h && pc2 > 0 && pc2 + PW < a.w)) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int item = wave + 4 * j;
+                    if (item < 18) {
+                        const int iy = pr2 - 1 + hr[j], ix = pc2 - 1 + hc[j];
+                        if (xvalid && !((unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w)) *(f32x4*)(sx + item * 256) = nbeta;
+                    }
+                }
+            }
+        } else
         // interior patch (the whole 4 x 18 halo inside the image) of a full 64-channel tile: every lane of every item normalises, no
         // per-lane tests -- block-uniform, 7 of 8 patches of a 256 x 256 map
         if (pr2 > 0 && pr2 + 2 < a.h && pc2 > 0 && pc2 + PW < a.w && ci0 + 64 <= a.cin_ld) {
@@ -695,6 +717,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
         }
     }
 
+    // NM = 2: the slab's rows times inv of the block's sample (row r of a lane: channel ci0 + 32 mi + (r & 3) + 8 (r >> 2) + 4 hh)
+    if constexpr (NM == 2)
+        if (nm_on) {
+            const float* iv = a.nt + ((size_t)n_blk * SHM_NT_PLANES + 1) * a.ntc + (ci0 - (second ? a.c1 : 0)) + mi * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 s4 = *(const f32x4*)(iv + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][4 * g + e] *= s4[e];
+            }
+        }
     float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
     const int con = co0 + ni * 32 + l31;
 #pragma unroll
@@ -866,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_thin_kernel(const WgradHalo
 // q + kh, so a stage of R rows needs (R + 2) x 3 fragment reads for 9 R MFMAs (hipcc keeps the shared ones in registers):
 // R = 4 reads 22 fragments per 36 MFMAs where two R = 2 stages read 28, with half the barriers and 3/4 of the halo bytes.
 // NM: as in wgrad_halo_kernel (a lane's eight channels are the same for every item and patch: 24 table registers).
-template <int R, bool NM = false>
+template <int R, int NM = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
     constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
     constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows (14 KiB); R = 4: 120 + 64 (23 KiB)
@@ -954,21 +989,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
     const bool nm_on = NM && a.nt != nullptr && (int)second == a.ntpart;        // block-uniform
     [[maybe_unused]] int n2 = n, pr2 = pr, pc2 = pc, nimg = -1;
     [[maybe_unused]] f32x4 nmean[2] = {}, ninv[2] = {}, nbeta[2] = {};
+    const int n_blk = n;                                    // NM = 2: the sample of this block's patches
     [[maybe_unused]] auto norm_x = [&](int stage) {
         if (n2 != nimg) {                                   // block-uniform
             nimg = n2;
             if (xvalid) {
-                const float* t = a.nt + (size_t)n2 * 3 * a.ntc + ccX;
+                const float* t = a.nt + (size_t)n2 * SHM_NT_PLANES * a.ntc + ccX;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    nmean[hf] = load16_drained(t + 4 * hf);
-                    ninv[hf] = load16_drained(t + a.ntc + 4 * hf);
-                    nbeta[hf] = load16_drained(t + 2 * a.ntc + 4 * hf);
+                    if constexpr (NM == 2) {
+                        nbeta[hf] = load16_drained(t + 3 * a.ntc + 4 * hf);        // ring
+                    } else {
+                        nmean[hf] = load16_drained(t + 4 * hf);
+                        ninv[hf] = load16_drained(t + a.ntc + 4 * hf);
+                        nbeta[hf] = load16_drained(t + 2 * a.ntc + 4 * hf);
+                    }
                 }
             }
         }
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         unsigned short* sx = smem + stage * STAGE + lane * 8;
+        if constexpr (NM == 2) {
+            // SHM_NORM_SCALED: `ring` over the out-of-image halo entries of a border patch (the two dummy columns of the pitch stay zero)
+            if (!(pr2 > 0 && pr2 + R < a.h && pc2 > 0 && pc2 + PW < a.w)) {
+                u32x4_t rg;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        rg[2 * hf + e] = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)nbeta[hf][2 * e]) |
+                                         ((unsigned)__builtin_bit_cast(unsigned short, (bf16_t)nbeta[hf][2 * e + 1]) << 16);
+#pragma unroll
+                for (int j = 0; j < NXJ; ++j) {
+                    const int item = wave + 4 * j;
+                    if (item < NXI) {
+                        const int iy = pr2 - 1 + hr[j], ix = pc2 - 1 + hc[j];
+                        if (xvalid && hc[j] < PW + 2 && !((unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w)) *(u32x4_t*)(sx + item * 512) = rg;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
             const int item = wave + 4 * j;
@@ -988,6 +1048,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
                     *(u32x4_t*)(sx + item * 512) = x;
                 }
             }
+        }
         }
         pc2 += PW;
         if (pc2 == a.w) {
@@ -1071,6 +1132,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         }
     }
 
+    // NM = 2: the slab's rows times inv of the block's sample (see wgrad_halo_kernel)
+    if constexpr (NM == 2)
+        if (nm_on) {
+            const float* iv = a.nt + ((size_t)n_blk * SHM_NT_PLANES + 1) * a.ntc + (ci0 - (second ? a.c1 : 0)) + mi * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 s4 = *(const f32x4*)(iv + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][4 * g + e] *= s4[e];
+            }
+        }
     float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
     const int con = co0 + ni * 32 + l31;
 #pragma unroll
@@ -1158,9 +1232,18 @@ extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin,
 // norm request of shm_conv2d_wgrad_norm around its launch (WgradHaloArgs::nt); query = shm_conv2d_wgrad_norm_supported's dry run
 struct WNormReq {
     const float* nt;
-    int part, c;
+    int part, c, mode;
     bool query, query_ok;
 };
+
+// SHM_NORM_SCALED: a block's patches must lie in one sample -- the largest divisor of the patches per image that does not exceed
+// the split the automatic choice would take
+static int wgrad_norm_aligned_pps(int pps, int ppi) {
+    int d = pps > ppi ? ppi : pps;
+    if (d < 1) d = 1;
+    while (ppi % d) --d;
+    return d;
+}
 static thread_local WNormReq g_wnorm = {};
 
 // Phase 1 of shm_conv2d_wgrad: the MFMA kernel; *nsplit_out receives the number of partial slabs written.
@@ -1262,7 +1345,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.npatch = batch * (hi / rows) * (wi / 16);
         int nsh = ns < hgs.npatch ? ns : hgs.npatch;
         hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        if (want_nm && g_wnorm.mode) hgs.patches_per_split = wgrad_norm_aligned_pps(hgs.patches_per_split, (hi / rows) * (wi / 16));
         nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        SHM_REQUIRE(ws_bytes >= (size_t)nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE,
+                    "shm_conv2d_wgrad: workspace %zu < %zu bytes (SHM_NORM_SCALED: shm_conv2d_wgrad_norm_workspace)", ws_bytes, (size_t)nsh * 9 * cin * cout * sizeof(float));
         hgs.xbytes = a.xbytes;
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
@@ -1270,22 +1356,32 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.ntpart = g_wnorm.part;
         hgs.ntc = g_wnorm.c;
         ns = nsh;
+        const int nmode = want_nm ? 1 + g_wnorm.mode : 0;
+        const dim3 gridb(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh);
         if (rows == 4) {
             constexpr unsigned kLds = 3u * (6 * 20 + 4 * 16) * 128u;      // 69 KiB
             static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-            static const hipError_t attrn = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-            SHM_REQUIRE(attr == hipSuccess && attrn == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s",
-                        hipGetErrorString(attr == hipSuccess ? attrn : attr));
-            if (want_nm)
-                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
+            static const hipError_t attr1 = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            static const hipError_t attr2 = hipFuncSetAttribute((const void*)wgrad_halo_bf16_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            SHM_REQUIRE(attr == hipSuccess && attr1 == hipSuccess && attr2 == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s",
+                        hipGetErrorString(attr != hipSuccess ? attr : attr1 != hipSuccess ? attr1 : attr2));
+            if (nmode == 2)
+                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4, 2>), gridb, dim3(256), kLds, st, hgs);
+            else if (nmode == 1)
+                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4, 1>), gridb, dim3(256), kLds, st, hgs);
             else
-                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), kLds, st, hgs);
-        } else if (want_nm) {
-            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
+                hipLaunchKernelGGL((wgrad_halo_bf16_kernel<4>), gridb, dim3(256), kLds, st, hgs);
+        } else if (nmode == 2) {
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2, 2>), gridb, dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
+        } else if (nmode == 1) {
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2, 1>), gridb, dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
         } else {
-            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
+            hipLaunchKernelGGL((wgrad_halo_bf16_kernel<2>), gridb, dim3(256), 3u * (4 * 20 + 2 * 16) * 128u, st, hgs);
         }
-        shm_set_last_kernel(want_nm ? "wgrad_halo_bf16_kernel<%d, true>" : "wgrad_halo_bf16_kernel<%d>", rows);
+        if (nmode)
+            shm_set_last_kernel("wgrad_halo_bf16_kernel<%d, %d>", rows, nmode);
+        else
+            shm_set_last_kernel("wgrad_halo_bf16_kernel<%d>", rows);
     } else if (dtype == SHM_BF16) {
         dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
         if (ksize == 3) {
@@ -1347,7 +1443,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.npatch = batch * (hi / 2) * (wi / 16);
         int nsh = ns < hgs.npatch ? ns : hgs.npatch;
         hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        if (want_nm && g_wnorm.mode) hgs.patches_per_split = wgrad_norm_aligned_pps(hgs.patches_per_split, (hi / 2) * (wi / 16));
         nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        SHM_REQUIRE(ws_bytes >= (size_t)nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE,
+                    "shm_conv2d_wgrad: workspace %zu < %zu bytes (SHM_NORM_SCALED: shm_conv2d_wgrad_norm_workspace)", ws_bytes, (size_t)nsh * 9 * cin * cout * sizeof(float));
         hgs.xbytes = a.xbytes;
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
@@ -1362,11 +1461,13 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.nt = g_wnorm.nt;
         hgs.ntpart = g_wnorm.part;
         hgs.ntc = g_wnorm.c;
-        if (want_nm)
-            hipLaunchKernelGGL(wgrad_halo_kernel<true>, gridh, dim3(256), 0, st, hgs);
+        if (want_nm && g_wnorm.mode)
+            hipLaunchKernelGGL(wgrad_halo_kernel<2>, gridh, dim3(256), 0, st, hgs);
+        else if (want_nm)
+            hipLaunchKernelGGL(wgrad_halo_kernel<1>, gridh, dim3(256), 0, st, hgs);
         else
-            hipLaunchKernelGGL(wgrad_halo_kernel<false>, gridh, dim3(256), 0, st, hgs);
-        shm_set_last_kernel(want_nm ? "wgrad_halo_kernel<true>" : "wgrad_halo_kernel");
+            hipLaunchKernelGGL(wgrad_halo_kernel<0>, gridh, dim3(256), 0, st, hgs);
+        shm_set_last_kernel(want_nm ? (g_wnorm.mode ? "wgrad_halo_kernel<2>" : "wgrad_halo_kernel<1>") : "wgrad_halo_kernel");
         }
     } else {
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);
@@ -1423,15 +1524,60 @@ extern "C" int shm_conv2d_wgrad_norm_supported(int batch, int hi, int wi, int ci
     return ok ? 1 : 0;
 }
 
-extern "C" int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* dy,
-                                             int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride, void* workspace,
-                                             size_t ws_bytes, int dtype, int* nsplit_out, void* stream) {
+// Workspace of shm_conv2d_wgrad_norm(SHM_NORM_SCALED): the splits are cut on sample boundaries, which can take more slabs than
+// shm_conv2d_wgrad_workspace allows for.
+extern "C" size_t shm_conv2d_wgrad_norm_workspace(int batch, int hi, int wi, int cin, int cout, int ksize, int dtype) {
+    const int esz = dtype == SHM_BF16 ? 2 : 4;
+    const int ns = wgrad_splits(batch, hi, wi, cin, cout, esz);
+    const int rows = dtype == SHM_BF16 ? ((hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2) ? 4 : 2) : 2;
+    if (hi % rows || wi % 16) return shm_conv2d_wgrad_workspace(batch, hi, wi, cin, cout, ksize);
+    const int ppi = (hi / rows) * (wi / 16), npatch = batch * ppi;
+    const int nsh = ns < npatch ? ns : npatch;
+    const int pps = wgrad_norm_aligned_pps(shm_cdiv(npatch, nsh), ppi);
+    const size_t aligned = (size_t)shm_cdiv(npatch, pps) * ksize * ksize * cin * cout * sizeof(float);
+    const size_t plain = shm_conv2d_wgrad_workspace(batch, hi, wi, cin, cout, ksize);
+    return aligned > plain ? aligned : plain;
+}
+
+// SHM_NORM_SCALED, the second term of the weight gradient: dw[tap][part_lo + k][co] += sum_n (beta[k] - mean_n[k] * inv_n[k]) * dzsum[n][co]
+// for every tap (with `ring` in the out-of-image taps the sum over the pixels does not depend on the tap).  dzsum = per-sample channel
+// sums of dz (shm_in_bwd_keep_dz_sums).
+__global__ __launch_bounds__(256) void wgrad_norm_finish_kernel(float* __restrict__ dw, const float* __restrict__ nt, const double* __restrict__ dzsum, int batch,
+                                                                int c, int part_lo, int cin, int cout, int ntaps) {
+    const int co = blockIdx.x * 64 + (threadIdx.x & 63), k = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (co >= cout || k >= c) return;
+    double s = 0.0;
+    for (int n = 0; n < batch; ++n) {
+        const float* t = nt + (size_t)n * SHM_NT_PLANES * c + k;
+        s += ((double)t[2 * c] - (double)t[0] * (double)t[c]) * dzsum[(size_t)n * cout + co];
+    }
+    const float sf = (float)s;
+    for (int tap = 0; tap < ntaps; ++tap) dw[((size_t)tap * cin + part_lo + k) * cout + co] += sf;
+}
+
+extern "C" int shm_conv2d_wgrad_norm_finish(float* dw, const float* nt, const double* dzsum, int batch, int c, int part_lo, int cin, int cout, int ksize,
+                                            void* stream) {
+    SHM_REQUIRE(dw && nt && dzsum, SHM_E_SHAPE, "shm_conv2d_wgrad_norm_finish: null pointer");
+    SHM_REQUIRE(c > 0 && part_lo >= 0 && part_lo + c <= cin, SHM_E_SHAPE, "shm_conv2d_wgrad_norm_finish: part [%d, %d) outside %d channels", part_lo,
+                part_lo + c, cin);
+    if (batch == 0 || cout == 0) return SHM_OK;
+    hipLaunchKernelGGL(wgrad_norm_finish_kernel, dim3(shm_cdiv(cout, 64), shm_cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, dw, nt, dzsum, batch, c, part_lo,
+                       cin, cout, ksize * ksize);
+    SHM_LAUNCH_CHECK("shm_conv2d_wgrad_norm_finish");
+    return SHM_OK;
+}
+
+extern "C" int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, int norm_mode,
+                                             const void* dy, int lddy, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride,
+                                             void* workspace, size_t ws_bytes, int dtype, int* nsplit_out, void* stream) {
     SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_wgrad_norm: at most one source can be normalised on the fly");
     SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: nt_x2 without a second source");
+    SHM_REQUIRE(norm_mode == SHM_NORM_EXACT || norm_mode == SHM_NORM_SCALED, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: norm_mode %d", norm_mode);
     if (nt_x || nt_x2) {
         g_wnorm.nt = nt_x ? nt_x : nt_x2;
         g_wnorm.part = nt_x ? 0 : 1;
         g_wnorm.c = x2 ? (nt_x ? c1 : cin_ld - c1) : cin_ld;
+        g_wnorm.mode = norm_mode;
     }
     const int r = shm_conv2d_wgrad_partial(x, x2, c1, ldx, ldx2, dy, lddy, batch, hi, wi, cin, cin_ld, cout, ksize, stride, workspace, ws_bytes, dtype,
                                            nsplit_out, stream);
@@ -1441,15 +1587,17 @@ extern "C" int shm_conv2d_wgrad_partial_norm(const void* x, const void* x2, int 
 
 // shm_conv2d_wgrad on a source that is the UN-normalised activation of an InstanceNorm block (nt_x / nt_x2: that block's table, at
 // most one of the two)
-extern "C" int shm_conv2d_wgrad_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, const void* dy, int lddy,
-                                     float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride, int accumulate,
-                                     void* workspace, size_t ws_bytes, int dtype, void* stream) {
+extern "C" int shm_conv2d_wgrad_norm(const void* x, const void* x2, int c1, int ldx, int ldx2, const float* nt_x, const float* nt_x2, int norm_mode,
+                                     const void* dy, int lddy, float* dw, int batch, int hi, int wi, int cin, int cin_ld, int cout, int ksize, int stride,
+                                     int accumulate, void* workspace, size_t ws_bytes, int dtype, void* stream) {
     SHM_REQUIRE(!(nt_x && nt_x2), SHM_E_SHAPE, "shm_conv2d_wgrad_norm: at most one source can be normalised on the fly");
     SHM_REQUIRE(!nt_x2 || x2, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: nt_x2 without a second source");
+    SHM_REQUIRE(norm_mode == SHM_NORM_EXACT || norm_mode == SHM_NORM_SCALED, SHM_E_SHAPE, "shm_conv2d_wgrad_norm: norm_mode %d", norm_mode);
     if (nt_x || nt_x2) {
         g_wnorm.nt = nt_x ? nt_x : nt_x2;
         g_wnorm.part = nt_x ? 0 : 1;
         g_wnorm.c = x2 ? (nt_x ? c1 : cin_ld - c1) : cin_ld;
+        g_wnorm.mode = norm_mode;
     }
     const int r = shm_conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride, accumulate, workspace, ws_bytes, dtype,
                                    stream);

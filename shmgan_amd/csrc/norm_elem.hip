@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ a, 
 
 // part != null: the sums were accumulated over `nslot` slot copies part[slot][total][2]; the copies are zeroed
 // again as they are consumed, so the scratch is zero whenever no call is in flight (no memset per launch)
-// nt != null: also the float table [batch][3][c] = (mean, inv, beta) of the consumers that normalise on the fly (common.h)
+// nt != null: also the float table [batch][4][c] = (mean, inv, beta, ring) of the consumers that normalise on the fly (common.h)
 __global__ void in_finalize_kernel(double* __restrict__ stats, double* __restrict__ part, int nslot, int total, int hw, double eps, float* __restrict__ nt,
                                    const float* __restrict__ beta, int c) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,10 +247,11 @@ __global__ void in_finalize_kernel(double* __restrict__ stats, double* __restric
     stats[2 * i + 1] = inv;
     if (nt) {
         const int n = i / c, ch = i - n * c;
-        float* t = nt + (size_t)n * 3 * c + ch;
+        float* t = nt + (size_t)n * SHM_NT_PLANES * c + ch;
         t[0] = (float)mean;
         t[c] = (float)inv;
         t[2 * c] = beta[ch];
+        t[3 * c] = (float)mean - beta[ch] / (float)inv;
     }
 }
 
@@ -265,10 +266,11 @@ __global__ void in_norm_table_kernel(const double* __restrict__ stats, const flo
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int n = i / c, ch = i - n * c;
-    float* t = nt + (size_t)n * 3 * c + ch;
+    float* t = nt + (size_t)n * SHM_NT_PLANES * c + ch;
     t[0] = (float)stats[2 * i];
     t[c] = (float)stats[2 * i + 1];
     t[2 * c] = beta[ch];
+    t[3 * c] = (float)stats[2 * i] - beta[ch] / (float)stats[2 * i + 1];
 }
 
 extern "C" int shm_in_norm_table(const double* stats, const float* beta, float* nt, int batch, int c, void* stream) {
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                     float xh = (x[u][e] - mean[e]) * inv[e];
                     float da = inv[e] * (g[u][e] - m1[e] - xh * m2[e]);
                     d[e] = x[u][e] > 0.f ? da : da * k.slope;
-                    sd[e] += d[e];
+                    sd[e] += rnd_as((const T*)nullptr, d[e]);            // the sum of dz AS STORED: what a weight gradient multiplies
                 }
                 st4((T*)k.dz + ((size_t)n * hw + p + u * pm.PP) * k.lddz + pm.cl * 4, d);
             }
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                 float xh = (x[e] - mean[e]) * inv[e];
                 float da = inv[e] * (g[e] - m1[e] - xh * m2[e]);
                 d[e] = x[e] > 0.f ? da : da * k.slope;
-                v[0][e] += (double)d[e];
+                v[0][e] += (double)rnd_as((const T*)nullptr, d[e]);
             }
             st4((T*)k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4, d);
         }
@@ -774,8 +776,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
 
 // shm_in_bwd_apply's last launch: fold the staged bias gradient (dbias[ch] += sum over samples) and clear the gsum slot copies the
 // apply pass consumed -- "zero on entry, zero on return" for every f64 scratch, no memset in front of a launch.
+// keep != null: the per-sample sums are also copied out ([nslot = batch][c]: shm_in_bwd_keep_dz_sums)
 __global__ __launch_bounds__(256) void gsum_finish_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c, double* __restrict__ clr1,
-                                                          size_t n1, double* __restrict__ clr2, size_t n2) {
+                                                          size_t n1, double* __restrict__ clr2, size_t n2, double* __restrict__ keep) {
     __shared__ double red[4][64];
     if (dbias && blockIdx.x * 64 < (unsigned)c) {
         const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -783,7 +786,9 @@ __global__ __launch_bounds__(256) void gsum_finish_kernel(double* __restrict__ p
         double s = 0.0;
         if (ch < c)
             for (int i = g; i < nslot; i += 4) {
-                s += part[(size_t)i * c + ch];
+                const double v = part[(size_t)i * c + ch];
+                s += v;
+                if (keep) keep[(size_t)i * c + ch] = v;
                 part[(size_t)i * c + ch] = 0.0;
             }
         red[g][cl] = s;
@@ -854,14 +859,16 @@ int shm_gsum_reduce_internal(const void* g, int ldg, const void* aux, int ldaux,
 // `clear` != null: also zero the 2*nslot*c reduction sums in front of `part` (shm_in_bwd's scratch is zero on return).
 // Block = 64 channels x 4 slot groups (a serial loop over the slots per channel was latency bound: 10 us per launch).
 __global__ __launch_bounds__(256) void dbias_fold_kernel(double* __restrict__ part, double* __restrict__ dbias, int nslot, int c,
-                                                         double* __restrict__ clear) {
+                                                         double* __restrict__ clear, double* __restrict__ keep) {
     __shared__ double red[4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + cl;
     double s = 0.0;
     if (ch < c)
         for (int i = g; i < nslot; i += 4) {
-            s += part[(size_t)i * c + ch];
+            const double v = part[(size_t)i * c + ch];
+            s += v;
+            if (keep) keep[(size_t)i * c + ch] = v;
             part[(size_t)i * c + ch] = 0.0;
             if (clear) {
                 clear[((size_t)i * c + ch) * 2] = 0.0;
@@ -873,10 +880,22 @@ __global__ __launch_bounds__(256) void dbias_fold_kernel(double* __restrict__ pa
     if (g == 0 && ch < c) dbias[ch] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// shm_in_bwd_keep_dz_sums: the next shm_in_bwd / shm_in_bwd_apply / shm_in_bwd_rank1 call of this thread also copies out the per-sample
+// channel sums of dz ([batch][c] float64) it stages on the way to the bias gradient (the second term of a SHM_NORM_SCALED weight
+// gradient needs them per sample).  One-shot.
+static thread_local double* g_keep_dzsum = nullptr;
+extern "C" int shm_in_bwd_keep_dz_sums(double* dst) {
+    g_keep_dzsum = dst;
+    return SHM_OK;
+}
+
 static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2, int ldg2, const float* r1_dz, const float* r1_w, const void* a, int lda,
                        const double* stats, double* red, void* dz, int lddz, double* dbias, int batch, int h, int w, int c, float slope, int dtype,
                        void* stream) {
     const bool r1 = r1_dz != nullptr;
+    double* const keep = g_keep_dzsum;
+    g_keep_dzsum = nullptr;
+    SHM_REQUIRE(!keep || dbias, SHM_E_SHAPE, "%s: the per-sample dz sums are staged only with a bias gradient", who);
     SHM_CHECK_C(c, who);
     SHM_REQUIRE((r1 || ldg1 % 4 == 0) && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "%s: bad pitch", who);
     SHM_REQUIRE(!g2 || (h % 2 == 0 && w % 2 == 0), SHM_E_SHAPE, "%s: pooled gradient needs even h,w", who);
@@ -943,7 +962,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
     SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(apply)", red, red_bytes, st);
     if (dbias) {
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, red, keep);
     } else {
         int r = shm_zero(red, (size_t)batch * c * 2 * sizeof(double), stream);
         if (r) return r;
@@ -966,6 +985,9 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
                                 double* red, double* redp, double* dstage, void* dz, int lddz, double* dbias, int batch, int h, int w, int c,
                                 float slope, int dtype, void* stream) {
     const char* who = "shm_in_bwd_apply";
+    double* const keep = g_keep_dzsum;
+    g_keep_dzsum = nullptr;
+    SHM_REQUIRE(!keep || dbias, SHM_E_SHAPE, "%s: the per-sample dz sums are staged only with a bias gradient", who);
     SHM_REQUIRE(g1 && a && stats && red && dz, SHM_E_SHAPE, "%s: null pointer", who);
     SHM_REQUIRE((g2 != nullptr) == (redp != nullptr), SHM_E_SHAPE, "%s: the pooled gradient g2 and its sums redp come together", who);
     SHM_REQUIRE(!redp || beta, SHM_E_SHAPE, "%s: the pooled form needs beta", who);
@@ -990,7 +1012,7 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
         const size_t nclr = (nred * (redp ? 2 : 1) + 2047) / 2048;
         int nb = nclr < 64 ? (int)nclr : 64;
         if (nb < shm_cdiv(c, 64)) nb = shm_cdiv(c, 64);
-        hipLaunchKernelGGL(gsum_finish_kernel, dim3(nb), dim3(256), 0, st, dstage, dbias, batch, c, red, nred, redp, redp ? nred : (size_t)0);
+        hipLaunchKernelGGL(gsum_finish_kernel, dim3(nb), dim3(256), 0, st, dstage, dbias, batch, c, red, nred, redp, redp ? nred : (size_t)0, keep);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {           // zero on return also on the error path
@@ -1072,7 +1094,7 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
                                     (const T*)y, ldy, (T*)dz, lddz, dbias ? red : nullptr, npix, c, chunk, slope));
     SHM_LAUNCH_CHECK("shm_lrelu_bwd");
     if (dbias) {
-        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr);
+        hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream, red, dbias, SHM_LRELU_RED_SLOTS, c, (double*)nullptr, (double*)nullptr);
         SHM_LAUNCH_CHECK_CLEAR("shm_lrelu_bwd(fold)", red, (size_t)SHM_LRELU_RED_SLOTS * c * sizeof(double), (hipStream_t)stream);
     }
     return SHM_OK;

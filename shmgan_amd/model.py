@@ -465,7 +465,7 @@ class Generator(_ModelBase):
         nb = r1 - r0
         a = A.get(f"{tag}/a{li}", (n, h, w, cout), self.adt)
         ahat = A.get(f"{tag}/h{li}", (n, h, w, cout), self.adt) if apply and not fold else None
-        nt = A.get(f"{tag}/nt{li}", (n, 3, cout), torch.float32) if fold else None
+        nt = A.get(f"{tag}/nt{li}", (n, 4, cout), torch.float32) if fold else None
         stats = A.get(f"{tag}/s{li}", (n * cout * 2,), torch.float64)
         st = stats[r0 * cout * 2:r1 * cout * 2]
         # zero-on-return scratch: one per concurrently running part

@@ -193,12 +193,16 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
 STATS_SLOTS = 16            # SHM_STATS_SLOTS
 
 
+NORM_EXACT, NORM_SCALED = 0, 1          # SHM_NORM_* of include/shmgan_hip.h
+
+
 def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout, ksize, stride, slope, stats, eps,
-                  cin_real=None, scratch=None, nt_x=None, nt_x2=None, nt_out=None, beta_out=None):
+                  cin_real=None, scratch=None, nt_x=None, nt_x2=None, nt_out=None, beta_out=None, norm_mode=NORM_EXACT):
     """conv2d_fwd fused with the InstanceNorm statistics of its output (stats <- mean, inv-std).
     scratch: optional f64 [STATS_SLOTS * batch * cout * 2] (spreads the statistics atomics).
     nt_x / nt_x2: x / x2 is the UN-normalised activation of an InstanceNorm block and this is that block's table
-    (shm_conv2d_in_fwd_norm: the kernel normalises its operand tile in LDS); nt_out (+ beta_out): this block's own table."""
+    (shm_conv2d_in_fwd_norm: NORM_EXACT -- the kernel normalises its operand tile in LDS; NORM_SCALED -- wk and bias are
+    conv2d_norm_prepare's per-sample operands); nt_out (+ beta_out): this block's own table."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
     label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
@@ -209,9 +213,29 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
             "shm_conv2d_in_fwd"), label)
         return
     _timed("", flops, lambda: check(
-        lib().shm_conv2d_in_fwd_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
+        lib().shm_conv2d_in_fwd_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), norm_mode, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
                                      cin, cout, ksize, stride, slope, _p(stats), _p(scratch), eps, _p(nt_out), _p(beta_out), _dt(x), _stream()),
         "shm_conv2d_in_fwd_norm"), label + (" +norm" if (nt_x is not None or nt_x2 is not None) else ""))
+
+
+def conv2d_norm_prepare(wk, bias, nt, c, part_lo, wk_n, bias_n, batch, cin, cout, ksize):
+    """NORM_SCALED operands: per-sample weights (the folded source's channels times inv) and bias rows."""
+    check(lib().shm_conv2d_norm_prepare(_p(wk), _p(bias), _p(nt), c, part_lo, _p(wk_n), _p(bias_n), batch, cin, cout, ksize, _dt(wk), _stream()),
+          "shm_conv2d_norm_prepare")
+
+
+def conv2d_wgrad_norm_workspace(batch, hi, wi, cin, cout, ksize, dtype):
+    return int(lib().shm_conv2d_wgrad_norm_workspace(batch, hi, wi, cin, cout, ksize, 1 if dtype == torch.bfloat16 else 0))
+
+
+def conv2d_wgrad_norm_finish(dw, nt, dzsum, batch, c, part_lo, cin, cout, ksize):
+    """NORM_SCALED weight gradient, second term: dw[tap][part_lo + k][co] += sum_n (beta - mean * inv)[n][k] * dzsum[n][co]."""
+    check(lib().shm_conv2d_wgrad_norm_finish(_p(dw), _p(nt), _p(dzsum), batch, c, part_lo, cin, cout, ksize, _stream()), "shm_conv2d_wgrad_norm_finish")
+
+
+def in_bwd_keep_dz_sums(dst):
+    """The next in_bwd / in_bwd_apply / in_bwd_rank1 call also copies its per-sample channel sums of dz ([batch][c] float64) to dst."""
+    check(lib().shm_in_bwd_keep_dz_sums(_p(dst)), "shm_in_bwd_keep_dz_sums")
 
 
 def conv2d_norm_supported(batch, hi, wi, cin, c1, cout, ksize, stride, norm_part, dtype):
@@ -277,14 +301,14 @@ def conv2d_wgrad_workspace(batch, ho, wo, cin, cout, ksize):
 
 
 def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld, cout, ksize, stride,
-                 accumulate, ws, nt_x=None, nt_x2=None):
+                 accumulate, ws, nt_x=None, nt_x2=None, norm_mode=NORM_EXACT):
     """nt_x / nt_x2: x / x2 is the un-normalised activation of an InstanceNorm block, normalised in LDS (shm_conv2d_wgrad_norm)."""
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
     label = f"wgrad n{batch} h{hi} {cin}x{cout} k{ksize} s{stride}"
     wsb = ws.numel() * ws.element_size()
     if (nt_x is not None or nt_x2 is not None) and TIMER is None:
-        check(lib().shm_conv2d_wgrad_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
+        check(lib().shm_conv2d_wgrad_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), norm_mode, _p(dy), lddy, _p(dw), batch, hi, wi, cin, cin_ld,
                                           cout, ksize, stride, int(accumulate), _p(ws), wsb, _dt(x), _stream()), "shm_conv2d_wgrad_norm")
         return
     if TIMER is None:
@@ -297,7 +321,7 @@ def conv2d_wgrad(x, x2, c1, ldx, ldx2, dy, lddy, dw, batch, hi, wi, cin, cin_ld,
     ns = ctypes.c_int(0)
     if nt_x is not None or nt_x2 is not None:
         TIMER.wrap("", flops, lambda: check(
-            lib().shm_conv2d_wgrad_partial_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
+            lib().shm_conv2d_wgrad_partial_norm(_p(x), _p(x2), c1, ldx, ldx2, _p(nt_x), _p(nt_x2), norm_mode, _p(dy), lddy, batch, hi, wi, cin, cin_ld, cout,
                                                 ksize, stride, _p(ws), wsb, _dt(x), ctypes.addressof(ns), _stream()),
             "shm_conv2d_wgrad_partial_norm"), label + " +norm")
     else:

@@ -52,7 +52,7 @@ def _block(rng, n, h, c, dt):
     beta = _t(rng.uniform(-0.5, 0.5, c), "f32")
     stats = torch.zeros(n * c * 2, dtype=torch.float64, device="cuda")
     ops.in_stats(a, c, stats, n, h * h, c, EPS)
-    nt = torch.full((n, 3, c), 9.0, dtype=torch.float32, device="cuda")
+    nt = torch.full((n, 4, c), 9.0, dtype=torch.float32, device="cuda")
     ops.in_norm_table(stats, beta, nt, n, c)
     ahat = torch.empty_like(a)
     ops.in_apply(a, c, stats, beta, ahat, c, n, h * h, c)
@@ -65,8 +65,9 @@ def _wk(rng, cin, cout, dt):
 
 
 def _same_stats(s0, s1):
-    """statistics of two launches over identical outputs: float64 atomics, i.e. equal up to the order of the adds"""
-    return torch.allclose(s0, s1, rtol=1e-12, atol=1e-13)
+    """statistics of two launches over identical outputs: per-lane fp32 partial sums (sum v * v is an fma in one instantiation of a
+    kernel and a multiply-add in another), float64 atomics across lanes: equal to fp32 rounding, not to the bit"""
+    return torch.allclose(s0, s1, rtol=1e-6, atol=1e-7)
 
 
 def _in_fwd(x, x2, c1, wk, bias, n, h, cin, cout, dt, **kw):
@@ -106,10 +107,10 @@ def test_forward_fold_is_bit_identical(variant, n, h, cin, cout, dt):
     wk, bias = _wk(rng, cin, cout, dt), _t(rng.standard_normal(cout) * 0.1, "f32")
     ops.set_tuning("tapgemm.variant", variant)
     y0, s0, k0 = _in_fwd(ahat, None, 0, wk, bias, n, h, cin, cout, dt)
-    nt_out = torch.full((n, 3, cout), 5.0, dtype=torch.float32, device="cuda")
+    nt_out = torch.full((n, 4, cout), 5.0, dtype=torch.float32, device="cuda")
     beta_out = _t(rng.uniform(-1, 1, cout), "f32")
     y1, s1, k1 = _in_fwd(a, None, 0, wk, bias, n, h, cin, cout, dt, nt_x=nt, nt_out=nt_out, beta_out=beta_out)
-    assert k1 != k0 and "true" in k1.rsplit(",", 1)[-1], (k0, k1)            # the norm instantiation ran
+    assert k1 != k0 and k1.rstrip(">").endswith(", 1"), (k0, k1)            # the SHM_NORM_EXACT instantiation ran
     assert torch.equal(y0, y1), (k1, float((y0.float() - y1.float()).abs().max()))
     assert _same_stats(s0, s1)
     # this block's own table, a by-product of the statistics finalisation, equals shm_in_norm_table's
@@ -119,6 +120,9 @@ def test_forward_fold_is_bit_identical(variant, n, h, cin, cout, dt):
     st64 = s1.view(n, cout, 2)
     assert torch.equal(nt_out[:, 0], st64[..., 0].float()) and torch.equal(nt_out[:, 1], st64[..., 1].float())
     assert torch.equal(nt_out[:, 2], beta_out.expand(n, cout))
+    # ring = the raw value whose normalised image is 0
+    ring = nt_out[:, 3].double()
+    assert float(((ring - nt_out[:, 0].double()) * nt_out[:, 1].double() + nt_out[:, 2].double()).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -174,7 +178,7 @@ def test_wgrad_fold_is_bit_identical(dt, rows, n, h, cin, cout, blocks):
         ops.set_tuning("wgrad.blocks", blocks)
     dw0, k0 = _wgrad(ahat, None, 0, dy, n, h, cin, cout)
     dw1, k1 = _wgrad(a, None, 0, dy, n, h, cin, cout, nt_x=nt)
-    assert "true" in k1 and k1 != k0, (k0, k1)
+    assert k1 != k0 and k1.rstrip(">").endswith("1"), (k0, k1)
     assert torch.equal(dw0, dw1), (k1, float((dw0 - dw1).abs().max()))
 
 
@@ -239,6 +243,132 @@ def test_unsupported_shapes_are_refused(dt):
     dw = torch.zeros((3, 3, 64, 64), device="cuda")
     with pytest.raises(ShmError, match="cannot normalise"):
         ops.conv2d_wgrad(a, None, 0, 64, 0, dy, 64, dw, n, h, h, 64, 64, 64, 3, 2, 0, ws, nt_x=nt)
+
+
+# ----------------------------------------------------------------------------- SHM_NORM_SCALED: the normalisation in the operands
+def _prepare(wk, bias, nt, c, part_lo, n, cin, cout):
+    ops = _ops()
+    wk_n = torch.empty((n,) + tuple(wk.shape), device="cuda", dtype=wk.dtype)
+    bias_n = torch.empty((n, cout), device="cuda")
+    ops.conv2d_norm_prepare(wk, bias, nt, c, part_lo, wk_n, bias_n, n, cin, cout, 3)
+    return wk_n, bias_n
+
+
+def _close(got, ref, dt):
+    """rel-L2 and worst element (relative to the tensor's scale): fp32 rounding of a re-associated sum / bf16 operand rounding"""
+    g, r = got.double(), ref.double()
+    rel = float((g - r).norm() / r.norm())
+    worst = float((g - r).abs().max() / r.abs().max())
+    return (rel < 3e-6 and worst < 3e-5) if dt == "f32" else (rel < 1.5e-2 and worst < 8e-2), (rel, worst)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant,n,h,cin,cout", FWD_CASES)
+def test_forward_scaled_mode_matches_the_two_pass_path(variant, n, h, cin, cout, dt):
+    """conv(w, (a - mean) * inv + beta) = conv(w * inv, a_ext) + bias_n with a_ext = `ring` outside the image: per-sample weights and bias
+    rows (shm_conv2d_norm_prepare), the kernels only fill the out-of-image halo entries -- border pixels are where it could go wrong."""
+    ops = _ops()
+    if variant == "wreg" and dt == "f32" and cin == 32 and cout != 64:
+        pytest.skip("fp32 wreg: 64 output channels per block")
+    rng = np.random.default_rng(21)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cin, dt)
+    wk, bias = _wk(rng, cin, cout, dt), _t(rng.standard_normal(cout) * 0.1, "f32")
+    ops.set_tuning("tapgemm.variant", variant)
+    y0, s0, k0 = _in_fwd(ahat, None, 0, wk, bias, n, h, cin, cout, dt)
+    wk_n, bias_n = _prepare(wk, bias, nt, cin, 0, n, cin, cout)
+    y1, s1, k1 = _in_fwd(a, None, 0, wk_n, bias_n, n, h, cin, cout, dt, nt_x=nt, norm_mode=ops.NORM_SCALED)
+    assert k1.rstrip(">").endswith(", 2"), k1
+    ok, err = _close(y1, y0, dt)
+    assert ok, (k1, err)
+    # the border rows / columns on their own (a wrong `ring` would hide in the rel-L2 of the whole tensor)
+    for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):
+        ok, err = _close(y1[sl], y0[sl], dt)
+        assert ok, (k1, sl, err)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant,n,h,cu,cs,cout", [("halo64_st", 2, 32, 64, 64, 64), ("halo128_st", 2, 16, 128, 128, 128), ("halo128_st", 1, 32, 256, 256, 256)])
+def test_concat_scaled_mode(variant, n, h, cu, cs, cout, dt):
+    ops = _ops()
+    rng = np.random.default_rng(22)
+    u = _t(rng.standard_normal((n, h, h, cu)), dt)
+    a, stats, beta, nt, ahat = _block(rng, n, h, cs, dt)
+    cin = cu + cs
+    wk, bias = _wk(rng, cin, cout, dt), _t(rng.standard_normal(cout) * 0.1, "f32")
+    ops.set_tuning("tapgemm.variant", variant)
+    y0, _, _ = _in_fwd(u, ahat, cu, wk, bias, n, h, cin, cout, dt)
+    wk_n, bias_n = _prepare(wk, bias, nt, cs, cu, n, cin, cout)
+    # the un-folded source's weights are copied, the folded one's scaled
+    assert torch.equal(wk_n[:, :, :, :cu], wk[None, :, :, :cu].expand(n, -1, -1, -1))
+    y1, _, k1 = _in_fwd(u, a, cu, wk_n, bias_n, n, h, cin, cout, dt, nt_x2=nt, norm_mode=ops.NORM_SCALED)
+    ok, err = _close(y1, y0, dt)
+    assert ok, (k1, err)
+
+
+@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2)])
+@pytest.mark.parametrize("n,h,cin,cout,c1", [(3, 16, 64, 64, 0), (2, 32, 128, 64, 0), (5, 16, 64, 128, 0), (2, 48, 64, 64, 0), (2, 32, 192, 64, 64)])
+def test_wgrad_scaled_mode(dt, rows, n, h, cin, cout, c1):
+    """sum x_hat * dz = inv * sum a_ext * dz (kernel: `ring` outside the image, slab rows times inv, splits on sample boundaries)
+    + (beta - mean * inv) * sum dz (shm_conv2d_wgrad_norm_finish from the per-sample dz sums)."""
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    cs = cin - c1
+    u = _t(rng.standard_normal((n, h, h, c1)), dt) if c1 else None
+    a, stats, beta, nt, ahat = _block(rng, n, h, cs, dt)
+    dy = _t(rng.standard_normal((n, h, h, cout)) + 0.05, dt)
+    if rows:
+        ops.set_tuning("wgrad.bf16_rows", rows)
+    key = "nt_x2" if c1 else "nt_x"
+    src0, src1 = ((u, ahat), (u, a)) if c1 else ((ahat, None), (a, None))
+    dw0, k0 = _wgrad(src0[0], src0[1], c1, dy, n, h, cin, cout)
+    ws = torch.empty(ops.conv2d_wgrad_norm_workspace(n, h, h, cin, cout, 3, a.dtype) // 4 + 16, device="cuda")
+    dw1 = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+    ops.conv2d_wgrad(src1[0], src1[1], c1, src1[0].shape[-1], 0 if src1[1] is None else src1[1].shape[-1], dy, cout, dw1, n, h, h, cin, cin, cout, 3, 1, 0,
+                     ws, norm_mode=ops.NORM_SCALED, **{key: nt})
+    k1 = ops.last_kernel()
+    dzsum = dy.double().sum(dim=(1, 2)).contiguous()
+    ops.conv2d_wgrad_norm_finish(dw1, nt, dzsum, n, cs, c1, cin, cout, 3)
+    torch.cuda.synchronize()
+    assert k1.rstrip(">").endswith("2"), k1
+    g, r = dw1.double(), dw0.double()
+    rel = float((g - r).norm() / r.norm())
+    assert rel < (2e-5 if dt == "f32" else 1.5e-2), (k1, rel)
+    if c1:                      # the un-folded source's rows are the plain kernel's sums (other split, same operands)
+        assert float((g[:, :, :c1] - r[:, :, :c1]).norm() / r[:, :, :c1].norm()) < (2e-6 if dt == "f32" else 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("gsum", [False, True])
+def test_in_bwd_keeps_the_per_sample_dz_sums(dt, gsum):
+    ops = _ops()
+    rng = np.random.default_rng(24)
+    n, h, c = 3, 32, 64
+    a, stats, beta, nt, ahat = _block(rng, n, h, c, dt)
+    g = _t(rng.standard_normal((n, h, h, c)), dt)
+    dz = torch.empty_like(a)
+    db = torch.zeros(c, dtype=torch.float64, device="cuda")
+    keep = torch.full((n, c), 7.0, dtype=torch.float64, device="cuda")
+    ops.in_bwd_keep_dz_sums(keep)
+    if gsum:
+        red = torch.zeros(ops.GSUM_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
+        g64, a64 = g.double(), a.double()
+        red.view(ops.GSUM_SLOTS, n, c, 2)[0] = torch.stack([g64.sum(dim=(1, 2)), (g64 * a64).sum(dim=(1, 2))], -1)
+        dstage = torch.zeros(n * c, dtype=torch.float64, device="cuda")
+        ops.in_bwd_apply(g, c, None, 0, a, c, stats, beta, red, None, dstage, dz, c, db, n, h, h, c, 0.2)
+    else:
+        red = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
+        ops.in_bwd(g, c, None, 0, a, c, stats, red, dz, c, db, n, h, h, c, 0.2)
+    torch.cuda.synchronize()
+    ref = dz.double().sum(dim=(1, 2))
+    assert float((keep - ref).abs().max()) < 1e-4 * float(ref.abs().max() + 1.0)          # the sums of dz as stored (fp32 partial sums)
+    assert float((keep.sum(0) - db).abs().max()) < 1e-9 * float(db.abs().max() + 1.0)
+    # one-shot: a second call leaves the buffer alone
+    keep.fill_(7.0)
+    db2 = torch.zeros_like(db)
+    if not gsum:
+        ops.in_bwd(g, c, None, 0, a, c, stats, red, dz, c, db2, n, h, h, c, 0.2)
+        torch.cuda.synchronize()
+        assert float(keep.min()) == 7.0
 
 
 def _step(S, F, B, dt, fold, seed=0):
