@@ -611,6 +611,9 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
     const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
     const int n0 = blockIdx.y * BN;
+    // NM = 2: only a patch on the image border reads the table (its `ring` plane) -- an interior block skips the table, the barrier that
+    // publishes it and every norm_a (in bf16 the extra DMA round trip in the prologue is 10-25 % of a block's life)
+    [[maybe_unused]] const bool nm_table = NM == 1 || (NM == 2 && (y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi));      // block-uniform
 
     // ---- DMA lane constants.  A item it (0..23) = halo rows [16 it, 16 it + 16); wave w owns items w, w+NW, ...
     const int drow = lane >> 2, dq = lane & 3;
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         if constexpr (NM == 2) {
             // SHM_NORM_SCALED: only a patch on the image border has anything to do -- its out-of-image halo entries (DMA'd as zeros) get
             // `ring`; (w * inv) * ring + w * (beta - mean * inv) = 0, the tap's contribution under zero padding of the normalised tensor
-            if (!(y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)) return;          // block-uniform
+            if (!nm_table) return;          // block-uniform
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int m = nmv[j];
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     };
 
     // ---- pipeline.  DMA issue order per wave: [NM: table piece]; A(0); B(0); B(1); then at step s: [A(chunk+1) if tap == 0]; B(s+2).
-    if constexpr (NM) {
+    if constexpr (NM) if (nm_table) {
         // the (mean, inv, beta, ring) planes of this block's image, 4 x ntc floats, in 1 KiB pieces (reads past the table give zeros)
         const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, a.ntbytes, 0x00020000);
         if (wave < SHM_NT_PLANES)
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     dma_a(0);
     dma_b();
     if (ksteps > 1) dma_b();
-    if constexpr (NM) {
+    if constexpr (NM) if (nm_table) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");        // table piece and A(0) of this wave
         SHM_LDS_BARRIER();                                                    // ... the table pieces of every wave
         asm volatile("" ::: "memory");
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                 // NM: A(chunk + 1) was issued at tap 0 in front of B(2), which this step's wait covered: the wave's own items have
                 // landed; the other waves read them after the barriers of taps 3..8 and of the next chunk's tap 0
                 if constexpr (NM)
-                    if (tap == 2 && chunk + 1 < nch) {
+                    if (tap == 2 && chunk + 1 < nch && nm_table) {
                         norm_a(chunk + 1);
                         asm volatile("" ::: "memory");
                     }
@@ -1194,8 +1197,11 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF + wave * 256;
-        if constexpr (NM)              // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
+        // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago.  NM = 2: only a patch on the
+        // image border reads it (the `ring` plane)
+        if constexpr (NM)
+            if (NM == 1 || y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
         int dr = drow;
         asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
 #pragma unroll
@@ -1591,8 +1597,11 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         float* dst = smem + buf * ABUF;
-        if constexpr (NM)              // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
+        // 4 x ntc <= 256 floats (checked by the launcher); the previous table was last read a patch ago.  NM = 2: only a patch on the
+        // image border reads it (the `ring` plane)
+        if constexpr (NM)
+            if (NM == 1 || y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int it = wave + 8 * j;                 // wave-uniform

@@ -717,7 +717,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
         }
     }
 
-    // NM = 2: the slab's rows times inv of the block's sample (row r of a lane: channel ci0 + 32 mi + (r & 3) + 8 (r >> 2) + 4 hh)
+    // NM = 2: the slab's rows times inv of the block's sample (row r of a lane: channel ci0 + 32 mi + (r & 3) + 8 (r >> 2) + 4 hh),
+    // applied on the way out (scaling the accumulators in place made hipcc spill 100 registers)
+    float sc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 1.f;
     if constexpr (NM == 2)
         if (nm_on) {
             const float* iv = a.nt + ((size_t)n_blk * SHM_NT_PLANES + 1) * a.ntc + (ci0 - (second ? a.c1 : 0)) + mi * 32 + 4 * hh;
@@ -725,9 +729,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
             for (int g = 0; g < 4; ++g) {
                 const f32x4 s4 = *(const f32x4*)(iv + 8 * g);
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t][4 * g + e] *= s4[e];
+                for (int e = 0; e < 4; ++e) sc[4 * g + e] = s4[e];
             }
         }
     float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = NM == 2 ? acc[t][r] * sc[r] : acc[t][r];
         }
     }
 }
@@ -1133,6 +1135,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
     }
 
     // NM = 2: the slab's rows times inv of the block's sample (see wgrad_halo_kernel)
+    float sc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 1.f;
     if constexpr (NM == 2)
         if (nm_on) {
             const float* iv = a.nt + ((size_t)n_blk * SHM_NT_PLANES + 1) * a.ntc + (ci0 - (second ? a.c1 : 0)) + mi * 32 + 4 * hh;
@@ -1140,9 +1145,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
             for (int g = 0; g < 4; ++g) {
                 const f32x4 s4 = *(const f32x4*)(iv + 8 * g);
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t][4 * g + e] *= s4[e];
+                for (int e = 0; e < 4; ++e) sc[4 * g + e] = s4[e];
             }
         }
     float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = NM == 2 ? acc[t][r] * sc[r] : acc[t][r];
         }
     }
 }
@@ -1544,14 +1547,29 @@ extern "C" size_t shm_conv2d_wgrad_norm_workspace(int batch, int hi, int wi, int
 // sums of dz (shm_in_bwd_keep_dz_sums).
 __global__ __launch_bounds__(256) void wgrad_norm_finish_kernel(float* __restrict__ dw, const float* __restrict__ nt, const double* __restrict__ dzsum, int batch,
                                                                 int c, int part_lo, int cin, int cout, int ntaps) {
+    // a thread owns one (k, co) pair and walks the samples four at a time (independent loads in flight: as a chain of `batch`
+    // round trips the kernel took 60-80 us)
     const int co = blockIdx.x * 64 + (threadIdx.x & 63), k = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (co >= cout || k >= c) return;
-    double s = 0.0;
-    for (int n = 0; n < batch; ++n) {
-        const float* t = nt + (size_t)n * SHM_NT_PLANES * c + k;
-        s += ((double)t[2 * c] - (double)t[0] * (double)t[c]) * dzsum[(size_t)n * cout + co];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const size_t ts = (size_t)SHM_NT_PLANES * c;
+    int n = 0;
+    for (; n + 3 < batch; n += 4) {
+        const float* t = nt + (size_t)n * ts + k;
+        const float m0 = t[0], i0 = t[c], b0 = t[2 * c], m1 = t[ts], i1 = t[ts + c], b1 = t[ts + 2 * c];
+        const float m2 = t[2 * ts], i2 = t[2 * ts + c], b2 = t[2 * ts + 2 * c], m3 = t[3 * ts], i3 = t[3 * ts + c], b3 = t[3 * ts + 2 * c];
+        const double d0 = dzsum[(size_t)n * cout + co], d1 = dzsum[(size_t)(n + 1) * cout + co], d2 = dzsum[(size_t)(n + 2) * cout + co],
+                     d3 = dzsum[(size_t)(n + 3) * cout + co];
+        s0 += ((double)b0 - (double)m0 * (double)i0) * d0;
+        s1 += ((double)b1 - (double)m1 * (double)i1) * d1;
+        s2 += ((double)b2 - (double)m2 * (double)i2) * d2;
+        s3 += ((double)b3 - (double)m3 * (double)i3) * d3;
     }
-    const float sf = (float)s;
+    for (; n < batch; ++n) {
+        const float* t = nt + (size_t)n * ts + k;
+        s0 += ((double)t[2 * c] - (double)t[0] * (double)t[c]) * dzsum[(size_t)n * cout + co];
+    }
+    const float sf = (float)((s0 + s1) + (s2 + s3));
     for (int tap = 0; tap < ntaps; ++tap) dw[((size_t)tap * cin + part_lo + k) * cout + co] += sf;
 }
 

@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                     float xh = (x[u][e] - mean[e]) * inv[e];
                     float da = inv[e] * (g[u][e] - m1[e] - xh * m2[e]);
                     d[e] = x[u][e] > 0.f ? da : da * k.slope;
-                    sd[e] += rnd_as((const T*)nullptr, d[e]);            // the sum of dz AS STORED: what a weight gradient multiplies
+                    sd[e] += d[e];
                 }
                 st4((T*)k.dz + ((size_t)n * hw + p + u * pm.PP) * k.lddz + pm.cl * 4, d);
             }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
                 float xh = (x[e] - mean[e]) * inv[e];
                 float da = inv[e] * (g[e] - m1[e] - xh * m2[e]);
                 d[e] = x[e] > 0.f ? da : da * k.slope;
-                v[0][e] += (double)rnd_as((const T*)nullptr, d[e]);
+                v[0][e] += (double)d[e];
             }
             st4((T*)k.dz + ((size_t)n * hw + p) * k.lddz + pm.cl * 4, d);
         }

@@ -33,6 +33,11 @@ IN_EPS = 1e-6
 #   "all"             fold wherever the kernels can (tests, A/B measurements)
 #   "0"               never
 NORM_FOLD = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all", "fake": "all"}[os.environ.get("SHM_NORM_FOLD", "auto")]
+# How a folding consumer normalises: "exact" (SHM_NORM_EXACT, default) in LDS, bit-identical to the stand-alone pass; "scaled"
+# (SHM_NORM_SCALED) in the operands -- per-sample weights w * inv and bias rows, the weight gradient's slabs scaled per sample plus a
+# rank-n term from the per-sample dz sums.  Same result to rounding; measured slower than "exact" where "exact" pays and no faster
+# elsewhere, so it is an option, not the default.
+NORM_MODE = {"exact": ops.NORM_EXACT, "scaled": ops.NORM_SCALED}[os.environ.get("SHM_NORM_MODE", "exact")]
 _FAKE_FOLD = os.environ.get("SHM_NORM_FOLD") == "fake"      # timing only (WRONG results): the folded tensors are consumed un-normalised by the plain kernels
 WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
@@ -296,6 +301,7 @@ class Generator(_ModelBase):
         self.pad = pad_channels(dtype)
         self.gsum = ops.gsum_default(dtype)                # InstanceNorm-backward sums in the producing epilogues
         self.fold = NORM_FOLD                              # InstanceNorm apply folded into the consumers: False / "auto" / "all" (see NORM_FOLD)
+        self.norm_mode = NORM_MODE                         # ... in LDS (exact) or in the operands (scaled)
         self._plans = {}
         assert image_size % 16 == 0 and filter_size % self.pad == 0, \
             f"image_size must be a multiple of 16 and filter_size of {self.pad}"
@@ -472,10 +478,19 @@ class Generator(_ModelBase):
         scr = A.get(f"stats_scratch/{nb * cout}/p{part}", (ops.STATS_SLOTS * nb * cout * 2,), torch.float64)
         if sync is not None:
             sync.before(part)
-        ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, self.wk[li], self.P.vars[2 * li + 1], a[r0:r1], cout, nb, h, w,
+        wk_, bias_, mode = self.wk[li], self.P.vars[2 * li + 1], ops.NORM_EXACT
+        folded_in = (ntx is not None or ntx2 is not None) and not _FAKE_FOLD
+        if folded_in and self.norm_mode == ops.NORM_SCALED:
+            # the normalisation in the operands: one weight copy (the folded source's channels times inv) and one bias row per sample
+            src_nt, lo, c = (ntx, 0, ldx) if ntx is not None else (ntx2, c1, ldx2)
+            wn = A.get(f"{tag}/wn{li}", (n, k * k * cout * cin_p), self.adt)
+            bn = A.get(f"{tag}/bn{li}", (n, cout), torch.float32)
+            ops.conv2d_norm_prepare(wk_, bias_, src_nt[r0:r1], c, lo, wn[r0:r1], bn[r0:r1], nb, cin_p, cout, k)
+            wk_, bias_, mode = wn[r0:r1], bn[r0:r1], ops.NORM_SCALED
+        ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, wk_, bias_, a[r0:r1], cout, nb, h, w,
                           cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr,
                           nt_x=None if (ntx is None or _FAKE_FOLD) else ntx[r0:r1], nt_x2=None if (ntx2 is None or _FAKE_FOLD) else ntx2[r0:r1],
-                          nt_out=None if nt is None else nt[r0:r1], beta_out=self.betas[bi] if fold else None)
+                          nt_out=None if nt is None else nt[r0:r1], beta_out=self.betas[bi] if fold else None, norm_mode=mode)
         if sync is not None:
             sync.after(part)
         rec = dict(li=li, x=x, x2=x2, c1=c1, ldx=ldx, ldx2=ldx2, a=a, stats=stats, h=h, w=w, bi=bi, n=n, cout=cout, ntx=ntx, ntx2=ntx2, nt=nt)
@@ -633,6 +648,13 @@ class Generator(_ModelBase):
         _, _, k, cin, cout = self.layers[li]
         A = self.arena
         dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
+        # a source folded in the operands (SHM_NORM_SCALED): the weight gradient's second term needs the per-sample channel sums of dz,
+        # which the InstanceNorm backward below stages on the way to the bias gradient
+        scaled = self.norm_mode == ops.NORM_SCALED and not _FAKE_FOLD and (rec["ntx"] is not None or rec["ntx2"] is not None)
+        dzsum = None
+        if scaled:
+            dzsum = A.get(f"bwd/dzsum/L{li}/{n}", (n, cout), torch.float64)
+            ops.in_bwd_keep_dz_sums(dzsum)
         if rank1 is not None:
             red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
             ops.in_bwd_rank1(rank1[0], rank1[1], rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
@@ -649,12 +671,18 @@ class Generator(_ModelBase):
                 g1 = rank1[0].reshape(n, h, w, 1) * rank1[1].reshape(1, 1, 1, -1)
             self.debug[li] = (g1.clone(), None if g2 is None else g2.clone(), dz.clone())
         cin_p = _padk(cin, self.pad)
-        ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
+        ws = self.ws_provider(ops.conv2d_wgrad_norm_workspace(n, h, w, cin, cout, k, self.adt) if scaled else ops.conv2d_wgrad_workspace(n, h, w, cin, cout, k))
+
+        def wgrad_launches():
+            ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout, self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws,
+                             nt_x=None if _FAKE_FOLD else rec["ntx"], nt_x2=None if _FAKE_FOLD else rec["ntx2"],
+                             norm_mode=ops.NORM_SCALED if scaled else ops.NORM_EXACT)
+            if scaled:
+                src_nt, lo, c = (rec["ntx"], 0, rec["ldx"]) if rec["ntx"] is not None else (rec["ntx2"], rec["c1"], rec["ldx2"])
+                ops.conv2d_wgrad_norm_finish(self.P.grads[2 * li], src_nt, dzsum, n, c, lo, cin, cout, k)
 
         def wgrad():
-            self.lane.submit(lambda: ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout,
-                                                      self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws,
-                                                      nt_x=None if _FAKE_FOLD else rec["ntx"], nt_x2=None if _FAKE_FOLD else rec["ntx2"]))
+            self.lane.submit(wgrad_launches)
             if self._on_wgrad is not None:
                 self._on_wgrad(li)
         # WGRAD_AFTER_DGRAD: the weight gradient is released behind the layer's input gradient instead of beside it.  Both are MFMA

@@ -360,7 +360,8 @@ def test_in_bwd_keeps_the_per_sample_dz_sums(dt, gsum):
         ops.in_bwd(g, c, None, 0, a, c, stats, red, dz, c, db, n, h, h, c, 0.2)
     torch.cuda.synchronize()
     ref = dz.double().sum(dim=(1, 2))
-    assert float((keep - ref).abs().max()) < 1e-4 * float(ref.abs().max() + 1.0)          # the sums of dz as stored (fp32 partial sums)
+    # (the sums are taken before dz is rounded to its storage type: fp32 partial sums in float32, plus bf16 rounding of the summands in bf16)
+    assert float((keep - ref).abs().max()) < (1e-4 if dt == "f32" else 1e-2) * float(ref.abs().max() + 1.0)
     assert float((keep.sum(0) - db).abs().max()) < 1e-9 * float(db.abs().max() + 1.0)
     # one-shot: a second call leaves the buffer alone
     keep.fill_(7.0)
@@ -371,10 +372,11 @@ def test_in_bwd_keeps_the_per_sample_dz_sums(dt, gsum):
         assert float(keep.min()) == 7.0
 
 
-def _step(S, F, B, dt, fold, seed=0):
+def _step(S, F, B, dt, fold, seed=0, mode=0):
     from shmgan_amd import ShmGANwithSSpecSeg
     m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype=dt).build()
     m.G.fold = fold
+    m.G.norm_mode = mode
     m.G._plans.clear()
     inp = st.make_inputs(B, S)
     dr = st.make_draws(seed, B, S, F)
@@ -408,3 +410,26 @@ def test_default_policy_folds_the_float32_wreg_consumers():
         assert m.G.fold == "auto"
         plan = m.G._fold_plan(5, 5, False)
         assert sorted(li for li, on in plan.items() if on) == want, (dt, plan)
+
+
+@pytest.mark.parametrize("S,F,B,dt", [(64, 64, 2, "float32"), (128, 64, 1, "float32"), (64, 64, 2, "bfloat16")])
+def test_train_step_with_the_fold_in_the_operands(S, F, B, dt):
+    """SHM_NORM_SCALED through the whole step (per-sample weights, bias rows, scaled slabs, rank-n term, per-sample dz sums): equal to the
+    un-folded step to rounding.  Not to the run-to-run bound: a re-associated fp32 sum differs in the last bit, and at random
+    initialisation the step amplifies a 1e-7 perturbation of an early activation about a thousandfold (LeakyReLU kinks, InstanceNorm
+    of near-constant channels) -- the bound here is the oracle contract's (losses 1e-4, gradients 1e-3)."""
+    l0, g0, d0, p0 = _step(S, F, B, dt, fold=False)
+    l1, g1, d1, p1 = _step(S, F, B, dt, fold="all", mode=_ops().NORM_SCALED)
+    folded = sorted({li for v in p1.values() for li, on in v.items() if on})
+    assert folded
+    # bf16: two paths that round at different points are each within the bf16 contract of the exact step (cosine >= 0.99), i.e.
+    # within rel-L2 ~ 0.15 of each other
+    ltol, gtol = (1e-4, 1e-3) if dt == "float32" else (2e-2, 0.15)
+    for k, v in l0.items():
+        if k != "ssim":
+            assert abs(l1[k] - v) <= ltol * max(1.0, abs(v)), (k, v, l1[k])
+    assert rel_l2(host(g1), host(g0)) <= gtol, (folded, rel_l2(host(g1), host(g0)))
+    assert rel_l2(host(d1), host(d0)) <= gtol
+    if dt != "float32":
+        from util import cosine
+        assert cosine(host(g1), host(g0)) >= 0.99
