@@ -32,12 +32,17 @@ IN_EPS = 1e-6
 #                     pass does at 128 x 128 and more below; in bfloat16, whose MFMA loops are 6 x shorter, it costs 2-4 x the pass.
 #   "all"             fold wherever the kernels can (tests, A/B measurements)
 #   "0"               never
-NORM_FOLD = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all", "fake": "all"}[os.environ.get("SHM_NORM_FOLD", "auto")]
+_FOLD_VALUES = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all", "fake": "all"}
+if os.environ.get("SHM_NORM_FOLD", "auto") not in _FOLD_VALUES:
+    raise ValueError(f"SHM_NORM_FOLD={os.environ['SHM_NORM_FOLD']!r}: expected one of auto, all, 0")
+NORM_FOLD = _FOLD_VALUES[os.environ.get("SHM_NORM_FOLD", "auto")]
 # How a folding consumer normalises: "exact" (SHM_NORM_EXACT, default) in LDS, bit-identical to the stand-alone pass; "scaled"
 # (SHM_NORM_SCALED) in the operands -- per-sample weights w * inv and bias rows, the weight gradient's slabs scaled per sample plus a
 # rank-n term from the per-sample dz sums.  Same result to rounding; measured slower than "exact" where "exact" pays and no faster
 # elsewhere, so it is an option, not the default.
-NORM_MODE = {"exact": ops.NORM_EXACT, "scaled": ops.NORM_SCALED}[os.environ.get("SHM_NORM_MODE", "exact")]
+if os.environ.get("SHM_NORM_MODE", "exact") not in ("exact", "scaled"):
+    raise ValueError(f"SHM_NORM_MODE={os.environ['SHM_NORM_MODE']!r}: expected exact or scaled")
+NORM_MODE = ops.NORM_SCALED if os.environ.get("SHM_NORM_MODE", "exact") == "scaled" else ops.NORM_EXACT
 _FAKE_FOLD = os.environ.get("SHM_NORM_FOLD") == "fake"      # timing only (WRONG results): the folded tensors are consumed un-normalised by the plain kernels
 WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
