@@ -210,8 +210,16 @@ def main():
             if tpath.exists():
                 tj = json.loads(tpath.read_text())
                 key = dom.split(" (+")[0].replace(" ", "")
+
+                def same_symbol(prof):
+                    """shm_last_kernel() spells a symbol without its trailing default template arguments, rocprofv3 with all of them"""
+                    b = prof.replace(" ", "")
+                    if b == key:
+                        return True
+                    base = key[:-1] + "," if key.endswith(">") else key + "<"
+                    return b.startswith(base) and all(t in ("false", "0") for t in b[len(base):].rstrip(">").split(","))
                 for name, rec in tj.items():
-                    if name.replace(" ", "") == key:
+                    if same_symbol(name):
                         traffic = rec["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
