@@ -79,9 +79,13 @@ const char* shm_last_kernel(void);
  *                               loads, 0 plain loads (default; round-3 A/B in DESIGN.md section 8)
  *   "elem.chunk_mb"             shm_in_bwd runs its reduce and apply passes per chunk of samples whose tensors fit this many MiB, so that
  *                               the apply pass re-reads them from the Infinity Cache; 0 = the whole batch at once (default)
+ *   "elem.interleave"           experiment, default 0: the InstanceNorm-backward apply pass deals a sample's pixel tiles round-robin over its
+ *                               blocks instead of one contiguous chunk per block (bf16 +14 % in isolation, fp32 none)
+ *   "elem.stream_blocks"        block target of the passes without a per-block prologue or reduction (InstanceNorm apply and its pooling
+ *                               forms), default 32768: short blocks keep the addresses in flight a narrow band of the tensors
  * value < 0 restores the knob's default; key "reset" restores all.  Initial values may be given in the
  * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_TAPGEMM_PHASE4_MIN, SHM_WGRAD_VARIANT, SHM_WGRAD_BF16_ROWS,
- * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE, SHM_ELEM_REDUCE_BLOCKS, SHM_ELEM_NT, SHM_ELEM_CHUNK_MB), read once.  Knobs change scheduling only, never results beyond the
+ * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE, SHM_ELEM_REDUCE_BLOCKS, SHM_ELEM_NT, SHM_ELEM_CHUNK_MB, SHM_ELEM_INTERLEAVE, SHM_ELEM_STREAM_BLOCKS), read once.  Knobs change scheduling only, never results beyond the
  * summation order of a tile shape. */
 #define SHM_TG_AUTO 0
 #define SHM_TG_HALO128 1

@@ -52,6 +52,8 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.reduce_blocks", "SHM_ELEM_REDUCE_BLOCKS", 0, 0, 1 << 20},
     {"elem.nt_loads", "SHM_ELEM_NT", 0, 0, 1},
     {"elem.chunk_mb", "SHM_ELEM_CHUNK_MB", 0, 0, 1 << 20},
+    {"elem.interleave", "SHM_ELEM_INTERLEAVE", 0, 0, 1},
+    {"elem.stream_blocks", "SHM_ELEM_STREAM_BLOCKS", 32768, 256, 1 << 20},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -159,13 +161,20 @@ struct PixMap {
     }
 };
 
-static int pix_chunks(long npix_per_sample, int batch, int c, int blocks = 4096) {
-    // enough blocks to fill the chip (~4k), but at least 16 pixel iterations per thread so the
+// blocks = 0: the target of the passes without a per-block prologue or reduction (InstanceNorm apply, its pooling forms),
+// "elem.stream_blocks", default 32768: short blocks keep the addresses in flight a narrow band that sweeps through the tensors
+// (tools/probes/elem_probe.hip: a 2-read / 1-write pass over 3 x 671 MB runs at 5.5 TB/s with 4k blocks of 160 KB each and at 7.0 TB/s with
+// 16k blocks of 40 KB; shm_in_apply on the same tensor 5.16 -> 5.85 TB/s in fp32, 5.24 -> 6.01 in bf16).  The passes that start with
+// a per-block prologue and end in an LDS reduction + atomics (InstanceNorm backward) keep 4096: they get SLOWER with more blocks.
+static int pix_chunks(long npix_per_sample, int batch, int c, int blocks = 0) {
+    // enough blocks to fill the chip, but at least 8 (streaming target) / 16 pixel iterations per thread so the
     // per-block LDS reduction + f64 atomics (one per channel and block) stay a small fraction
+    const int min_iter = blocks == 0 ? 8 : 16;
+    if (blocks == 0) blocks = shm_tune(SHM_TUNE_ELEM_STREAM_BLOCKS);
     int lanes_c = c / 4;
     int PP = 256 / lanes_c;
     long want = (blocks + batch - 1) / batch;
-    long maxc = npix_per_sample / ((long)PP * 16);
+    long maxc = npix_per_sample / ((long)PP * min_iter);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
     return (int)want;
@@ -289,7 +298,7 @@ extern "C" int shm_in_stats(const void* a, int lda, double* stats, int batch, in
     if (batch == 0 || hw == 0) return SHM_OK;
     int r = shm_zero(stats, (size_t)batch * c * 2 * sizeof(double), stream);
     if (r) return r;
-    int nch = pix_chunks(hw, batch, c);
+    int nch = pix_chunks(hw, batch, c, 4096);
     int chunk = shm_cdiv(hw, nch);
     SHM_DISPATCH(dtype, "shm_in_stats",
                  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(shm_cdiv(hw, chunk), batch), dim3(256), 0, st, (const T*)a, lda, stats, hw, c, chunk));
@@ -486,6 +495,7 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     int gslots;
     int nt;                      // apply pass: g1 is read for the last time -> non-temporal loads
     int n0, nbatch;              // sample chunking (in_bwd_impl): this launch covers samples [n0, n0 + gridDim.y) of nbatch
+    int interleave;              // apply pass: tiles of pixels dealt round-robin over a sample's blocks ("elem.interleave")
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -689,7 +699,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
         if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
     }
     const int n = k.n0 + blockIdx.y, hw = k.h * k.w;
-    const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    const int p0 = blockIdx.x * k.chunk;
+    int p1 = min(hw, p0 + k.chunk);
     // RAW: the two means of every channel, formed ONCE per block from the slot copies (thread ch sums channel ch's slots: with every
     // thread summing the slots of its own four channels the pass spent a third of its time re-reading 64 doubles per thread)
     __shared__ float sm12[RAW ? 2048 : 2];
@@ -732,7 +743,16 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
         }
         constexpr int U = sizeof(T) == 2 ? 8 : 4;
         int p = p0 + pm.pp;
-        for (; p + (U - 1) * pm.PP < p1; p += U * pm.PP) {
+        // k.interleave (experiment "elem.interleave"): the blocks of a sample take tiles of U * PP pixels round-robin instead of one
+        // contiguous chunk each -- at any instant the chip then reads a narrow band of the tensors instead of ~2000 separate places
+        const int tile = U * pm.PP;
+        int pstep = tile, pend = p1;
+        if (k.interleave) {
+            p = blockIdx.x * tile + pm.pp;
+            pstep = gridDim.x * tile;
+            pend = hw - hw % tile;
+        }
+        for (; p + (U - 1) * pm.PP < pend; p += pstep) {
             f32x4 g[U], x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -754,6 +774,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
+        }
+        if (k.interleave) {                  // the pixels beyond the last whole tile: block 0, one at a time
+            p = blockIdx.x == 0 ? pend + pm.pp : hw;
+            p1 = hw;
         }
         for (; p < p1; p += pm.PP) {
             f32x4 g = in_bwd_dout<TG, G2, R1>(k, n, p, pm.cl, wr);
@@ -908,6 +932,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     k.nbatch = batch;
     InBwdArgs kr = k;
     k.nt = shm_tune(SHM_TUNE_ELEM_NT);          // the apply pass is the last reader of g1
+    k.interleave = shm_tune(SHM_TUNE_ELEM_INTERLEAVE);
     const int rb = shm_tune(SHM_TUNE_ELEM_REDUCE_BLOCKS);
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
@@ -931,7 +956,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         // data moves in 40) and the 512-channel maps issue 1.3 M atomics per launch.  Fewer, longer blocks -- about the same bytes per
         // block in both dtypes: bf16 step 27.8 -> 27.1 ms, fp32 123.4 -> 122.9.  (The apply pass, one atomic per channel and block, is faster with
         // its 4096 blocks: same grid for both measured +0.15 / +0.6 ms.)
-        k.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c));
+        k.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, 4096));
         kr.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
         const dim3 grid(shm_cdiv(hw, k.chunk), nb), gridr(shm_cdiv(hw, kr.chunk), nb);
         if (wide8) {
@@ -999,8 +1024,9 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
     hipStream_t st = (hipStream_t)stream;
     InBwdArgs k{g1, g2, a, stats, nullptr, dz, dbias, ldg1, ldg2, lda, lddz, h, w, c, 0, slope, 0, nullptr, nullptr, red, redp, beta, dstage, SHM_GSUM_SLOTS,
                 shm_tune(SHM_TUNE_ELEM_NT), 0, batch};
+    k.interleave = shm_tune(SHM_TUNE_ELEM_INTERLEAVE);
     const int hw = h * w;
-    k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c));
+    k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, 4096));
     const dim3 grid(shm_cdiv(hw, k.chunk), batch);
     if (g2)
         SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true, false, true>), grid, dim3(256), 0, st, k));
@@ -1087,7 +1113,7 @@ extern "C" int shm_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, v
     SHM_CHECK_C(c, "shm_lrelu_bwd");
     SHM_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0, SHM_E_SHAPE, "shm_lrelu_bwd: bad pitch");
     if (npix == 0) return SHM_OK;
-    int nch = pix_chunks((long)npix, 1, c);
+    int nch = pix_chunks((long)npix, 1, c, 4096);
     size_t chunk = (npix + nch - 1) / nch;
     SHM_DISPATCH_G(dtype, "shm_lrelu_bwd",
                  hipLaunchKernelGGL((lrelu_bwd_kernel<T, TG>), dim3(shm_cdiv((long)npix, (long)chunk)), dim3(256), 0, (hipStream_t)stream, (const TG*)dy, lddy,
