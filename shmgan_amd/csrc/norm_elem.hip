@@ -52,7 +52,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.reduce_blocks", "SHM_ELEM_REDUCE_BLOCKS", 0, 0, 1 << 20},
     {"elem.nt_loads", "SHM_ELEM_NT", 0, 0, 1},
     {"elem.chunk_mb", "SHM_ELEM_CHUNK_MB", 0, 0, 1 << 20},
-    {"elem.interleave", "SHM_ELEM_INTERLEAVE", 0, 0, 1},
+    {"elem.interleave", "SHM_ELEM_INTERLEAVE", 1, 0, 1},
     {"elem.stream_blocks", "SHM_ELEM_STREAM_BLOCKS", 32768, 256, 1 << 20},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
@@ -637,7 +637,16 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
         };
         constexpr int U = 4;
         int p = p0 + pp;
-        for (; p + (U - 1) * PP < p1; p += U * PP) {
+        // k.interleave ("elem.interleave"): a sample's blocks take tiles of U * PP pixels round-robin (back to front under k.rev) instead of
+        // one contiguous chunk each: see in_bwd_apply_kernel
+        const int tile = U * PP, ntiles = hw / tile;
+        int pstep = tile, pend = p1;
+        if (k.interleave) {
+            p = (k.rev ? ntiles - 1 - (int)blockIdx.x : (int)blockIdx.x) * tile + pp;
+            pstep = (k.rev ? -(int)gridDim.x : (int)gridDim.x) * tile;
+            pend = ntiles * tile;
+        }
+        for (; p >= 0 && p + (U - 1) * PP < pend; p += pstep) {
             f32x8 g[U], x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -657,7 +666,13 @@ __global__ __launch_bounds__(256) void in_bwd_reduce8_kernel(const InBwdArgs k) 
                 v[1][e] += (double)sx;
             }
         }
-        for (; p < p1; p += PP) {
+        int ptail = p, ptend = p1;
+        if (k.interleave) {                  // the pixels beyond the last whole tile: block 0, one at a time
+            ptail = blockIdx.x == 0 ? pend + pp : hw;
+            ptend = hw;
+        }
+        p = ptail;
+        for (; p < ptend; p += PP) {
             const f32x8 g = dout(p);
             const f32x8 x = ld8((const bf16_t*)k.a + ((size_t)n * hw + p) * k.lda + cl * 8);
 #pragma unroll
@@ -931,8 +946,8 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     const int hw = h * w;
     k.nbatch = batch;
     InBwdArgs kr = k;
+    k.interleave = kr.interleave = shm_tune(SHM_TUNE_ELEM_INTERLEAVE);
     k.nt = shm_tune(SHM_TUNE_ELEM_NT);          // the apply pass is the last reader of g1
-    k.interleave = shm_tune(SHM_TUNE_ELEM_INTERLEAVE);
     const int rb = shm_tune(SHM_TUNE_ELEM_REDUCE_BLOCKS);
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&

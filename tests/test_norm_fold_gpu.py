@@ -433,3 +433,29 @@ def test_train_step_with_the_fold_in_the_operands(S, F, B, dt):
     if dt != "float32":
         from util import cosine
         assert cosine(host(g1), host(g0)) >= 0.99
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,h,c,pool", [(3, 32, 64, False), (2, 48, 32, True), (2, 16, 256, False), (1, 24, 8, False)])
+def test_in_bwd_pixel_mappings_agree(dt, n, h, c, pool):
+    """"elem.interleave": a sample's blocks take pixel tiles round-robin (default) or one contiguous chunk each -- the same pixels either
+    way (ragged tails included: 24 x 24 and 48 x 48 maps are not whole tiles), so dz and the bias gradient agree to the order of the sums."""
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    a, stats, beta, nt, ahat = _block(rng, n, h, c, dt)
+    g = _t(rng.standard_normal((n, h, h, c)), dt)
+    g2 = _t(rng.standard_normal((n, h // 2, h // 2, c)), dt) if pool else None
+    outs = []
+    for il in (0, 1):
+        ops.set_tuning("elem.interleave", il)
+        dz = torch.full_like(a, 9.0)
+        db = torch.zeros(c, dtype=torch.float64, device="cuda")
+        red = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
+        ops.in_bwd(g, c, g2, c if pool else 0, a, c, stats, red, dz, c, db, n, h, h, c, 0.2)
+        torch.cuda.synchronize()
+        assert float(red.abs().max()) == 0.0
+        outs.append((dz.double(), db.clone()))
+    (z0, b0), (z1, b1) = outs
+    tol = 1e-5 if dt == "f32" else 2e-2
+    assert float((z0 - z1).norm() / z0.norm()) < tol
+    assert float((b0 - b1).abs().max()) < tol * float(b0.abs().max() + 1.0)
