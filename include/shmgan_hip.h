@@ -83,9 +83,12 @@ const char* shm_last_kernel(void);
  *                               contiguous chunk per block (bf16 step 26.2 -> 26.0 ms, fp32 neutral)
  *   "elem.stream_blocks"        block target of the passes without a per-block prologue or reduction (InstanceNorm apply and its pooling
  *                               forms), default 32768: short blocks keep the addresses in flight a narrow band of the tensors
+ *   "elem.apply_blocks"         block target of the InstanceNorm-backward apply pass, default 4096 (every block ends in an LDS reduction and
+ *                               one f64 atomic per channel for the bias gradient: 5.2 TB/s at 4-8k blocks, 4.3 at 32k; without a bias
+ *                               gradient the pass keeps gaining up to 32k: tools/probes/bwd_blocks.py)
  * value < 0 restores the knob's default; key "reset" restores all.  Initial values may be given in the
  * environment (SHM_TAPGEMM_VARIANT, SHM_TAPGEMM_HALO_MIN, SHM_TAPGEMM_SMALLM, SHM_TAPGEMM_PHASE4_MIN, SHM_WGRAD_VARIANT, SHM_WGRAD_BF16_ROWS,
- * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE, SHM_ELEM_REDUCE_BLOCKS, SHM_ELEM_NT, SHM_ELEM_CHUNK_MB, SHM_ELEM_INTERLEAVE, SHM_ELEM_STREAM_BLOCKS), read once.  Knobs change scheduling only, never results beyond the
+ * SHM_WGRAD_BLOCKS, SHM_STATS_FUSION, SHM_ELEM_REVERSE, SHM_ELEM_REDUCE_BLOCKS, SHM_ELEM_NT, SHM_ELEM_CHUNK_MB, SHM_ELEM_INTERLEAVE, SHM_ELEM_STREAM_BLOCKS, SHM_ELEM_APPLY_BLOCKS), read once.  Knobs change scheduling only, never results beyond the
  * summation order of a tile shape. */
 #define SHM_TG_AUTO 0
 #define SHM_TG_HALO128 1

@@ -33,6 +33,7 @@ enum ShmTune {
     SHM_TUNE_ELEM_CHUNK_MB,           // shm_in_bwd: reduce + apply per chunk of samples whose tensors fit this many MiB (0 = the whole batch at once)
     SHM_TUNE_ELEM_INTERLEAVE,         // InstanceNorm-backward apply pass: a sample's blocks take pixel tiles round-robin instead of one contiguous chunk each
     SHM_TUNE_ELEM_STREAM_BLOCKS,      // block target of the streaming elementwise passes (InstanceNorm apply / backward apply, pooling forms)
+    SHM_TUNE_ELEM_APPLY_BLOCKS,       // block target of the InstanceNorm-backward apply pass
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);

@@ -54,6 +54,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.chunk_mb", "SHM_ELEM_CHUNK_MB", 0, 0, 1 << 20},
     {"elem.interleave", "SHM_ELEM_INTERLEAVE", 1, 0, 1},
     {"elem.stream_blocks", "SHM_ELEM_STREAM_BLOCKS", 32768, 256, 1 << 20},
+    {"elem.apply_blocks", "SHM_ELEM_APPLY_BLOCKS", 4096, 256, 1 << 20},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -169,8 +170,8 @@ struct PixMap {
 static int pix_chunks(long npix_per_sample, int batch, int c, int blocks = 0) {
     // enough blocks to fill the chip, but at least 8 (streaming target) / 16 pixel iterations per thread so the
     // per-block LDS reduction + f64 atomics (one per channel and block) stay a small fraction
-    const int min_iter = blocks == 0 ? 8 : 16;
     if (blocks == 0) blocks = shm_tune(SHM_TUNE_ELEM_STREAM_BLOCKS);
+    const int min_iter = blocks > 4096 ? 8 : 16;
     int lanes_c = c / 4;
     int PP = 256 / lanes_c;
     long want = (blocks + batch - 1) / batch;
@@ -971,7 +972,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         // data moves in 40) and the 512-channel maps issue 1.3 M atomics per launch.  Fewer, longer blocks -- about the same bytes per
         // block in both dtypes: bf16 step 27.8 -> 27.1 ms, fp32 123.4 -> 122.9.  (The apply pass, one atomic per channel and block, is faster with
         // its 4096 blocks: same grid for both measured +0.15 / +0.6 ms.)
-        k.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, 4096));
+        k.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, shm_tune(SHM_TUNE_ELEM_APPLY_BLOCKS)));
         kr.chunk = shm_cdiv(hw, pix_chunks(hw, nb, c, rb ? rb : (dtype == SHM_F32 ? 1024 : 512)));
         const dim3 grid(shm_cdiv(hw, k.chunk), nb), gridr(shm_cdiv(hw, kr.chunk), nb);
         if (wide8) {
@@ -1041,7 +1042,7 @@ extern "C" int shm_in_bwd_apply(const void* g1, int ldg1, const void* g2, int ld
                 shm_tune(SHM_TUNE_ELEM_NT), 0, batch};
     k.interleave = shm_tune(SHM_TUNE_ELEM_INTERLEAVE);
     const int hw = h * w;
-    k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, 4096));
+    k.chunk = shm_cdiv(hw, pix_chunks(hw, batch, c, shm_tune(SHM_TUNE_ELEM_APPLY_BLOCKS)));
     const dim3 grid(shm_cdiv(hw, k.chunk), batch);
     if (g2)
         SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, true, false, true>), grid, dim3(256), 0, st, k));
