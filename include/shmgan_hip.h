@@ -79,8 +79,8 @@ const char* shm_last_kernel(void);
  *                               loads, 0 plain loads (default; round-3 A/B in DESIGN.md section 8)
  *   "elem.chunk_mb"             shm_in_bwd runs its reduce and apply passes per chunk of samples whose tensors fit this many MiB, so that
  *                               the apply pass re-reads them from the Infinity Cache; 0 = the whole batch at once (default)
- *   "elem.interleave"           1 (default): the InstanceNorm-backward passes deal a sample's pixel tiles round-robin over its blocks, 0: one
- *                               contiguous chunk per block (bf16 step 26.2 -> 26.0 ms, fp32 neutral)
+ *   "elem.interleave"           bf16 activations: 1 (default) the InstanceNorm-backward passes deal a sample's pixel tiles round-robin over its
+ *                               blocks, 0 one contiguous chunk per block (bf16 step 26.2 -> 26.0 ms; float32 always takes the chunk form)
  *   "elem.stream_blocks"        block target of the passes without a per-block prologue or reduction (InstanceNorm apply and its pooling
  *                               forms), default 32768: short blocks keep the addresses in flight a narrow band of the tensors
  *   "elem.apply_blocks"         block target of the InstanceNorm-backward apply pass, default 4096 (every block ends in an LDS reduction and

@@ -715,8 +715,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
         if (pm.active) wr = *(const f32x4*)(k.r1_w + pm.cl * 4);
     }
     const int n = k.n0 + blockIdx.y, hw = k.h * k.w;
-    const int p0 = blockIdx.x * k.chunk;
-    int p1 = min(hw, p0 + k.chunk);
+    const int p0 = blockIdx.x * k.chunk, p1 = min(hw, p0 + k.chunk);
+    // interleaved pixel mapping ("elem.interleave"): bf16 activations only -- a compile-time property of the instantiation, because the
+    // float32 pass gains nothing from it and loses 5 % to the extra loop bookkeeping when it is a run-time option (4.12 -> 4.34 ms per step)
+    constexpr bool IL = sizeof(T) == 2;
     // RAW: the two means of every channel, formed ONCE per block from the slot copies (thread ch sums channel ch's slots: with every
     // thread summing the slots of its own four channels the pass spent a third of its time re-reading 64 doubles per thread)
     __shared__ float sm12[RAW ? 2048 : 2];
@@ -763,12 +765,13 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
         // contiguous chunk each -- at any instant the chip then reads a narrow band of the tensors instead of ~2000 separate places
         const int tile = U * pm.PP;
         int pstep = tile, pend = p1;
-        if (k.interleave) {
-            p = blockIdx.x * tile + pm.pp;
-            pstep = gridDim.x * tile;
-            pend = hw - hw % tile;
-        }
-        for (; p + (U - 1) * pm.PP < pend; p += pstep) {
+        if constexpr (IL)
+            if (k.interleave) {
+                p = blockIdx.x * tile + pm.pp;
+                pstep = gridDim.x * tile;
+                pend = hw - hw % tile;
+            }
+        for (; p + (U - 1) * pm.PP < (IL ? pend : p1); p += (IL ? pstep : tile)) {
             f32x4 g[U], x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -791,11 +794,13 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[0][e] += (double)sd[e];
         }
-        if (k.interleave) {                  // the pixels beyond the last whole tile: block 0, one at a time
-            p = blockIdx.x == 0 ? pend + pm.pp : hw;
-            p1 = hw;
-        }
-        for (; p < p1; p += pm.PP) {
+        int ptend = p1;
+        if constexpr (IL)
+            if (k.interleave) {              // the pixels beyond the last whole tile: block 0, one at a time
+                p = blockIdx.x == 0 ? pend + pm.pp : hw;
+                ptend = hw;
+            }
+        for (; p < (IL ? ptend : p1); p += pm.PP) {
             f32x4 g = in_bwd_dout<TG, G2, R1>(k, n, p, pm.cl, wr);
             f32x4 x = ld4((const T*)k.a + ((size_t)n * hw + p) * k.lda + pm.cl * 4);
             f32x4 d;
