@@ -32,7 +32,7 @@ IN_EPS = 1e-6
 #                     pass does at 128 x 128 and more below; in bfloat16, whose MFMA loops are 6 x shorter, it costs 2-4 x the pass.
 #   "all"             fold wherever the kernels can (tests, A/B measurements)
 #   "0"               never
-_FOLD_VALUES = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all", "fake": "all"}
+_FOLD_VALUES = {"0": False, "": False, "1": "auto", "auto": "auto", "all": "all"}
 if os.environ.get("SHM_NORM_FOLD", "auto") not in _FOLD_VALUES:
     raise ValueError(f"SHM_NORM_FOLD={os.environ['SHM_NORM_FOLD']!r}: expected one of auto, all, 0")
 NORM_FOLD = _FOLD_VALUES[os.environ.get("SHM_NORM_FOLD", "auto")]
@@ -43,7 +43,6 @@ NORM_FOLD = _FOLD_VALUES[os.environ.get("SHM_NORM_FOLD", "auto")]
 if os.environ.get("SHM_NORM_MODE", "exact") not in ("exact", "scaled"):
     raise ValueError(f"SHM_NORM_MODE={os.environ['SHM_NORM_MODE']!r}: expected exact or scaled")
 NORM_MODE = ops.NORM_SCALED if os.environ.get("SHM_NORM_MODE", "exact") == "scaled" else ops.NORM_EXACT
-_FAKE_FOLD = os.environ.get("SHM_NORM_FOLD") == "fake"      # timing only (WRONG results): the folded tensors are consumed un-normalised by the plain kernels
 WGRAD_AFTER_DGRAD = os.environ.get("SHM_WGRAD_AFTER_DGRAD", "0") == "1"
 PAD_C = 16          # channel pitch of 3- and 10-channel images in float32 (one 64-byte MFMA staging row)
 
@@ -484,7 +483,7 @@ class Generator(_ModelBase):
         if sync is not None:
             sync.before(part)
         wk_, bias_, mode = self.wk[li], self.P.vars[2 * li + 1], ops.NORM_EXACT
-        folded_in = (ntx is not None or ntx2 is not None) and not _FAKE_FOLD
+        folded_in = (ntx is not None or ntx2 is not None)
         if folded_in and self.norm_mode == ops.NORM_SCALED:
             # the normalisation in the operands: one weight copy (the folded source's channels times inv) and one bias row per sample
             src_nt, lo, c = (ntx, 0, ldx) if ntx is not None else (ntx2, c1, ldx2)
@@ -494,7 +493,7 @@ class Generator(_ModelBase):
             wk_, bias_, mode = wn[r0:r1], bn[r0:r1], ops.NORM_SCALED
         ops.conv2d_in_fwd(x[r0:r1], None if x2 is None else x2[r0:r1], c1, ldx, ldx2, wk_, bias_, a[r0:r1], cout, nb, h, w,
                           cin_p, cout, k, 1, LRELU, st, IN_EPS, cin_real=cin, scratch=scr,
-                          nt_x=None if (ntx is None or _FAKE_FOLD) else ntx[r0:r1], nt_x2=None if (ntx2 is None or _FAKE_FOLD) else ntx2[r0:r1],
+                          nt_x=None if ntx is None else ntx[r0:r1], nt_x2=None if ntx2 is None else ntx2[r0:r1],
                           nt_out=None if nt is None else nt[r0:r1], beta_out=self.betas[bi] if fold else None, norm_mode=mode)
         if sync is not None:
             sync.after(part)
@@ -655,7 +654,7 @@ class Generator(_ModelBase):
         dz = A.get(f"bwd/dz/L{li}/{n}", (n, h, w, cout), self.adt)       # per layer: read later by the wgrad lane
         # a source folded in the operands (SHM_NORM_SCALED): the weight gradient's second term needs the per-sample channel sums of dz,
         # which the InstanceNorm backward below stages on the way to the bias gradient
-        scaled = self.norm_mode == ops.NORM_SCALED and not _FAKE_FOLD and (rec["ntx"] is not None or rec["ntx2"] is not None)
+        scaled = self.norm_mode == ops.NORM_SCALED and (rec["ntx"] is not None or rec["ntx2"] is not None)
         dzsum = None
         if scaled:
             dzsum = A.get(f"bwd/dzsum/L{li}/{n}", (n, cout), torch.float64)
@@ -680,7 +679,7 @@ class Generator(_ModelBase):
 
         def wgrad_launches():
             ops.conv2d_wgrad(rec["x"], rec["x2"], rec["c1"], rec["ldx"], rec["ldx2"], dz, cout, self.P.grads[2 * li], n, h, w, cin, cin_p, cout, k, 1, 1, ws,
-                             nt_x=None if _FAKE_FOLD else rec["ntx"], nt_x2=None if _FAKE_FOLD else rec["ntx2"],
+                             nt_x=rec["ntx"], nt_x2=rec["ntx2"],
                              norm_mode=ops.NORM_SCALED if scaled else ops.NORM_EXACT)
             if scaled:
                 src_nt, lo, c = (rec["ntx"], 0, rec["ldx"]) if rec["ntx"] is not None else (rec["ntx2"], rec["c1"], rec["ldx2"])
