@@ -12,6 +12,10 @@ taps stay zero, hence every check here is BITWISE against the two-pass path (shm
     agree with what the entry points then do;
   * the whole train_step with the fold on and off: same losses and gradients to the run-to-run bound of a step (the statistics
     sums are float64 atomics, whose order is not fixed: tests/test_train_loop_gpu.py::test_step_is_reproducible_run_to_run).
+The second half of the file is SHM_NORM_SCALED, the same fold carried by the operands (per-sample weights w * inv and bias rows, `ring`
+in the out-of-image taps, weight-gradient slabs scaled per sample + a rank-n term): equal to the two-pass path to ROUNDING -- fp32
+outputs 3e-6, weight gradients 2e-5, border rows and columns on their own, the whole step within the oracle contract -- plus the
+per-sample dz sums the InstanceNorm backward keeps for it and the pixel mappings of the backward passes ("elem.interleave").
 """
 import numpy as np
 import pytest
