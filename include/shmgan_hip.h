@@ -67,7 +67,7 @@ const char* shm_last_kernel(void);
  *   "tapgemm.small_grid_blocks" grids with fewer 128x128 tiles take the 64x128 tile (default 1024)
  *   "tapgemm.phase4_min_blocks" stride-2 transposed 3x3 products with at least this many fused (16x16 input pixels x 64 channels) blocks
  *                               take the four-phases-in-one-block kernel (default 256)
- *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing
+ *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing, 3 no stride-2 halo form
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)
  *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass

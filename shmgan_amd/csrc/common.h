@@ -23,7 +23,7 @@ enum ShmTune {
     SHM_TUNE_TAPGEMM_HALO_MIN,        // fp32: 128-wide halo blocks from which the 128-wide block is taken unconditionally
     SHM_TUNE_TAPGEMM_SMALL_GRID,      // grids below this many 128x128 tiles take the 64x128 tile
     SHM_TUNE_TAPGEMM_PHASE4_MIN,      // four-phase (stride-2 transposed) launches with at least this many fused blocks take tapgemm_phase4_kernel
-    SHM_TUNE_WGRAD_VARIANT,           // 0 = automatic, 1 = generic kernel only, 2 = halo kernel but no thin-input packing
+    SHM_TUNE_WGRAD_VARIANT,           // 0 = automatic, 1 = generic kernel only, 2 = halo kernel but no thin-input packing, 3 = no stride-2 halo form
     SHM_TUNE_WGRAD_BLOCKS,            // split-K target (blocks), 0 = automatic
     SHM_TUNE_WGRAD_BF16_ROWS,         // wgrad_halo_bf16_kernel: pixel rows per stage, 0 = automatic (4 when the map allows), 2 or 4
     SHM_TUNE_STATS_FUSION,            // 1 = InstanceNorm statistics in the conv epilogue (default), 0 = separate pass

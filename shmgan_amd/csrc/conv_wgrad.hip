@@ -487,11 +487,22 @@ __device__ __forceinline__ f32x4 load16_drained(const float* p) {
 // NM: a wave normalises the halo items it DMA'd itself, one stage ahead of their use.  A lane's four channels are the same for
 // every item and patch (no swizzle in this image), so their (mean, inv, beta) live in registers and are re-read when the image
 // changes (at most a few times per block).
-template <int NM = 0>
+// IS = 2 (round 3): the stride-2 3x3 layers (SAME padding of an even map: no pad before, one row / column after).  A stage is a patch of
+// 2 x 8 OUTPUT pixels and its 5 x 17 input halo -- 22 + 4 DMA items, the same 26 KiB stage, per-wave DMA counts and waits as the
+// unit-stride form, with half the MFMAs per barrier; tap (kh, kw) of output pixel (qr, qc) is halo pixel (2 qr + kh, 2 qc + kw), still an
+// immediate offset on the ds_read_b32 (a lane reads one float of a 128-byte run whatever the pixel stride: no bank conflicts).
+// Against wgrad_kernel<9> (nine shifted tiles through registers, a barrier per 8 pixels): 5.3 input pixels fetched per output pixel
+// instead of 9, no VGPR staging, no ds_write, a barrier per 16 pixels.
+template <int NM = 0, int IS = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs a) {
-    constexpr int PW = 16, HC = PW + 2;                 // patch 2 x 16, halo 4 x 18
-    constexpr int NHP = 4 * HC, NPX = 2 * PW;           // 72 halo pixels, 32 output pixels
-    constexpr int STAGE = (NHP + NPX) * 64;             // floats per stage
+    static_assert(IS == 1 || (IS == 2 && NM == 0), "norm: unit-stride form");
+    constexpr int PW = IS == 1 ? 16 : 8, HC = IS * PW + 3 - IS, HR = 2 * IS + 3 - IS;    // patch 2 x 16, halo 4 x 18 | 2 x 8, 5 x 17
+    constexpr int PAD = IS == 1 ? 1 : 0;
+    constexpr int NHP = HR * HC, NPX = 2 * PW;          // 72 halo pixels, 32 output pixels | 85, 16
+    constexpr int NXI = (NHP + 3) / 4, NDI = NPX / 4;   // DMA items (4 pixel rows each): 18 + 8 | 22 + 4
+    constexpr int NXJ = (NXI + 3) / 4;                  // X items per wave, at most
+    static_assert(NXI + NDI == 26, "26 items per stage: waves 0, 1 issue seven, waves 2, 3 six (wait_older)");
+    constexpr int STAGE = (NXI + NDI) * 256;            // floats per stage
     constexpr int NST = 3;
     __shared__ __attribute__((aligned(1024))) float smem[NST * STAGE];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -523,48 +534,72 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     // items 0..17: halo rows [4i,4i+4); items 18..25: dY rows.  Wave w takes items w, w+4, ...
     // per-lane constants of the X items (j = 0..4): halo coordinates of this lane's pixel
-    int hr[5], hc[5];
+    [[maybe_unused]] int hr[NXJ], hc[NXJ];                 // (NM: norm_x)
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NXJ; ++j) {
         const int hp = 4 * (wave + 4 * j) + dpx;
         hr[j] = hp / HC;
         hc[j] = hp - hr[j] * HC;
     }
 
-    // running patch coordinate (block-uniform)
+    // running patch coordinate (block-uniform), in OUTPUT pixels (ho x wo = h / IS x w / IS)
+    const int ho = a.h / IS, wo = a.w / IS;
     int n, pr, pc;
     {
-        const int ppr = a.w / PW, ppi = (a.h / 2) * ppr;
+        const int ppr = wo / PW, ppi = (ho / 2) * ppr;
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
         pr = (r / ppr) * 2;
         pc = (r % ppr) * PW;
     }
+    // DMA addressing, one v_add and one masked select per instruction: a lane's byte offset in item j is a per-lane constant plus the
+    // patch origin, and whether its halo pixel lies outside the image depends only on which edges of the image the patch touches
+    // (block-uniform, four bits) and on which edges of the halo the lane's pixel sits (per-lane constant, four bits per item; a fifth
+    // marks lanes with nothing to fetch -- channel tail, tail of the last halo item -- and is always asked for).  (Until round 3 every
+    // stage recomputed coordinates, range tests and exec-masked selects per item: ~450 instructions between the barrier and the
+    // stage's first MFMA.)  The LDS destination is item * 1 KiB for both kinds of item (the dY rows follow the halo); descriptor and
+    // origin are scalar selects.
+    unsigned off0[7], bma = 0, bmb = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int item = wave + 4 * j;
+        unsigned bits;
+        if (item < NXI) {
+            const int hp = 4 * item + dpx;
+            const int r = hp / HC, c = hp - r * HC;
+            off0[j] = (unsigned)((r * a.w + c) * ldX + ccX) * 4u;
+            bits = !(xvalid && hp < NHP) ? 16u : ((PAD && r == 0) ? 1u : 0u) | (r == HR - 1 ? 2u : 0u) | ((PAD && c == 0) ? 4u : 0u) | (c == HC - 1 ? 8u : 0u);
+        } else {
+            const int q = 4 * (item - NXI) + dpx;
+            off0[j] = (unsigned)(((q / PW) * (a.w / IS) + q % PW) * a.lddy + coD) * 4u;
+            bits = (dvalid && item < NXI + NDI) ? 0u : 16u;
+        }
+        if (j < 4)
+            bma |= bits << (8 * j);
+        else
+            bmb |= bits << (8 * (j - 4));
+    }
     auto dma = [&](int stage) {
         float* sx = smem + stage * STAGE;
-        float* sd = sx + NHP * 64;
-        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
+        const int org = (n * a.h + IS * pr - PAD) * a.w + (IS * pc - PAD);       // pixel index of halo (0,0)
+        const unsigned edges = 16u | ((PAD && pr == 0) ? 1u : 0u) | (pr + 2 == ho ? 2u : 0u) | ((PAD && pc == 0) ? 4u : 0u) | (pc + PW == wo ? 8u : 0u);
+        const unsigned xb = (unsigned)(org * ldX) * 4u, db = (unsigned)(((n * ho + pr) * wo + pc) * a.lddy) * 4u;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int item = wave + 4 * j;
-            if (item < 18) {
-                const int iy = pr - 1 + hr[j < 5 ? j : 0], ix = pc - 1 + hc[j < 5 ? j : 0];
-                const bool v = xvalid && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-                const unsigned off = v ? (unsigned)((org + hr[j < 5 ? j : 0] * a.w + hc[j < 5 ? j : 0]) * ldX + ccX) * 4u : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
-            } else if (item < 26) {
-                const int q = 4 * (item - 18) + dpx;
-                const int oy = pr + (q >> 4), ox = pc + (q & 15);
-                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 4u : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - 18) * 256), 16, (int)off, 0, 0, 0);
+            if (j < 6 || wave < 2) {
+                const bool isx = item < NXI;                   // wave-uniform
+                const unsigned out = (j < 4 ? bma : bmb) & (edges << (8 * (j & 3)));
+                const unsigned off = out ? 0xffffffffu : off0[j] + (isx ? xb : db);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
             }
         }
         pc += PW;
-        if (pc == a.w) {
+        if (pc == wo) {
             pc = 0;
             pr += 2;
-            if (pr == a.h) {
+            if (pr == ho) {
                 pr = 0;
                 ++n;
             }
@@ -655,18 +690,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int xl = hh * 64 + mi * 32 + l31;       // + ((qr+kh)*18 + qc + kw)*64, qc even part
+    const int xl = hh * 64 * IS + mi * 32 + l31;  // + ((IS*qr+kh)*HC + IS*qc + kw)*64, qc even part
     const int dl = hh * 64 + ni * 32 + l31;       // + 2*kk*64
     auto compute = [&](int stage) {
         const float* X = smem + stage * STAGE + xl;
-        const float* D = smem + stage * STAGE + NHP * 64 + dl;
+        const float* D = smem + stage * STAGE + NXI * 256 + dl;
 #pragma unroll
         for (int kk = 0; kk < NPX / 2; ++kk) {
-            const int qr = kk >> 3, qc = 2 * (kk & 7);
+            const int qr = kk / (PW / 2), qc = 2 * (kk % (PW / 2));
             const float bv = D[kk * 128];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const float av = X[((qr + t / 3) * HC + qc + t % 3) * 64];
+                const float av = X[((IS * qr + t / 3) * HC + IS * qc + t % 3) * 64];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
         }
@@ -1309,13 +1344,16 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     a.pix_per_split = pps;
     hipStream_t st = (hipStream_t)stream;
     const bool straddle = x2 && (c1 % 64 != 0);
-    const int wv = shm_tune(SHM_TUNE_WGRAD_VARIANT);       // 0 automatic, 1 generic kernels only, 2 no thin-input packing
+    const int wv = shm_tune(SHM_TUNE_WGRAD_VARIANT);       // 0 automatic, 1 generic kernels only, 2 no thin-input packing, 3 no stride-2 halo form
     const int no_halo = wv == 1;
     const bool halo_ok = ksize == 3 && stride == 1 && wi % 16 == 0 && hi % 2 == 0 && !straddle && !no_halo;
     const int no_thin = wv == 2;
     // thin first layers: (tap, ci) pairs packed into the MFMA rows; patches of 2 x 16 OUTPUT pixels
     const bool thin_ok = !no_thin && !no_halo && ksize == 3 && !x2 && 9 * cin <= 96 && ldx == 16 && cin_ld <= 16 && wo % 16 == 0 && ho % 2 == 0 &&
                          hi % stride == 0 && wi % stride == 0;
+    // stride 2 (wv == 3: not this form): SAME padding of an even map puts nothing before the first row / column
+    const bool halo2_ok = ksize == 3 && stride == 2 && pt == 0 && pl == 0 && hi % 2 == 0 && wi % 2 == 0 && wo % 8 == 0 && ho % 2 == 0 && !straddle &&
+                          !no_halo && wv != 3 && !(thin_ok && dtype == SHM_F32);
     // norm: the halo-image kernels normalise their x halo in LDS (a block's 64 input channels lie in one source: no straddle)
     const bool want_nm = g_wnorm.nt != nullptr;
     if (want_nm || g_wnorm.query) {
@@ -1427,6 +1465,32 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
             hipLaunchKernelGGL((wgrad_halo_thin_kernel<3, 2>), dim3(1, shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
             shm_set_last_kernel("wgrad_halo_thin_kernel<3, 2>");
         }
+    } else if (dtype == SHM_F32 && halo2_ok) {
+        // stride-2 3x3 layers: patches of 2 x 8 OUTPUT pixels with a 5 x 17 input halo
+        WgradHaloArgs hgs{};
+        hgs.x = x;
+        hgs.x2 = x2;
+        hgs.c1 = a.c1;
+        hgs.ldx = ldx;
+        hgs.ldx2 = ldx2;
+        hgs.dy = dy;
+        hgs.lddy = lddy;
+        hgs.part = (float*)workspace;
+        hgs.h = hi;
+        hgs.w = wi;
+        hgs.cin_ld = cin_ld;
+        hgs.cin = cin;
+        hgs.cout = cout;
+        hgs.npatch = batch * (ho / 2) * (wo / 8);
+        int nsh = ns < hgs.npatch ? ns : hgs.npatch;
+        hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        hgs.xbytes = a.xbytes;
+        hgs.x2bytes = a.x2bytes;
+        hgs.dybytes = a.dybytes;
+        ns = nsh;
+        hipLaunchKernelGGL((wgrad_halo_kernel<0, 2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+        shm_set_last_kernel("wgrad_halo_kernel<0, 2>");
     } else if (halo_ok) {
         const bool thin = thin_ok;
         WgradHaloArgs hgs{};

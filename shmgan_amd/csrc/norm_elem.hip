@@ -44,7 +44,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"tapgemm.halo_min_blocks", "SHM_TAPGEMM_HALO_MIN", 1024, 0, 1 << 30},
     {"tapgemm.small_grid_blocks", "SHM_TAPGEMM_SMALLM", 1024, 0, 1 << 30},
     {"tapgemm.phase4_min_blocks", "SHM_TAPGEMM_PHASE4_MIN", 256, 0, 1 << 30},
-    {"wgrad.variant", "SHM_WGRAD_VARIANT", 0, 0, 2},
+    {"wgrad.variant", "SHM_WGRAD_VARIANT", 0, 0, 3},
     {"wgrad.blocks", "SHM_WGRAD_BLOCKS", 0, 0, 1 << 20},
     {"wgrad.bf16_rows", "SHM_WGRAD_BF16_ROWS", 0, 0, 4},
     {"stats.fusion", "SHM_STATS_FUSION", 1, 0, 1},

@@ -382,6 +382,57 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
         assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
 
 
+# ---- stride-2 3x3 weight gradient: halo form (2 x 8 output patches, 5 x 17 input halo) against the generic kernel and float64
+@pytest.mark.parametrize("n,h,cin,cout,c1,blocks", [
+    (2, 32, 64, 128, 0, 0), (3, 16, 64, 64, 0, 0), (1, 64, 128, 64, 0, 0), (2, 32, 96, 80, 0, 0), (2, 32, 128, 64, 64, 0),
+    (2, 32, 64, 128, 0, 7), (5, 16, 192, 64, 128, 3), (1, 16, 32, 16, 0, 0),
+])
+def test_wgrad_stride2_halo(n, h, cin, cout, c1, blocks):
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    dy = rng.standard_normal((n, h // 2, h // 2, cout)).astype(np.float32)
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(x.astype(np.float64)), wt, 2), wt, nchw(dy.astype(np.float64)))
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, cin, cout, 3) // 4 + 1024, device="cuda")
+    xa = torch.from_numpy(np.ascontiguousarray(x[..., :c1] if c1 else x)).cuda()
+    xb = torch.from_numpy(np.ascontiguousarray(x[..., c1:])).cuda() if c1 else None
+    dyd = torch.from_numpy(dy).cuda()
+    got = {}
+    for wv in (0, 3):
+        ops.set_tuning("wgrad.variant", wv)
+        ops.set_tuning("wgrad.blocks", blocks)
+        dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+        ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
+        k = ops.last_kernel()
+        assert k == ("wgrad_halo_kernel<0, 2>" if wv == 0 else "wgrad_kernel<9, false>"), k
+        got[wv] = host(dw)
+        assert rel_l2(got[wv], ref.numpy()) < 1e-5, (k, rel_l2(got[wv], ref.numpy()))
+        # accumulate into the result
+        ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 1, ws)
+        assert rel_l2(host(dw), 2 * ref.numpy()) < 1e-5
+    ops.set_tuning("reset", 0)
+    assert rel_l2(got[0], got[3]) < 1e-5
+
+
+def test_wgrad_stride2_halo_refuses_what_it_cannot_tile():
+    """an 8 x 8 map (4 output columns) and a concat split inside a 64-channel tile stay on the generic kernel"""
+    ops = _ops()
+    rng = np.random.default_rng(32)
+    for n, h, cin, cout, c1 in ((2, 8, 64, 64, 0), (2, 32, 96, 64, 32)):
+        x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+        dy = rng.standard_normal((n, h // 2, h // 2, cout)).astype(np.float32)
+        wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+        ref, = torch.autograd.grad(st.conv2d_same(nchw(x.astype(np.float64)), wt, 2), wt, nchw(dy.astype(np.float64)))
+        ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, cin, cout, 3) // 4 + 1024, device="cuda")
+        xa = torch.from_numpy(np.ascontiguousarray(x[..., :c1] if c1 else x)).cuda()
+        xb = torch.from_numpy(np.ascontiguousarray(x[..., c1:])).cuda() if c1 else None
+        dw = torch.empty((3, 3, cin, cout), device="cuda")
+        ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, torch.from_numpy(dy).cuda(), cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
+        assert ops.last_kernel().startswith("wgrad_kernel<9"), ops.last_kernel()
+        assert rel_l2(host(dw), ref.numpy()) < 1e-5
+
+
 # ======================================================================================================
 # Real layer shapes of BASELINE configs[1] (S=256, F=64, B=8) through the DEFAULT dispatch.  The float64
 # reference convolutions take a few seconds each on the GPU box's host cores.
