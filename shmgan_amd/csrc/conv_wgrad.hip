@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
                                               : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     // items 0..9: halo rows [8i, 8i+8); items 10..13: dY rows.  Wave w takes items w, w+4, w+8, w+12.
-    int hr[NXJ], hc[NXJ];
+    [[maybe_unused]] int hr[NXJ], hc[NXJ];                 // (NM: norm_x)
 #pragma unroll
     for (int j = 0; j < NXJ; ++j) {
         const int hp = 8 * (wave + 4 * j) + drow;
@@ -992,24 +992,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
         pr = (r / ppr) * R;
         pc = (r % ppr) * PW;
     }
+    // DMA addressing as in wgrad_halo_kernel: per-lane constant offset + patch origin, edge bits (five per item, one register)
+    static_assert(NJ <= 6, "five mask bits per item in one register");
+    unsigned off0[NJ], bm = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int item = wave + 4 * j;
+        unsigned bits;
+        if (item < NXI) {
+            const int hp = 8 * item + drow;
+            const int r_ = hp / HP, c_ = hp - r_ * HP;
+            off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 2u;
+            bits = !(xvalid && c_ < PW + 2) ? 16u : (r_ == 0 ? 1u : 0u) | (r_ == R + 1 ? 2u : 0u) | (c_ == 0 ? 4u : 0u) | (c_ == PW + 1 ? 8u : 0u);
+        } else {
+            const int q = 8 * (item - NXI) + drow;
+            off0[j] = (unsigned)(((q >> 4) * a.w + (q & 15)) * a.lddy + coD) * 2u;
+            bits = (dvalid && item < NIT) ? 0u : 16u;
+        }
+        bm |= bits << (5 * j);
+    }
     auto dma = [&](int stage) {
         unsigned short* sx = smem + stage * STAGE;
-        unsigned short* sd = sx + NHR * 64;
         const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
+        const unsigned edges = 16u | (pr == 0 ? 1u : 0u) | (pr + R == a.h ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc + PW == a.w ? 8u : 0u);
+        const unsigned xb = (unsigned)(org * ldX) * 2u, db = (unsigned)(((n * a.h + pr) * a.w + pc) * a.lddy) * 2u;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int item = wave + 4 * j;
-            if (item < NXI) {
-                const int r_ = hr[j < NXJ ? j : 0], c_ = hc[j < NXJ ? j : 0];
-                const int iy = pr - 1 + r_, ix = pc - 1 + c_;
-                const bool v = xvalid && c_ < PW + 2 && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-                const unsigned off = v ? (unsigned)((org + r_ * a.w + c_) * ldX + ccX) * 2u : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
-            } else if (item < NXI + NDI) {
-                const int q = 8 * (item - NXI) + drow;
-                const int oy = pr + (q >> 4), ox = pc + (q & 15);
-                const unsigned off = dvalid ? (unsigned)(((n * a.h + oy) * a.w + ox) * a.lddy + coD) * 2u : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr)(sd + (item - NXI) * 512), 16, (int)off, 0, 0, 0);
+            if (j < NJ - 1 || item < NIT) {
+                const bool isx = item < NXI;                   // wave-uniform
+                const unsigned off = (bm & (edges << (5 * j))) ? 0xffffffffu : off0[j] + (isx ? xb : db);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
             }
         }
         pc += PW;
