@@ -1024,34 +1024,36 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             // aux through a scalar descriptor and 32-bit offsets (the part is below 4 GiB); zero-length when the group takes no sums
             const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
             const unsigned ldab = (unsigned)a.ldgaux[gp] * (unsigned)sizeof(T), nlb = (unsigned)(n < a.nout ? nl : 0) * (unsigned)sizeof(T);
+            // ... and so is the group's output part (the launcher fuses the sums only when the outputs are below 4 GiB).  A lane's
+            // address is ONE register per 32 x 32 tile -- its pixel of accumulator row 0 -- plus a scalar offset per row (row r of a lane
+            // is pixel (r >> 3, 8 ((r >> 2) & 1) + (r & 3)) of the tile's two patch rows): no address arithmetic and no address
+            // registers in the element loops (with 64-bit element addresses hipcc kept a pixel index per row and spilled 37 of them
+            // to scratch around the sixteen loads)
+            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(gp ? a.y2 : a.y, 0, gp ? a.y2bytes : a.ybytes, 0x00020000);
+            const unsigned ldyb = (unsigned)(gp ? a.ldy2 : a.ldy) * (unsigned)sizeof(TO), nyb = (unsigned)(n < a.nout ? nl : 0) * (unsigned)sizeof(TO);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const unsigned pix0 = (unsigned)((img * a.hi + (y0 + 2 * TM * wm + 2 * i)) * a.wi + x0 + 4 * h);
+                const unsigned ao = pix0 * ldab + nlb, yo = pix0 * ldyb + nyb;
                 float q[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int py = 2 * TM * wm + 2 * i + (row >> 4), px = row & 15;
-                    const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
+                    const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));         // scalar
                     if constexpr (sizeof(T) == 4)
-                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + nlb, 0, 0));
+                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, cr * ldab, 0));
                     else
-                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, opix * ldab + nlb, 0, 0) << 16);
+                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, ao, cr * ldab, 0) << 16);
                 }
+                if (n < a.nout) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int py = 2 * TM * wm + 2 * i + (row >> 4), px = row & 15;
-                    const size_t opix = ((size_t)img * a.hi + (y0 + py)) * a.wi + (x0 + px);
-                    if (n < a.nout) {
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));
                         float v = acc[i][j][r] + bj[j];
                         const TO vo = (TO)shm_lrelu(v, a.slope);
                         v = (float)vo;
                         s1[j] += v;
                         s2[j] += v * q[r];
-                        if (n < a.n1)
-                            ((TO*)a.y)[opix * a.ldy + n] = vo;
-                        else
-                            ((TO*)a.y2)[opix * a.ldy2 + (n - a.n1)] = vo;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), rsy, yo, cr * ldyb, 0);
                     }
                 }
             }
