@@ -21,6 +21,7 @@
 #include "ablate.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -180,7 +181,9 @@ __device__ __forceinline__ void tap_mfma(const f32x4 (&av)[TM], const f32x4 (&bv
 // T = float or bf16_t.  BK counts 4-byte words per LDS row (16 -> 64-byte rows); a K step covers
 // BKE = BK*4/sizeof(T) channels.
 template <typename T, typename TO, int BM, int BN, int WGM, int WGN, int NST, int BK>
-__global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGemmArgs a) {
+// (eight-wave blocks with element-store epilogues: two blocks per CU fit in LDS, i.e. four waves per SIMD -- the second launch bound
+// keeps them at 128 VGPRs, where hipcc left to itself lands between 121 and 155 depending on the epilogue code around the loop)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && sizeof(TO) == 4) ? 4 : 1) void tapgemm_dma_kernel(const TapGemmArgs a) {
     static_assert(BK == 16 || BK == 32, "K step of 16 words (64-byte LDS rows) or 32 (128-byte rows)");
     constexpr int ESZ = sizeof(T);
     constexpr int BKE = BK * 4 / ESZ;                // channels per K step
@@ -451,7 +454,115 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
         const int oh = t % a.hg, n = t / a.hg;
         return ((size_t)n * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw);
     };
-    if (!wide && gs_any) {
+    // Element stores (and the gsum aux loads) without per-element address arithmetic: the rows of a lane's 32 x 32 accumulator tile are
+    // GEMM rows mb + 8 g + 4 h + e (g = r >> 2, e = r & 3, mb a multiple of 32), so when the phase grid is a multiple of 8 pixels wide
+    // the output pixel of a row is a SCALAR -- (n, oh, ow) of row mb + 8 g, four scalar decompositions per tile -- plus e and 4 h pixel
+    // steps: one per-lane address register for the whole wave tile, everything else in the instruction's scalar offset.  (Per
+    // element it was a 64-bit address from two integer divisions: ~40 VALU instructions, 64 elements per lane.)  Needs outputs below
+    // 4 GiB (scalar descriptors) and every 32-column group inside one output part.
+    const bool fastep = !abl::nostore && a.ybytes != 0 && (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0)) && (direct || a.wg % 8 == 0) &&
+                        a.M % 8 == 0;
+    if (!wide && fastep) {
+        unsigned sp[TM][4];                // scalar: output pixel of GEMM row mb + 8 g of tile i (one decomposition per tile, then steps of 8)
+        bool sv[TM][4];                    // ... and whether that row group exists (M % 8 == 0)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = __builtin_amdgcn_readfirstlane(m0 + wm * WTM + i * 32);
+            int ow = mb % a.wg, t = mb / a.wg;
+            int oh = t % a.hg, ni = t / a.hg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sv[i][g] = mb + 8 * g < a.M;
+                sp[i][g] = direct ? (unsigned)(mb + 8 * g) : (unsigned)((ni * a.ho + (oh * a.os + P.oph)) * a.wo + (ow * a.os + P.opw));
+                ow += 8;
+                if (ow >= a.wg) {          // wg % 8 == 0: a step of 8 ends exactly on the row end
+                    ow = 0;
+                    if (++oh == a.hg) {
+                        oh = 0;
+                        ++ni;
+                    }
+                }
+            }
+        }
+        auto elem_stores = [&](auto gsx) {
+            constexpr bool GSX = decltype(gsx)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * WTN + j * 32);
+            const int gp = nb < a.n1 ? 0 : 1;
+            const bool on = GSX && a.gred[gp] != nullptr && nb < a.nout;
+            const int n = nb + l31;
+            const int nl = n - (gp ? a.n1 : 0);
+            const int pc = gp ? a.nout - a.n1 : a.n1;
+            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(gp ? a.y2 : a.y, 0, gp ? a.y2bytes : a.ybytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
+            const unsigned ldyb = (unsigned)(gp ? a.ldy2 : a.ldy) * (unsigned)sizeof(TO), ldab = (unsigned)a.ldgaux[gp] * (unsigned)sizeof(T);
+            const unsigned lanepix = (unsigned)(4 * h * a.os);
+            const unsigned yo = lanepix * ldyb + (unsigned)(n < a.nout ? nl : 0) * (unsigned)sizeof(TO);
+            const unsigned ao = lanepix * ldab + (unsigned)(n < a.nout ? nl : 0) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                [[maybe_unused]] float q[GSX ? 16 : 1];
+#pragma unroll
+                for (int r = 0; r < (GSX ? 16 : 1); ++r) q[r] = 0.f;
+                if constexpr (GSX) if (on) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (sv[i][g]) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned so = (sp[i][g] + (unsigned)(e * a.os)) * ldab;
+                                if constexpr (sizeof(T) == 4)
+                                    q[4 * g + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, so, 0));
+                                else
+                                    q[4 * g + e] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, ao, so, 0) << 16);
+                            }
+                        }
+                }
+                if (n < a.nout) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (sv[i][g]) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * g + e;
+                                float v = acc[i][j][r] + bj[j];
+                                const TO vo = (TO)shm_lrelu(v, a.slope);
+                                v = (float)vo;                       // statistics of the value as stored
+                                s1[j] += v;
+                                if constexpr (GSX)
+                                    s2[j] += v * q[r];
+                                else
+                                    s2[j] = __builtin_fmaf(v, v, s2[j]);
+                                const unsigned so = (sp[i][g] + (unsigned)(e * a.os)) * ldyb;
+                                if constexpr (sizeof(TO) == 4)
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), rsy, yo, so, 0);
+                                else
+                                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), rsy, yo, so, 0);
+                            }
+                        }
+                }
+            }
+            const int mw = m0 + wm * WTM;
+            if (on && mw < a.M) {
+                const int img = mw / a.hw;
+                const int slot = ((mw - img * a.hw) / WTM) % a.gslots;
+                const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (h == 0 && n < a.nout) {
+                    double* dst = a.gred[gp] + ((size_t)slot * a.gbatch * pc + (size_t)img * pc + nl) * 2;
+                    atomicAdd(dst, (double)t1);
+                    atomicAdd(dst + 1, (double)t2);
+                }
+            }
+        }
+        };
+        if (gs_any)
+            elem_stores(std::true_type{});
+        else
+            elem_stores(std::false_type{});
+    }
+    if (!wide && gs_any && !fastep) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * WTN + j * 32);
@@ -505,7 +616,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void tapgemm_dma_kernel(const TapGe
             }
         }
     }
-    if (!wide && !gs_any) {
+    if (!wide && !gs_any && !fastep) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1069,7 +1180,40 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             }
         }
     }
-    if (!wide && !gs_any) {
+    // plain element stores: as in the gsum path above, through a scalar descriptor with one address register per 32 x 32 tile and a
+    // scalar offset per row when the outputs are below 4 GiB and a 32-column group lies in one output part
+    const bool ybuf = !abl::nostore && a.ybytes != 0 && (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0));
+    if (!wide && !gs_any && ybuf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * 64 + j * 32);
+            const int gp = nb < a.n1 ? 0 : 1;
+            const int n = nb + l31;
+            const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(gp ? a.y2 : a.y, 0, gp ? a.y2bytes : a.ybytes, 0x00020000);
+            const unsigned ldyb = (unsigned)(gp ? a.ldy2 : a.ldy) * (unsigned)sizeof(TO);
+            const unsigned nyb = (unsigned)(n < a.nout ? n - (gp ? a.n1 : 0) : 0) * (unsigned)sizeof(TO);
+            if (n < a.nout) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned yo = (unsigned)((img * a.hi + (y0 + 2 * TM * wm + 2 * i)) * a.wi + x0 + 4 * h) * ldyb + nyb;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));         // scalar
+                        float v = acc[i][j][r] + bj[j];
+                        const TO vo = (TO)shm_lrelu(v, a.slope);
+                        v = (float)vo;
+                        s1[j] += v;
+                        s2[j] = __builtin_fmaf(v, v, s2[j]);
+                        if constexpr (sizeof(TO) == 4)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), rsy, yo, cr * ldyb, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), rsy, yo, cr * ldyb, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wide && !gs_any && !ybuf) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1962,7 +2106,36 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    if (!wide && a.gred[0] == nullptr) {
+    // Element stores: a lane's output address is ONE register per (phase, tile) -- its pixel of accumulator row 0 -- plus a scalar
+    // offset per row (row r of a lane is input pixel (r >> 3, 8 ((r >> 2) & 1) + (r & 3)) of the tile's two patch rows, i.e. twice
+    // that in output pixels), through a scalar descriptor when the output is below 4 GiB: no per-element address arithmetic
+    // (it was ~5 VALU instructions per element, 128 elements per lane, in a kernel whose epilogue nobody overlaps: one block per CU)
+    const bool ybuf = a.ybytes != 0;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+    const unsigned ldyb = (unsigned)a.ldy * (unsigned)sizeof(TO), nyb = (unsigned)(ncol < a.nout ? ncol : 0) * (unsigned)sizeof(TO);
+    auto lane_pix0 = [&](int p, int i) {                  // output pixel of the lane's accumulator row 0 of tile i, phase p
+        return (unsigned)((img * a.ho + (2 * (y0 + 4 * wm + 2 * i) + a.ph[p].oph)) * a.wo + (2 * (x0 + 4 * h) + a.ph[p].opw));
+    };
+    auto row_pix = [&](int r) { return (unsigned)(2 * (r >> 3) * a.wo + 16 * ((r >> 2) & 1) + 2 * (r & 3)); };       // scalar
+    if (!wide && a.gred[0] == nullptr && ybuf) {
+        if (ncol < a.nout) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned yo = lane_pix0(p, i) * ldyb + nyb;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const TO vo = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
+                        if constexpr (sizeof(TO) == 4)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), rsy, yo, row_pix(r) * ldyb, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), rsy, yo, row_pix(r) * ldyb, 0);
+                    }
+                }
+        }
+    }
+    if (!wide && a.gred[0] == nullptr && !ybuf) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -1986,28 +2159,27 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const unsigned pix0 = lane_pix0(p, i);
+                const unsigned ao = pix0 * ldab + nlb, yo = pix0 * ldyb + nyb;
                 float q[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
-                    const unsigned opix = (unsigned)((img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw));
                     if constexpr (sizeof(T) == 4)
-                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + nlb, 0, 0));
+                        q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, row_pix(r) * ldab, 0));
                     else
-                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, opix * ldab + nlb, 0, 0) << 16);
+                        q[r] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsa, ao, row_pix(r) * ldab, 0) << 16);
                 }
+                if (ncol < a.nout) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int py = 4 * wm + 2 * i + (row >> 4), px = row & 15;
-                    const size_t opix = ((size_t)img * a.ho + (2 * (y0 + py) + a.ph[p].oph)) * a.wo + (2 * (x0 + px) + a.ph[p].opw);
-                    if (ncol < a.nout) {
+                    for (int r = 0; r < 16; ++r) {
                         const TO vo = (TO)shm_lrelu(acc[p][i][0][r] + bcol, a.slope);
                         const float v = (float)vo;
                         s1 += v;
                         s2 += v * q[r];
-                        ((TO*)a.y)[opix * a.ldy + ncol] = vo;
+                        if constexpr (sizeof(TO) == 4)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), rsy, yo, row_pix(r) * ldyb, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), rsy, yo, row_pix(r) * ldyb, 0);
                     }
                 }
             }
