@@ -1856,13 +1856,13 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         if constexpr (GS) {
             const int img = q / ppi, prem = q - img * ppi;
             const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+            // one address register (the lane's pixel of tile 0, register 0); tile m / register r is a scalar offset
+            const unsigned ao = (unsigned)((img * a.hi + (y0 + 4 * wm)) * a.wi + (x0 + 4 * lq)) * ldab + (unsigned)gnl * 4u;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
-                    gq[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, opix * ldab + (unsigned)gnl * 4u, 0, 0));
-                }
+                for (int r = 0; r < 4; ++r)
+                    gq[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, (unsigned)(m * a.wi + r) * ldab, 0));
         }
 
         f32x4 acc[4];
@@ -1905,6 +1905,11 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
             simg = img;
         }
         float s1 = 0.f, s2 = 0.f;
+        // the wave's 16 channels lie in one output part (n1 % 16 == 0): descriptor, pitch and channel offset are scalar selects (a per-lane
+        // choice of the descriptor makes hipcc wrap every store in a readfirstlane loop); one address register -- the lane's pixel of
+        // tile 0, register 0 -- and a scalar offset per (tile, register)
+        const unsigned ldyb = (unsigned)(part0 ? a.ldy : a.ldy2) * 4u;
+        const unsigned yo = (unsigned)((img * a.hi + (y0 + 4 * wm)) * a.wi + (x0 + 4 * lq)) * ldyb + (unsigned)(part0 ? ncol : ncol - a.n1) * 4u;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1914,13 +1919,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
                 s1 += v;
                 if constexpr (GS) s2 += v * gq[m][r];
                 else s2 = __builtin_fmaf(v, v, s2);
-                const unsigned opix = (unsigned)((img * a.hi + (y0 + 4 * wm + m)) * a.wi + (x0 + 4 * lq + r));
-                // the wave's 16 channels lie in one output part (n1 % 16 == 0): a scalar branch -- a per-lane choice of the buffer
-                // descriptor makes hipcc wrap every store in a readfirstlane (waterfall) loop
-                if (part0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, (opix * (unsigned)a.ldy + (unsigned)ncol) * 4u, 0, 0);
-                else
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy2, (opix * (unsigned)a.ldy2 + (unsigned)(ncol - a.n1)) * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
             }
         S1 += (double)s1;
         S2 += (double)s2;
