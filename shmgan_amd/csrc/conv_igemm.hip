@@ -1689,12 +1689,20 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // NM: "norm" (see tapgemm_halo_kernel) -- the source is the un-normalised activation of an InstanceNorm block; a wave normalises
 // the halo items it DMA'd itself at the end of the patch in front (they have landed by then), from its own 1 KiB copy of the
 // image's (mean, inv, beta) planes, which travels with the halo DMA.
+// LDS pitch (halo rows per patch row, 18 of them used) and DMA items per 16-channel chunk of tapgemm_wreg_f32_kernel.  The 64-channel
+// form (WN = 4, the hot one) pads its halo image to 24 rows per patch row: the chunk swizzle (lq + (R >> 1)) & 3 then repeats from one
+// patch row to the next (12 = 0 mod 4), so the four M tiles of a tap read at ONE address register plus immediates -- 9 fragment address
+// registers instead of 36, which is what lets the gsum form keep them across patches (recomputing them per patch, as it had to at
+// pitch 18, was 4 % of the kernel) -- for 15 instead of 12 DMA items per chunk (the padding rows are out-of-range reads: zeros, no
+// memory traffic).  The narrow forms keep pitch 18 (their 18- and 34-row halos would not fit at 24).
+constexpr int wreg32_pitch(int wn) { return wn == 4 ? 24 : 18; }
+constexpr int wreg32_nit(int wn) { return ((32 / wn + 2) * wreg32_pitch(wn) + 15) / 16; }
 template <int NCH, int WN = 4, bool TWO = false, bool GS = false, int NM = 0>
 __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
     static_assert(!NM || (!TWO && !GS), "norm: one source, forward form");
     // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
     // patches of 8 / 16 / 32 rows -- the narrow forms serve SpecSeg's 16- and 32-channel layers without idle N waves
-    constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, NIT = ((PH + 2) * HC + 15) / 16;     // halo (PH + 2) x 18 rows in DMA items of 16 rows
+    constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, HP = wreg32_pitch(WN), NIT = wreg32_nit(WN);     // halo (PH + 2) x 18 pixels at pitch HP, in DMA items of 16 rows
     constexpr int ASTG = NIT * 256;                     // floats per 16-channel chunk
     constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
     constexpr int NITEM = NIT * NCH;                    // DMA items per patch
@@ -1754,9 +1762,9 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
             if (it < NITEM) {
                 const int c = it / NIT, ri = it - c * NIT;
                 const int hrow = 16 * ri + drow;
-                const int hr = hrow / HC, hc = hrow - hr * HC;
+                const int hr = hrow / HP, hc = hrow - hr * HP;
                 const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-                const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+                const bool v = hr < PH + 2 && hc < HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
                 // LDS chunk dq of row hrow holds channel chunk (dq - (hrow >> 1)) & 3
                 const unsigned sw = (unsigned)(((dq - (hrow >> 1)) & 3) << 4);
                 const unsigned pix = (unsigned)((img * a.hi + iy) * a.wi + ix);
@@ -1786,12 +1794,13 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
             if (it < NITEM) {
                 const int c = it / NIT, ri = it - c * NIT;
                 const int hrow = 16 * ri + drow;
-                const int hr = hrow / HC, hc = hrow - hr * HC;
+                const int hr = hrow / HP, hc = hrow - hr * HP;
                 const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
                 const bool inside = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+                const bool halo = hr < PH + 2 && hc < HC;          // (not a padding row of the LDS image)
                 if constexpr (NM == 2) {            // SHM_NORM_SCALED: `ring` over the out-of-image entries (see tapgemm_halo_kernel)
-                    if (hrow < (PH + 2) * HC && !inside) *(f32x4*)(dst + it * 256) = *(const f32x4*)(tbl + 3 * a.ntc + c * 16 + (((dq - (hrow >> 1)) & 3) << 2));
-                } else if (hrow < (PH + 2) * HC && inside) {
+                    if (halo && !inside) *(f32x4*)(dst + it * 256) = *(const f32x4*)(tbl + 3 * a.ntc + c * 16 + (((dq - (hrow >> 1)) & 3) << 2));
+                } else if (halo && inside) {
                     const float* tb = tbl + c * 16 + (((dq - (hrow >> 1)) & 3) << 2);
                     f32x4 x = *(const f32x4*)(dst + it * 256);
                     const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
@@ -1804,10 +1813,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     };
 
     // ---- fragment addressing: M tile m = patch row 4 wm + m, pixel = l15; halo row of the centre tap
-    const int hb0 = (4 * wm + 1) * HC + l15 + 1;
+    const int hb0 = (4 * wm + 1) * HP + l15 + 1;
     int tsh[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tsh[t] = P.dh[t] * HC + P.dw[t];
+    for (int t = 0; t < 9; ++t) tsh[t] = P.dh[t] * HP + P.dw[t];
 
     double S1 = 0.0, S2 = 0.0;
     int simg = q0 / ppi;
@@ -1875,15 +1884,16 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         // beside the sixteen aux values, and the spills landed in the DMA issue path (a scratch reload + vmcnt(0) in front of every
         // halo DMA: the DMAs of a patch ran one after the other, 84 instead of 131 TFLOP/s)
         int hbq = hb0;
-        if constexpr (GS) asm volatile("" : "+v"(hbq));
+        if constexpr (GS && HP % 8 != 0) asm volatile("" : "+v"(hbq));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // rows of the four M tiles are 18 halo rows apart; the swizzle term (R >> 1) grows by 9 per tile: per-tile addresses
+            // rows of the four M tiles are HP halo rows apart.  Pitch 18: the swizzle term (R >> 1) grows by 9 per tile, per-tile addresses;
+            // pitch 24: by 12, the same chunk -- one address per tap, the tiles are immediates
             int fa[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int hrow = hbq + m * HC + tsh[t];
-                fa[m] = hrow * 16 + (((lq + (hrow >> 1)) & 3) << 2);
+                const int hrow = hbq + (HP % 8 == 0 ? 0 : m * HP) + tsh[t];
+                fa[m] = hrow * 16 + (((lq + (hrow >> 1)) & 3) << 2) + (HP % 8 == 0 ? m * HP * 16 : 0);
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -2488,13 +2498,13 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
             if (gx < 1) gx = 1;
             if (gx > npw) gx = npw;
             const int nch = a.K / 16;
-            const unsigned lds = 2u * (unsigned)nch * (unsigned)(((ph + 2) * 18 + 15) / 16) * 1024u + (want_nm ? 8u * 1024u : 0u);      // two halo buffers (+ norm: 1 KiB of planes per wave)
+            const unsigned lds = 2u * (unsigned)nch * (unsigned)wreg32_nit(wreg32_wn) * 1024u + (want_nm ? 8u * 1024u : 0u);      // two halo buffers (+ norm: 1 KiB of planes per wave)
             hipError_t attr = hipSuccess;
 #define SHM_WREG32_LAUNCH2(NCH_, WN_, TWO_)                                                                                              \
     do {                                                                                                                                 \
         static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, WN_, TWO_>,                         \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize,                                    \
-                                                          2 * NCH_ * ((((32 / WN_) + 2) * 18 + 15) / 16) * 1024);                        \
+                                                          2 * NCH_ * wreg32_nit(WN_) * 1024);                        \
         attr = at_;                                                                                                                      \
         if (attr == hipSuccess)                                                                                                          \
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, WN_, TWO_>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);                \
@@ -2503,7 +2513,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
 #define SHM_WREG32_LAUNCH_GS(NCH_)                                                                                                       \
     do {                                                                                                                                 \
         static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, true>,                    \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * 12 * 1024);             \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * wreg32_nit(4) * 1024);             \
         attr = at_;                                                                                                                      \
         if (attr == hipSuccess)                                                                                                          \
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, true>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);           \
@@ -2511,7 +2521,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
 #define SHM_WREG32_LAUNCH_NM(NCH_, MODE_)                                                                                                \
     do {                                                                                                                                 \
         static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_wreg_f32_kernel<NCH_, 4, false, false, MODE_>,            \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * 12 * 1024 + 8 * 1024);  \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NCH_ * wreg32_nit(4) * 1024 + 8 * 1024);  \
         attr = at_;                                                                                                                      \
         if (attr == hipSuccess)                                                                                                          \
             hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<NCH_, 4, false, false, MODE_>), dim3(gx, nyw, 1), dim3(512), lds, st, a, npw);   \
