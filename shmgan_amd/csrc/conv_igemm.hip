@@ -1705,8 +1705,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, HP = wreg32_pitch(WN), NIT = wreg32_nit(WN);     // halo (PH + 2) x 18 pixels at pitch HP, in DMA items of 16 rows
     constexpr int ASTG = NIT * 256;                     // floats per 16-channel chunk
     constexpr int ABUF = NCH * ASTG;                    // floats per halo buffer
-    constexpr int NITEM = NIT * NCH;                    // DMA items per patch
-    constexpr int NA = (NITEM + 7) / 8;                 // per wave (the last ones may be idle)
     extern __shared__ __attribute__((aligned(1024))) float smem[];      // two halo buffers
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -1739,7 +1737,14 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     };
     load_w(NM == 2 ? q0 / ppi : 0);
 
-    // ---- halo DMA: item it = chunk it / NIT, halo rows [16 (it % NIT), +16); wave w owns items w, w + 8, ...
+    // ---- halo DMA: item (c, ri) = 16-channel chunk c, halo rows [16 ri, 16 ri + 16) of the LDS image; wave w owns row items w, w + 8, ...
+    // of EVERY chunk, so a lane's pixel inside the halo depends on the row item only: per lane and row item one pixel offset and five
+    // edge bits (top / bottom / left / right edge of the halo, "nothing to fetch"), per patch four scalar edge bits and the origin --
+    // an add, a masked test, a multiply-add and one select per DMA instruction.  (Until round 3 every patch recomputed coordinates,
+    // range tests and exec-masked selects per item, ~25 VALU instructions each, from the lane id -- the registers to keep them were
+    // not there before the fragment addresses went from 36 to 9, see wreg32_pitch.)
+    constexpr int NR = (NIT + 7) / 8;                    // row items per wave (the last one may be idle)
+    static_assert(NR <= 6, "five edge bits per row item in one register");
     const int drow = lane >> 2, dq = lane & 3;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
@@ -1747,6 +1752,21 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     const int nc1 = a.c1 >> 4;                           // TWO: chunks [0, nc1) come from x, the rest from x2 (Concatenate)
     float* const tbl = smem + 2 * ABUF + wave * 256;     // NM: this wave's copy of the planes of the image of the halo in flight
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, NM ? a.ntbytes : 0u, 0x00020000);
+    // LDS chunk dq of row R holds channel chunk (dq - (R >> 1)) & 3; items start at multiples of 16 rows, so the term depends on the lane only
+    const unsigned swb = (unsigned)(((dq - (drow >> 1)) & 3) << 4);
+    unsigned po[NR], bm = 0;
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr) {
+        const int ri = wave + 8 * jr;
+        const int hrow = 16 * ri + drow;
+        const int hr = hrow / HP, hc = hrow - hr * HP;
+        po[jr] = (unsigned)(hr * a.wi + hc);
+        const unsigned bits = (ri >= NIT || hr >= PH + 2 || hc >= HC) ? 16u : (hr == 0 ? 1u : 0u) | (hr == PH + 1 ? 2u : 0u) | (hc == 0 ? 4u : 0u) | (hc == HC - 1 ? 8u : 0u);
+        bm |= bits << (5 * jr);
+    }
+    auto patch_edges = [&](int y0, int x0) {             // which edges of the image the halo of the patch at (y0, x0) sticks out of (+ bit 4)
+        return 16u | (y0 == 0 ? 1u : 0u) | (y0 + PH == a.hi ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.wi ? 8u : 0u);
+    };
     auto dma = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
@@ -1756,24 +1776,25 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         if constexpr (NM)
             if (NM == 1 || y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
+        const unsigned edges = patch_edges(y0, x0);
+        const unsigned basepix = (unsigned)((img * a.hi + y0 - 1) * a.wi + x0 - 1);          // pixel index of halo (0, 0); may wrap below zero
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int it = wave + 8 * j;                 // wave-uniform
-            if (it < NITEM) {
-                const int c = it / NIT, ri = it - c * NIT;
-                const int hrow = 16 * ri + drow;
-                const int hr = hrow / HP, hc = hrow - hr * HP;
-                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-                const bool v = hr < PH + 2 && hc < HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-                // LDS chunk dq of row hrow holds channel chunk (dq - (hrow >> 1)) & 3
-                const unsigned sw = (unsigned)(((dq - (hrow >> 1)) & 3) << 4);
-                const unsigned pix = (unsigned)((img * a.hi + iy) * a.wi + ix);
-                if (!TWO || c < nc1) {
-                    const unsigned off = v ? pix * pixb + (unsigned)(c * 64) + sw : 0xffffffffu;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
-                } else {
-                    const unsigned off = v ? pix * pixb2 + (unsigned)((c - nc1) * 64) + sw : 0xffffffffu;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + it * 256), 16, (int)off, 0, 0, 0);
+        for (int jr = 0; jr < NR; ++jr) {
+            const int ri = wave + 8 * jr;                // wave-uniform
+            if (jr < NR - 1 || ri < NIT) {
+                const bool out = (bm & (edges << (5 * jr))) != 0;
+                const unsigned pp = po[jr] + basepix;
+                const unsigned o1 = pp * pixb + swb;
+                [[maybe_unused]] const unsigned o2 = TWO ? pp * pixb2 + swb : 0u;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (!TWO || c < nc1) {
+                        const unsigned off = out ? 0xffffffffu : o1 + (unsigned)(c * 64);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + (c * NIT + ri) * 256), 16, (int)off, 0, 0, 0);
+                    } else {
+                        const unsigned off = out ? 0xffffffffu : o2 + (unsigned)((c - nc1) * 64);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr)(dst + (c * NIT + ri) * 256), 16, (int)off, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1784,29 +1805,28 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
         if (NM == 2 && !(y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)) return;       // block-uniform: no out-of-image halo entry
-        int ln = lane;
-        asm volatile("" : "+v"(ln));        // recompute the lane's coordinates per call: hoisted out of the patch loop they would stay live across the MFMAs
-        const int drow = ln >> 2, dq = ln & 3;
-        float* dst = smem + buf * ABUF + ln * 4;
+        const unsigned edges = patch_edges(y0, x0);
+        float* dst = smem + buf * ABUF + lane * 4;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int it = wave + 8 * j;
-            if (it < NITEM) {
-                const int c = it / NIT, ri = it - c * NIT;
-                const int hrow = 16 * ri + drow;
-                const int hr = hrow / HP, hc = hrow - hr * HP;
-                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-                const bool inside = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-                const bool halo = hr < PH + 2 && hc < HC;          // (not a padding row of the LDS image)
-                if constexpr (NM == 2) {            // SHM_NORM_SCALED: `ring` over the out-of-image entries (see tapgemm_halo_kernel)
-                    if (halo && !inside) *(f32x4*)(dst + it * 256) = *(const f32x4*)(tbl + 3 * a.ntc + c * 16 + (((dq - (hrow >> 1)) & 3) << 2));
-                } else if (halo && inside) {
-                    const float* tb = tbl + c * 16 + (((dq - (hrow >> 1)) & 3) << 2);
-                    f32x4 x = *(const f32x4*)(dst + it * 256);
-                    const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
+        for (int jr = 0; jr < NR; ++jr) {
+            const int ri = wave + 8 * jr;
+            if (jr < NR - 1 || ri < NIT) {
+                const unsigned m = (bm >> (5 * jr)) & 31u;
+                const bool halo = (m & 16u) == 0;                  // (not a padding row of the LDS image)
+                const bool inside = (m & edges & 15u) == 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], mean[e], inv[e], beta[e]);
-                    *(f32x4*)(dst + it * 256) = x;
+                for (int c = 0; c < NCH; ++c) {
+                    float* p = dst + (c * NIT + ri) * 256;
+                    if constexpr (NM == 2) {        // SHM_NORM_SCALED: `ring` over the out-of-image entries (see tapgemm_halo_kernel)
+                        if (halo && !inside) *(f32x4*)p = *(const f32x4*)(tbl + 3 * a.ntc + c * 16 + (swb >> 2));
+                    } else if (halo && inside) {
+                        const float* tb = tbl + c * 16 + (swb >> 2);
+                        f32x4 x = *(const f32x4*)p;
+                        const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], mean[e], inv[e], beta[e]);
+                        *(f32x4*)p = x;
+                    }
                 }
             }
         }
