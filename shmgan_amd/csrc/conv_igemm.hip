@@ -1339,6 +1339,17 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
     const unsigned pixb = (unsigned)a.ldx * 2u;
     float* const tbl = smem + 2 * ABUF + 4 * 1024 + wave * 256;     // NM: this wave's copy of the planes of the image of the halo in flight
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, NM ? a.ntbytes : 0u, 0x00020000);
+    // (the instantiations that are out of registers -- gsum, SHM_NORM_SCALED with two chunks: neither runs in the default bf16 step --
+    // keep recomputing the halo coordinates per patch from the lane id: four more live registers would be four more spills)
+    constexpr bool kDmaConst = !(NCH == 2 && (GS || NM == 2));
+    [[maybe_unused]] unsigned doff[3], dbm = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int hrow = 16 * (wave + 4 * j) + drow;
+        const int hr = hrow / HC, hc = hrow - hr * HC;
+        doff[j] = (unsigned)(hr * a.wi + hc) * pixb + (unsigned)((dq ^ (((hrow >> 1) + hr) & 3)) << 4);
+        dbm |= (hrow >= (PH + 2) * HC ? 16u : (hr == 0 ? 1u : 0u) | (hr == PH + 1 ? 2u : 0u) | (hc == 0 ? 4u : 0u) | (hc == HC - 1 ? 8u : 0u)) << (5 * j);
+    }
     auto dma = [&](int q, int buf) {
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
@@ -1348,19 +1359,35 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
         if constexpr (NM)
             if (NM == 1 || y0 == 0 || y0 + PH == a.hi || x0 == 0 || x0 + 16 == a.wi)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsn, (lds_ptr)tbl, 16, (int)((unsigned)img * 16u * (unsigned)a.ntc + (unsigned)lane * 16u), 0, 0, 0);
-        int dr = drow;
-        asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
+        if constexpr (!kDmaConst) {
+            int dr = drow;
+            asm volatile("" : "+v"(dr));        // recompute the halo coordinates per patch: hoisted, they are spilled
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int hrow = 16 * (wave + 4 * j) + dr;
+                const int hr = hrow / HC, hc = hrow - hr * HC;
+                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+                const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+                const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)((dq ^ (((hrow >> 1) + hr) & 3)) << 4) : 0xffffffffu;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + c * ASTG + j * 4 * 256), 16,
+                                                             (int)(v ? off + 64u * c : 0xffffffffu), 0, 0, 0);
+            }
+            return;
+        }
+        // per-lane constants (byte offset of the lane's pixel inside the halo incl. the source-side swizzle, five edge bits per item)
+        // + the patch's origin and edge bits: see tapgemm_wreg_f32_kernel
+        const unsigned edges = 16u | (y0 == 0 ? 1u : 0u) | (y0 + PH == a.hi ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.wi ? 8u : 0u);
+        const unsigned baseb = (unsigned)((img * a.hi + y0 - 1) * a.wi + x0 - 1) * pixb;           // halo (0, 0); may wrap below zero
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int hrow = 16 * (wave + 4 * j) + dr;
-            const int hr = hrow / HC, hc = hrow - hr * HC;
-            const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-            const bool v = hrow < (PH + 2) * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-            const unsigned off = v ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (unsigned)((dq ^ (((hrow >> 1) + hr) & 3)) << 4) : 0xffffffffu;
+            const bool out = (dbm & (edges << (5 * j))) != 0;
+            const unsigned off = doff[j] + baseb;
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(dst + c * ASTG + j * 4 * 256), 16,
-                                                         (int)(v ? off + 64u * c : 0xffffffffu), 0, 0, 0);
+                                                         (int)(out ? 0xffffffffu : off + 64u * c), 0, 0, 0);
         }
     };
 

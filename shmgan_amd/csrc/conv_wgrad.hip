@@ -487,15 +487,16 @@ __device__ __forceinline__ f32x4 load16_drained(const float* p) {
 // NM: a wave normalises the halo items it DMA'd itself, one stage ahead of their use.  A lane's four channels are the same for
 // every item and patch (no swizzle in this image), so their (mean, inv, beta) live in registers and are re-read when the image
 // changes (at most a few times per block).
-// IS = 2 (round 3): the stride-2 3x3 layers (SAME padding of an even map: no pad before, one row / column after).  A stage is a patch of
+// S2 (round 3; IS = conv stride 2): the stride-2 3x3 layers (SAME padding of an even map: no pad before, one row / column after).  A stage is a patch of
 // 2 x 8 OUTPUT pixels and its 5 x 17 input halo -- 22 + 4 DMA items, the same 26 KiB stage, per-wave DMA counts and waits as the
 // unit-stride form, with half the MFMAs per barrier; tap (kh, kw) of output pixel (qr, qc) is halo pixel (2 qr + kh, 2 qc + kw), still an
 // immediate offset on the ds_read_b32 (a lane reads one float of a 128-byte run whatever the pixel stride: no bank conflicts).
 // Against wgrad_kernel<9> (nine shifted tiles through registers, a barrier per 8 pixels): 5.3 input pixels fetched per output pixel
 // instead of 9, no VGPR staging, no ds_write, a barrier per 16 pixels.
-template <int NM = 0, int IS = 1>
+template <int NM = 0, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs a) {
-    static_assert(IS == 1 || (IS == 2 && NM == 0), "norm: unit-stride form");
+    static_assert(!S2 || NM == 0, "norm: unit-stride form");
+    constexpr int IS = S2 ? 2 : 1;
     constexpr int PW = IS == 1 ? 16 : 8, HC = IS * PW + 3 - IS, HR = 2 * IS + 3 - IS;    // patch 2 x 16, halo 4 x 18 | 2 x 8, 5 x 17
     constexpr int PAD = IS == 1 ? 1 : 0;
     constexpr int NHP = HR * HC, NPX = 2 * PW;          // 72 halo pixels, 32 output pixels | 85, 16
@@ -1502,8 +1503,8 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
         ns = nsh;
-        hipLaunchKernelGGL((wgrad_halo_kernel<0, 2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
-        shm_set_last_kernel("wgrad_halo_kernel<0, 2>");
+        hipLaunchKernelGGL((wgrad_halo_kernel<0, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+        shm_set_last_kernel("wgrad_halo_kernel<0, true>");
     } else if (halo_ok) {
         const bool thin = thin_ok;
         WgradHaloArgs hgs{};

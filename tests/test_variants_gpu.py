@@ -405,7 +405,7 @@ def test_wgrad_stride2_halo(n, h, cin, cout, c1, blocks):
         dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
         ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
         k = ops.last_kernel()
-        assert k == ("wgrad_halo_kernel<0, 2>" if wv == 0 else "wgrad_kernel<9, false>"), k
+        assert k == ("wgrad_halo_kernel<0, true>" if wv == 0 else "wgrad_kernel<9, false>"), k
         got[wv] = host(dw)
         assert rel_l2(got[wv], ref.numpy()) < 1e-5, (k, rel_l2(got[wv], ref.numpy()))
         # accumulate into the result

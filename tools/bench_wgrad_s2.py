@@ -1,4 +1,4 @@
-"""A/B of the stride-2 3x3 weight gradient: halo form (wgrad_halo_kernel<0, 2>) against the generic kernel (wgrad.variant 3), fp32, on the
+"""A/B of the stride-2 3x3 weight gradient: halo form (wgrad_halo_kernel<0, true>) against the generic kernel (wgrad.variant 3), fp32, on the
 step's layer shapes (generator encoder / Conv2DTranspose at n = 40, discriminator at n = 96).  usage: bench_wgrad_s2.py [n,h,cin,cout ...]"""
 import statistics
 import sys
