@@ -941,6 +941,17 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
         }
         typedef const __attribute__((address_space(3))) f32x4* lds_f4;
         const unsigned sA_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)sA;
+        int tw[9];                                     // weight slice of tap t (scalars)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tw[t] = __builtin_amdgcn_readlane(tapw_v, t);
+        auto dma_b_at = [&](int t_wi, int chunk2, int stage2) {
+            const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + chunk2 * BKE) * (unsigned)ESZ + (NM == 2 ? (unsigned)img * a.wimg : 0u);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned off = wrow[j] == 0xffffffffu ? wrow[j] : wrow[j] + wbase;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sB + stage2 * BSTG + (wave + NW * j) * 256), 16, (int)off, 0, 0, 0);
+            }
+        };
         for (int chunk = 0; chunk < nch; ++chunk) {
             // LDS byte address of the A stage: the k-group-1 address is formed as (stage + offset) ^ 32 inside the chunk loop,
             // so that the compiler keeps 18 address registers, not 36 (the stage base is a multiple of 64 bytes)
@@ -959,7 +970,9 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                 asm volatile("" ::: "memory");
                 if constexpr (!abl::nodma) {
                     if (tap == 0 && chunk + 1 < nch) dma_a(chunk + 1);
-                    if (tap < 7 || chunk + 1 < nch) dma_b();
+                    // the weight slice of step s + 2: tap, chunk carry and stage are compile-time here (9 % 3 == 0) -- the running
+                    // (tap, chunk, stage) state of dma_b() cost ~25 scalar / vector instructions per tap, against eight bf16 MFMAs
+                    if (tap < 7 || chunk + 1 < nch) dma_b_at(tw[(tap + 2) % 9], chunk + (tap + 2) / 9, (tap + 2) % 3);
                 }
                 const float* Bb = sB + (tap % 3) * BSTG + wn * 64 * 16;
 #pragma unroll
