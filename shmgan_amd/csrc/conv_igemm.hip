@@ -276,12 +276,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && sizeof(TO) == 4)
         ld_c0 = (ld_g + ld_sub) * BKE;
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    // the two pixel pitches as opaque scalars: hipcc otherwise re-reads the selected one from the kernel arguments in every K step -- a
+    // scalar memory load whose s_waitcnt lgkmcnt(0) also drains the wave's ds_reads (found in the ISA of the 256 x 128 tile)
+    int ldx_s = a.ldx, ldx2_s = a.ldx2;
+    asm volatile("" : "+s"(ldx_s), "+s"(ldx2_s));
     auto dma = [&](int stage) {
         float* sa = smem + stage * STAGE + wave * (BM / NW) * BK;
         float* sb = smem + stage * STAGE + BM * BK + wave * (BN / NW) * BK;
         const int c0 = ld_c0;
         const bool second = c0 >= a.c1;
-        const int ld = second ? a.ldx2 : a.ldx;
+        const int ld = second ? ldx2_s : ldx_s;
         const int cc = second ? c0 - a.c1 : c0;
         const int t_off = __builtin_amdgcn_readlane(tapoff_v, ld_tap);
         const int t_wi = __builtin_amdgcn_readlane(tapw_v, ld_tap);
@@ -846,6 +850,10 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
     };
 
     // NM: normalise this wave's own items of the A stage of `chunk` in place (they have landed: the caller waited)
+    // (the plane pitch as an opaque scalar: re-read from the kernel arguments inside the tap loop it is a scalar memory load whose
+    // s_waitcnt lgkmcnt(0) drains the ds_reads)
+    [[maybe_unused]] int ntc_s = NM ? a.ntc : 0;
+    if constexpr (NM != 0) asm volatile("" : "+s"(ntc_s));
     [[maybe_unused]] auto norm_a = [&](int chunk) {
         const int c0 = chunk * BKE;
         const bool second = c0 >= a.c1;
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
             for (int j = 0; j < NA; ++j) {
                 const int m = nmv[j];
                 if (m < 0 && m != (int)0x80000000) {
-                    const float* tb = tb0 + (-1 - m) + 3 * a.ntc;
+                    const float* tb = tb0 + (-1 - m) + 3 * ntc_s;
                     float* p = dst + j * NW * 256;
                     if constexpr (ESZ == 4) {
                         *(f32x4*)p = *(const f32x4*)tb;
@@ -887,7 +895,7 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                 float* p = dst + j * NW * 256;
                 if constexpr (ESZ == 4) {
                     f32x4 x = *(const f32x4*)p;
-                    const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + a.ntc), beta = *(const f32x4*)(tb + 2 * a.ntc);
+                    const f32x4 mean = *(const f32x4*)tb, inv = *(const f32x4*)(tb + ntc_s), beta = *(const f32x4*)(tb + 2 * ntc_s);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = shm_in_norm(x[e], mean[e], inv[e], beta[e]);
                     *(f32x4*)p = x;
@@ -895,8 +903,8 @@ __global__ __launch_bounds__(BN * PH / (2 * TM), ST ? BN * PH / (256 * TM) : 1) 
                     u32x4 x = *(const u32x4*)p;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        const f32x4 mean = *(const f32x4*)(tb + 4 * hf), inv = *(const f32x4*)(tb + a.ntc + 4 * hf),
-                                    beta = *(const f32x4*)(tb + 2 * a.ntc + 4 * hf);
+                        const f32x4 mean = *(const f32x4*)(tb + 4 * hf), inv = *(const f32x4*)(tb + ntc_s + 4 * hf),
+                                    beta = *(const f32x4*)(tb + 2 * ntc_s + 4 * hf);
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const unsigned u = x[2 * hf + e];
