@@ -165,6 +165,9 @@ static inline void shm_same_pad(int in, int k, int s, int* out, int* before) {
 }
 
 __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions (v_mul, v_med3 with FLT_MAX -- with +inf LLVM folds the median back into fmaxf): fmaxf costs a third -- hipcc quiets a
+// possible signalling NaN in u first (v_max u, u, u), which for an MFMA result it cannot rule out.  Bit-identical to shm_lrelu.
+__device__ __forceinline__ float shm_lrelu_max(float u, float slope) { return __builtin_amdgcn_fmed3f(u, u * slope, 3.4028234663852886e38f); }
 
 // InstanceNormalization apply, (x - mean) * inv + beta, in ONE spelling for the stand-alone pass (shm_in_apply) and for the
 // consumers that normalise their operand tile in LDS ("fused block", shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm): a

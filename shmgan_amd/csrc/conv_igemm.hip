@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float u = acc[i][r];
-                    const bf16_t vo = (bf16_t)fmaxf(u, u * a.slope);      // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
+                    const bf16_t vo = (bf16_t)shm_lrelu_max(u, a.slope);      // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                     const float v = (float)vo;
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
                     const int py = 4 * wm + (row >> 4), px = row & 15;
                     const unsigned opix = (unsigned)((img * a.hi + (y0 + py)) * a.wi + (x0 + px));
                     const float u = acc[i][r];
-                    const float v = fmaxf(u, u * a.slope);
+                    const float v = shm_lrelu_max(u, a.slope);
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
                     if (__builtin_amdgcn_readfirstlane(n0 + wn * 32) < a.n1) {        // wave-uniform (n1 % 32 == 0): no waterfall loop
@@ -1993,7 +1993,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float u = acc[m][r];
-                const float v = fmaxf(u, u * a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
+                const float v = shm_lrelu_max(u, a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
                 s1 += v;
                 if constexpr (GS) s2 += v * gq[m][r];
                 else s2 = __builtin_fmaf(v, v, s2);
