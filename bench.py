@@ -217,7 +217,7 @@ def main():
                     if b == key:
                         return True
                     base = key[:-1] + "," if key.endswith(">") else key + "<"
-                    return b.startswith(base) and all(t in ("false", "0") for t in b[len(base):].rstrip(">").split(","))
+                    return b.startswith(base) and all(t in ("false", "0", "float") for t in b[len(base):].rstrip(">").split(","))
                 for name, rec in tj.items():
                     if same_symbol(name):
                         traffic = rec["hbm_bytes_per_launch"]

@@ -1745,9 +1745,17 @@ __global__ __launch_bounds__(256, 2) void tapgemm_wreg_kernel(const TapGemmArgs 
 // memory traffic).  The narrow forms keep pitch 18 (their 18- and 34-row halos would not fit at 24).
 constexpr int wreg32_pitch(int wn) { return wn == 4 ? 24 : 18; }
 constexpr int wreg32_nit(int wn) { return ((32 / wn + 2) * wreg32_pitch(wn) + 15) / 16; }
-template <int NCH, int WN = 4, bool TWO = false, bool GS = false, int NM = 0>
-__global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
+// T = bf16_t (round 3, "tapgemm.wreg16"): the same kernel on bf16 operands and outputs -- the LDS image, the DMA and every address are
+// the fp32 kernel's (64-byte rows = 32 channels, a lane's 16-byte fragment = 8 channels = ONE v_mfma_f32_16x16x32_bf16 where fp32
+// issues four 16x16x4), the weights of a 16-column wave tile are 9 x NCH x 4 registers -- 72 at 64 input channels, against 144 in the
+// four-wave tapgemm_wreg_kernel -- so the kernel fits 128 VGPRs and a SIMD holds four waves of two blocks instead of two
+// (profiles/r03_bf16_wreg_ablation.txt: at two waves per SIMD the MFMA phase and the epilogue / store / DMA-wait phase of that kernel add up
+// instead of overlapping).  Plain forward form only (no gsum, no norm, one source).
+template <int NCH, int WN = 4, bool TWO = false, bool GS = false, int NM = 0, typename T = float>
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void tapgemm_wreg_f32_kernel(const TapGemmArgs a, const int npatch) {
     static_assert(!NM || (!TWO && !GS), "norm: one source, forward form");
+    static_assert(sizeof(T) == 4 || (WN == 4 && !TWO && !GS && !NM), "bf16: plain 64-channel form");
+    constexpr int ESZ = sizeof(T), CHE = 16 / ESZ, BKE = 64 / ESZ;       // channels per 16-byte fragment / per 64-byte row
     // WN waves along N (16 columns each), WM = 8 / WN along M (four patch rows each): 64 / 32 / 16 output channels per block on
     // patches of 8 / 16 / 32 rows -- the narrow forms serve SpecSeg's 16- and 32-channel layers without idle N waves
     constexpr int WM = 8 / WN, PH = 4 * WM, HC = 18, HP = wreg32_pitch(WN), NIT = wreg32_nit(WN);     // halo (PH + 2) x 18 pixels at pitch HP, in DMA items of 16 rows
@@ -1776,11 +1784,11 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     // (NM = 2, SHM_NORM_SCALED: the weight copy and the bias row of image `img`, re-read when the block's patch range moves on to the
     // next image -- outside the patch loop, so that hipcc's waitcnt pass drains these loads in the loop's preheader, not at every use)
     auto load_w = [&](int img) {
-        const float* wp = (const float*)a.w + (NM == 2 ? (size_t)img * (a.wimg >> 2) : (size_t)0);
+        const T* wp = (const T*)a.w + (NM == 2 ? (size_t)img * (a.wimg / ESZ) : (size_t)0);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) bw[t][c] = *(const f32x4*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * 16 + lq * 4);
+            for (int c = 0; c < NCH; ++c) bw[t][c] = *(const f32x4*)(wp + ((size_t)P.widx[t] * a.nout + ncol) * a.K + c * BKE + lq * CHE);
         bias = a.bias ? a.bias[(NM == 2 ? (size_t)img * a.bias_img : (size_t)0) + ncol] : 0.f;
     };
     load_w(NM == 2 ? q0 / ppi : 0);
@@ -1796,8 +1804,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
     const int drow = lane >> 2, dq = lane & 3;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
-    const unsigned pixb = (unsigned)a.ldx * 4u, pixb2 = (unsigned)a.ldx2 * 4u;
-    const int nc1 = a.c1 >> 4;                           // TWO: chunks [0, nc1) come from x, the rest from x2 (Concatenate)
+    const unsigned pixb = (unsigned)a.ldx * (unsigned)ESZ, pixb2 = (unsigned)a.ldx2 * (unsigned)ESZ;
+    const int nc1 = a.c1 / BKE;                           // TWO: chunks [0, nc1) come from x, the rest from x2 (Concatenate)
     float* const tbl = smem + 2 * ABUF + wave * 256;     // NM: this wave's copy of the planes of the image of the halo in flight
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nt, 0, NM ? a.ntbytes : 0u, 0x00020000);
     // LDS chunk dq of row R holds channel chunk (dq - (R >> 1)) & 3; items start at multiples of 16 rows, so the term depends on the lane only
@@ -1965,13 +1973,24 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                f32x4 av[4];
+                if constexpr (ESZ == 4) {
+                    f32x4 av[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) av[m] = *(const f32x4*)(Ab + c * ASTG + fa[m]);
+                    for (int m = 0; m < 4; ++m) av[m] = *(const f32x4*)(Ab + c * ASTG + fa[m]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][e], bw[t][c][e], acc[m], 0, 0, 0);
+                        for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][e], bw[t][c][e], acc[m], 0, 0, 0);
+                } else {
+                    // two fragments at a time (128 VGPRs: 72 of weights, 16 accumulators)
+#pragma unroll
+                    for (int mh = 0; mh < 4; mh += 2) {
+                        const f32x4 a0 = *(const f32x4*)(Ab + c * ASTG + fa[mh]), a1 = *(const f32x4*)(Ab + c * ASTG + fa[mh + 1]);
+                        acc[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw[t][c]), acc[mh], 0, 0, 0);
+                        acc[mh + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw[t][c]), acc[mh + 1], 0, 0, 0);
+                        asm volatile("" ::: "memory");
+                    }
+                }
             }
         }
 
@@ -1986,18 +2005,22 @@ __global__ __launch_bounds__(512, 2) void tapgemm_wreg_f32_kernel(const TapGemmA
         // the wave's 16 channels lie in one output part (n1 % 16 == 0): descriptor, pitch and channel offset are scalar selects (a per-lane
         // choice of the descriptor makes hipcc wrap every store in a readfirstlane loop); one address register -- the lane's pixel of
         // tile 0, register 0 -- and a scalar offset per (tile, register)
-        const unsigned ldyb = (unsigned)(part0 ? a.ldy : a.ldy2) * 4u;
-        const unsigned yo = (unsigned)((img * a.hi + (y0 + 4 * wm)) * a.wi + (x0 + 4 * lq)) * ldyb + (unsigned)(part0 ? ncol : ncol - a.n1) * 4u;
+        const unsigned ldyb = (unsigned)(part0 ? a.ldy : a.ldy2) * (unsigned)ESZ;
+        const unsigned yo = (unsigned)((img * a.hi + (y0 + 4 * wm)) * a.wi + (x0 + 4 * lq)) * ldyb + (unsigned)(part0 ? ncol : ncol - a.n1) * (unsigned)ESZ;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float u = acc[m][r];
-                const float v = shm_lrelu_max(u, a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
+                const T vo = (T)shm_lrelu_max(u, a.slope);           // LeakyReLU for 0 <= slope <= 1 (checked by the launcher)
+                const float v = (float)vo;                           // statistics of the value as stored
                 s1 += v;
                 if constexpr (GS) s2 += v * gq[m][r];
                 else s2 = __builtin_fmaf(v, v, s2);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
+                if constexpr (ESZ == 4)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
             }
         S1 += (double)s1;
         S2 += (double)s2;
@@ -2551,11 +2574,27 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
                 else if (want_nm)
                     hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1, false, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             }
-            if (gs_fused || want_nm) {
+            // "tapgemm.wreg16": the eight-wave form with 16-column wave tiles (tapgemm_wreg_f32_kernel<..., bf16_t>): plain bf16 -> bf16 launches
+            bool w16 = false;
+            if constexpr (sizeof(TO) == 2) w16 = shm_tune(SHM_TUNE_TAPGEMM_WREG16) != 0 && !gs_fused && !want_nm && a.nout % 64 == 0 && a.n1 % 16 == 0;
+            if constexpr (sizeof(TO) == 2) if (w16) {
+                const int nyw = a.nout / 64;
+                int gxw = 2 * ncu / nyw;            // two eight-wave blocks per CU (60 KiB of LDS, 128 VGPRs each)
+                if (gxw < 1) gxw = 1;
+                if (gxw > np8) gxw = np8;
+                const unsigned lds = 2u * (unsigned)(a.K / 32) * (unsigned)wreg32_nit(4) * 1024u;
+                if (a.K == 64)
+                    hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<2, 4, false, false, 0, bf16_t>), dim3(gxw, nyw, 1), dim3(512), lds, st, a, np8);
+                else
+                    hipLaunchKernelGGL((tapgemm_wreg_f32_kernel<1, 4, false, false, 0, bf16_t>), dim3(gxw, nyw, 1), dim3(512), lds, st, a, np8);
+                shm_set_last_kernel("tapgemm_wreg_f32_kernel<%d, 4, false, false, 0, __bf16>", a.K / 32);
+            }
+            if (gs_fused || want_nm || w16) {
             } else if (a.K == 64)
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 2>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
             else
                 hipLaunchKernelGGL((tapgemm_wreg_kernel<TO, 1>), dim3(gx, ny, 1), dim3(256), 0, st, a, np8);
+            if (!w16)
             shm_set_last_kernel(gs_fused ? "tapgemm_wreg_kernel<%s, %d, true>"
                                 : want_nm ? (a.ntmode ? "tapgemm_wreg_kernel<%s, %d, false, 2>" : "tapgemm_wreg_kernel<%s, %d, false, 1>") : "tapgemm_wreg_kernel<%s, %d>",
                                 ton, a.K / 32);

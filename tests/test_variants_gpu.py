@@ -28,7 +28,8 @@ SYMBOL = {
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
-    "wreg": "tapgemm_wreg_kernel<{t}, {nch}>",
+    "wreg": "tapgemm_wreg_f32_kernel<{nch}, 4, false, false, 0, {t}>",      # bf16: the eight-wave form ("tapgemm.wreg16", default on)
+    "wreg4": "tapgemm_wreg_kernel<{t}, {nch}>",                             # ... and the four-wave form with 32-column wave tiles
     "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 2>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true, 2>",
     "phase4": "tapgemm_phase4_kernel<{t}, {t}>", "halo128_st_w4": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 4>",
 }
@@ -136,6 +137,19 @@ def test_wreg_forced_variant(dt, n, h, cin, cout):
     if dt == "f32" and cin == 32:
         cin = 16
     _fwd_case("wreg", dt, n, h, cin, 0, cout, 3, 1, seed=3)
+
+
+# ---- "tapgemm.wreg16" = 0: the four-wave bf16 form with 32-column wave tiles (the default is the eight-wave form, test_wreg_forced_variant)
+@pytest.mark.parametrize("n,h,cin,cout", [(3, 16, 64, 64), (2, 32, 64, 192), (5, 16, 32, 128), (1, 64, 64, 64), (7, 48, 64, 64)])
+def test_wreg_four_wave_bf16(n, h, cin, cout):
+    ops = _ops()
+    sym = SYMBOL["wreg"]
+    SYMBOL["wreg"] = SYMBOL["wreg4"]
+    try:
+        ops.set_tuning("tapgemm.wreg16", 0)
+        _fwd_case("wreg", "bf16", n, h, cin, 0, cout, 3, 1, seed=5)
+    finally:
+        SYMBOL["wreg"] = sym
 
 
 @pytest.mark.parametrize("n,h,c1,c2,cout,sym", [
