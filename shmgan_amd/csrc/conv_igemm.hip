@@ -2017,7 +2017,9 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void tapgemm_wreg_f32_
                 s1 += v;
                 if constexpr (GS) s2 += v * gq[m][r];
                 else s2 = __builtin_fmaf(v, v, s2);
-                if constexpr (ESZ == 4)
+                if constexpr (abl::nostore)
+                    asm volatile("" ::"v"(v));                           // timing only
+                else if constexpr (ESZ == 4)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
                 else
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vo), part0 ? rsy : rsy2, yo, (unsigned)(m * a.wi + r) * ldyb, 0);
@@ -2026,7 +2028,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void tapgemm_wreg_f32_
         S2 += (double)s2;
         // halo(q + 1) was issued at the top of this patch; younger: this epilogue's sixteen stores (plus the rare flush; the gsum
         // form's aux loads were issued right behind the halo and have been consumed: loads return in order)
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (abl::nostore)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // timing only: no stores behind the halo DMA
+        else
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         if constexpr (NM)
             if (q + 1 < q1) norm_a(q + 1, buf ^ 1);
     };
