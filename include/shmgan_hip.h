@@ -69,6 +69,7 @@ const char* shm_last_kernel(void);
  *                               take the four-phases-in-one-block kernel (default 256)
  *   "tapgemm.wreg16"            bf16 weights-in-registers layers (one source, 32 / 64 input channels): 1 = eight-wave form with 16-column wave tiles
  *                               (v_mfma_f32_16x16x32_bf16, four waves per SIMD; default), 0 = four-wave form with 32-column tiles
+ *   "tapgemm.flat_epilogue"     1 = treat every output as larger than 4 GiB: element stores through 64-bit addresses, no buffer-store kernels (tests), default 0
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing, 3 no stride-2 halo form
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)
  *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4

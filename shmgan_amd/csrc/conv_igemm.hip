@@ -2761,8 +2761,11 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
         a.wbytes = (unsigned)wb;
         const int oesz = dtype == SHM_BF16 ? 2 : 4;
         const size_t yb = (size_t)batch * a.ho * a.wo * a.ldy * oesz, y2b = a.y2 ? (size_t)batch * a.ho * a.wo * a.ldy2 * oesz : 0;
-        a.ybytes = yb < lim ? (unsigned)yb : 0u;
-        a.y2bytes = y2b < lim ? (unsigned)y2b : 0u;
+        // ("tapgemm.flat_epilogue": the >= 4 GiB behaviour on demand -- keeps the 64-bit-address epilogues and the variant choice without
+        // the buffer-store kernels under test at sizes a test can afford)
+        const bool flat = shm_tune(SHM_TUNE_TAPGEMM_FLAT_EPILOGUE) != 0;
+        a.ybytes = (yb < lim && !flat) ? (unsigned)yb : 0u;
+        a.y2bytes = (y2b < lim && !flat) ? (unsigned)y2b : 0u;
     }
     int rc;
     if (dtype == SHM_BF16)

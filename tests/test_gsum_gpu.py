@@ -108,6 +108,15 @@ def test_dgrad_gsum_forced_variant(variant, dt, n, h, cin, cout, n1, which):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", ["dma128x128", "dma64x128", "dma256x128", "halo128_st"])
+def test_dgrad_gsum_with_outputs_beyond_4gib(variant, dt):
+    """"tapgemm.flat_epilogue": the DMA tiles keep their sums on the 64-bit-address epilogue, the halo kernels (32-bit aux offsets) hand
+    them to the follow-up reduce pass -- same gradient, same sums either way"""
+    _ops().set_tuning("tapgemm.flat_epilogue", 1)
+    _dgrad_case(variant, dt, 2, 32, 256, 64, 128, which=(True, True))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,h,cin,cout,n1,which", [
     (3, 16, 64, 64, 0, (True, True)),            # 64 <- 64: the layers in front of the 256 x 256 blocks
     (2, 32, 128, 64, 64, (False, True)),         # 128 <- 64 with the skip half summed

@@ -124,6 +124,51 @@ def test_conv3x3_s1_forced_variant(variant, dt, n, h, c1, c2, cout):
     _fwd_case(variant, dt, n, h, c1, c2, cout, 3, 1)
 
 
+# ---- outputs "larger than 4 GiB" ("tapgemm.flat_epilogue"): the 64-bit-address element stores of every kernel family, which real tests
+# cannot reach by size (the default epilogues go through 32-bit buffer descriptors)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant,n,h,c1,c2,cout,k,s", [
+    ("halo128_st", 2, 32, 64, 0, 160, 3, 1), ("halo64_st", 2, 16, 64, 128, 128, 3, 1), ("dma128x128", 2, 32, 64, 0, 160, 3, 1),
+    ("dma256x128", 3, 32, 64, 0, 128, 3, 2), ("dma64x128", 5, 16, 128, 0, 48, 3, 2), ("dma128x128_bk32", 2, 32, 64, 0, 128, 3, 2),
+])
+def test_flat_epilogue_forced_variant(variant, dt, n, h, c1, c2, cout, k, s):
+    _ops().set_tuning("tapgemm.flat_epilogue", 1)
+    _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=8)
+
+
+def test_flat_epilogue_refuses_the_buffer_store_kernels_and_keeps_results():
+    """the weights-in-registers kernels store through buffer descriptors: with outputs "beyond 4 GiB" the automatic choice moves on to
+    another kernel and a forced one is refused; Conv2DTranspose (four-phase kernel) keeps its result through the 64-bit path"""
+    ops = _ops()
+    from shmgan_amd._lib import ShmError
+    ops.set_tuning("tapgemm.flat_epilogue", 1)
+    rng = np.random.default_rng(12)
+    n, h, cin, cout = 2, 32, 64, 64
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    ref = conv_ref(x.astype(np.float64), w.astype(np.float64), 1)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    y = torch.empty((n, h, h, cout), device="cuda")
+    ops.conv2d_fwd(_dev(x, "f32"), None, 0, cin, 0, _wk(w, cin, "f32"), None, y, cout, n, h, h, cin, cout, 3, 1, 0.2)
+    assert not ops.last_kernel().startswith("tapgemm_wreg"), ops.last_kernel()
+    assert rel_l2(host(y), ref) < 1e-5
+    ops.set_tuning("tapgemm.variant", "wreg")
+    with pytest.raises(ShmError):
+        ops.conv2d_fwd(_dev(x, "f32"), None, 0, cin, 0, _wk(w, cin, "f32"), None, y, cout, n, h, h, cin, cout, 3, 1, 0.2)
+    ops.set_tuning("tapgemm.variant", "auto")
+    ci, co, hs = 128, 64, 16
+    xt = rng.standard_normal((n, hs, hs, ci)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, co, ci)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    r = nhwc(st.conv2d_transpose_same(nchw(xt.astype(np.float64)), t64(wt))) + b
+    r = np.where(r > 0, r, 0.2 * r)
+    yt = torch.empty((n, 2 * hs, 2 * hs, co), device="cuda")
+    ops.set_tuning("tapgemm.phase4_min_blocks", 0)
+    ops.conv2d_transpose_fwd(torch.from_numpy(xt).cuda(), ci, torch.from_numpy(wt).cuda(), torch.from_numpy(b).cuda(), yt, co, n, hs, hs, ci, co, 0.2)
+    assert ops.last_kernel().startswith("tapgemm_phase4_kernel"), ops.last_kernel()
+    assert rel_l2(host(yt), r) < 1e-5
+
+
 # ---- weights-in-registers kernels (<= 64 input channels from one tensor): persistent blocks over 8 x 16 patches
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("n,h,cin,cout", [
