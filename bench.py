@@ -56,6 +56,11 @@ def main():
                     help="f32 = BASELINE configs[1] (default, the headline line); bf16 = configs[3]/[4] (bf16 MFMA path)")
     args = ap.parse_args()
 
+    # Before torch is imported or any torch.cuda function runs (device_count() may already bring HSA up, and HSA reads this at
+    # initialisation): the host driver only supports dmabuf IPC, without which RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
     # --gpus N is the contract: N ranks, one per GPU.  Launched by the driver through torch.distributed.run the environment
     # carries WORLD_SIZE = N; launched as plain `python bench.py --gpus N` this process only becomes the launcher: it starts
     # the N ranks as children (before anything here touches the GPU: no exec from a GPU process) and relays their output.
@@ -142,12 +147,18 @@ def main():
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     sync()
+    if world > 1:            # N > 1: bracket every collective (reducer stream) and every wait on one (main stream) with timing events
+        model._reducer.probe = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.train_step(*inputs, draws=draws_for(args.warmup + i), next_batch=inputs)
     sync()
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f}s")
+    comm = None
+    if world > 1:
+        comm = model._reducer.comm_summary(args.steps)
+        model._reducer.probe = None
     # per-kernel HIP-event pass: serialized replay (single stream) of the same number of steps
     timer = None
     dt_serial = 0.0
@@ -192,6 +203,12 @@ def main():
                            "backend": dist.get_backend() if world > 1 else None,
                            "device_count": torch.cuda.device_count(), "same_device": bool(args.same_device)},
         }
+        if comm is not None:
+            # why the N-GPU number is what it is: per step on rank 0, the time its collectives took on the reducer stream (D bucket /
+            # the G buckets), the bytes they reduced, and the part of it the main stream actually waited for (`exposed_ms`: timing
+            # events either side of the waits in front of clip+Adam) -- everything else ran under the generator backward
+            comm["exposed_frac_of_step"] = round(comm["exposed_ms"] / ms, 5)
+            out["comm"] = comm
         if timer is not None:
             summ = timer.summary()
             # the dominant MFMA kernel by time (entries without FLOPs -- the slab reduce -- are bandwidth kernels; under a host-staged

@@ -107,19 +107,35 @@ def header_functions():
     return re.findall(r"\b(shm_[a-z0-9_]+)\s*\(", txt)
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip into libshmgan_hip.so with hipcc (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/*.hip into libshmgan_hip.so with hipcc (cross-compiles without a GPU): one object per source under
+    csrc/_obj/ (rebuilt when older than its source or a shared header, up to `jobs` at a time), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "common.h", CSRC / "ablate.h", HEADER]
+    shared = [CSRC / "common.h", CSRC / "ablate.h", HEADER]
+    deps = srcs + shared
     if not force and LIB_PATH.exists():
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, *map(str, srcs), "-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    objdir = CSRC / "_obj"
+    objdir.mkdir(exist_ok=True)
+    hdr_time = max(p.stat().st_mtime for p in shared)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    todo = []
+    for src in srcs:
+        obj = objdir / (src.stem + ".o")
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
+            todo.append([hipcc, *cflags, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=jobs or min(4, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[str(objdir / (src.stem + ".o")) for src in srcs], "-o", str(LIB_PATH)])
     return LIB_PATH
 
 

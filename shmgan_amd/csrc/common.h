@@ -167,9 +167,16 @@ static inline void shm_same_pad(int in, int k, int s, int* out, int* before) {
 }
 
 __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-// LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions (v_mul, v_med3 with FLT_MAX -- with +inf LLVM folds the median back into fmaxf): fmaxf costs a third -- hipcc quiets a
-// possible signalling NaN in u first (v_max u, u, u), which for an MFMA result it cannot rule out.  Bit-identical to shm_lrelu.
-__device__ __forceinline__ float shm_lrelu_max(float u, float slope) { return __builtin_amdgcn_fmed3f(u, u * slope, 3.4028234663852886e38f); }
+// LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions (v_mul, v_max): fmaxf costs a third -- hipcc quiets a possible signalling NaN in u first
+// (v_max u, u, u), which for an MFMA result it cannot rule out; the instruction itself already does that in the kernels' IEEE mode.  Same bits as shm_lrelu for every
+// finite u; a NaN stays a NaN (both operands are NaN then), so a diverged activation still shows in the statistics and the losses (round 3 used
+// v_med3(u, u * slope, FLT_MAX), which turned a NaN into FLT_MAX: advisor finding).  A plain VALU instruction whose inputs hipcc sees: no memory operation, no hazard of its own.
+__device__ __forceinline__ float shm_lrelu_max(float u, float slope) {
+    const float m = u * slope;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(m));
+    return r;
+}
 
 // InstanceNormalization apply, (x - mean) * inv + beta, in ONE spelling for the stand-alone pass (shm_in_apply) and for the
 // consumers that normalise their operand tile in LDS ("fused block", shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm): a

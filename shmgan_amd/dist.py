@@ -50,9 +50,13 @@ class GradReducer:
     def __init__(self, device=None):
         self.device = device
         self.stream = None
+        # measurement only (bench.py, N > 1): when a list, every collective is bracketed by timing events on the reducer stream
+        # and every consumer-side wait by timing events on the consumer stream; comm_summary() turns them into milliseconds
+        self.probe = None
 
-    def allreduce_async(self, flat, after=None):
-        """`after`: optional extra event (e.g. the wgrad lane) the collective must also wait for."""
+    def allreduce_async(self, flat, after=None, tag="g"):
+        """`after`: optional extra event (e.g. the wgrad lane) the collective must also wait for.  tag: bucket family ("d" / "g")
+        for the probe."""
         if world_size() == 1:
             return None
         if not flat.is_cuda:
@@ -67,9 +71,50 @@ class GradReducer:
             self.stream.wait_event(ready)
             if after is not None:
                 self.stream.wait_event(after)
-            self._reduce(flat)
+            if self.probe is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.stream)          # behind the waits: the bracket holds the collective, not the producer
+                self._reduce(flat)
+                t1.record(self.stream)
+                self.probe.append((tag, flat.numel() * flat.element_size(), t0, t1))
+            else:
+                self._reduce(flat)
             done.record(self.stream)
         return done
+
+    def wait_on(self, event, stream=None):
+        """Consumer side: `stream` (default: the current one) waits for a collective's `done` event.  Under the probe the wait is
+        bracketed by two timing events on that stream: their distance is the time the consumer stream sat idle behind the
+        collective, i.e. the EXPOSED communication time of this wait."""
+        if event is None:
+            return
+        stream = stream or torch.cuda.current_stream()
+        if self.probe is None:
+            stream.wait_event(event)
+            return
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(stream)
+        stream.wait_event(event)
+        t1.record(stream)
+        self.probe.append(("wait", 0, t0, t1))
+
+    def comm_summary(self, steps):
+        """Per-step averages of the probe (call after a device synchronize): collective time on the reducer stream per bucket
+        family, bytes reduced, and the exposed time (consumer-stream waits).  Clears the probe."""
+        out = {"exposed_ms": 0.0, "d_bucket_ms": 0.0, "g_buckets_ms": 0.0, "bytes": 0, "collectives": 0}
+        for tag, nbytes, t0, t1 in self.probe or ():
+            ms = t0.elapsed_time(t1)
+            if tag == "wait":
+                out["exposed_ms"] += ms
+            else:
+                out["d_bucket_ms" if tag == "d" else "g_buckets_ms"] += ms
+                out["bytes"] += nbytes
+                out["collectives"] += 1
+        n = max(int(steps), 1)
+        out = {k: (round(v / n, 4) if isinstance(v, float) else v // n) for k, v in out.items()}
+        if self.probe is not None:
+            self.probe = []
+        return out
 
     @staticmethod
     def _reduce(flat):

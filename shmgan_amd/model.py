@@ -659,17 +659,23 @@ class Generator(_ModelBase):
         if scaled:
             dzsum = A.get(f"bwd/dzsum/L{li}/{n}", (n, cout), torch.float64)
             ops.in_bwd_keep_dz_sums(dzsum)
-        if rank1 is not None:
-            red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
-            ops.in_bwd_rank1(rank1[0], rank1[1], rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
-        elif rec.get("gred") is not None and (g2 is None) == (rec.get("gredp") is None):
-            dstage = A.get(f"bwd/dstage/{n * cout}", (n * cout,), torch.float64)
-            ops.in_bwd_apply(g1, cout, g2, cout, rec["a"], cout, rec["stats"], self.betas[rec["bi"]], rec.pop("gred"), rec.pop("gredp", None),
-                             dstage, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
-        else:
-            red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
-            ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
-                       h, w, cout, LRELU)
+        try:
+            if rank1 is not None:
+                red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
+                ops.in_bwd_rank1(rank1[0], rank1[1], rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
+            elif rec.get("gred") is not None and (g2 is None) == (rec.get("gredp") is None):
+                dstage = A.get(f"bwd/dstage/{n * cout}", (n * cout,), torch.float64)
+                ops.in_bwd_apply(g1, cout, g2, cout, rec["a"], cout, rec["stats"], self.betas[rec["bi"]], rec.pop("gred"), rec.pop("gredp", None),
+                                 dstage, dz, cout, self._acc_slice(2 * li + 1), n, h, w, cout, LRELU)
+            else:
+                red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
+                ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
+                           h, w, cout, LRELU)
+        finally:
+            # the request is one-shot, thread-local state of the library, consumed by the call above; if Python raised before reaching
+            # it (an arena allocation, a bad argument) it must not stay armed for an unrelated InstanceNorm backward (advisor, round 3)
+            if scaled:
+                ops.in_bwd_keep_dz_sums(None)
         if self.debug is not None:           # test diagnostics: keep the per-layer gradients
             if g1 is None:
                 g1 = rank1[0].reshape(n, h, w, 1) * rank1[1].reshape(1, 1, 1, -1)

@@ -280,9 +280,9 @@ class ShmGANwithSSpecSeg:
     def _world(self):
         return world_size()
 
-    def _allreduce_async(self, flat, after=None):
+    def _allreduce_async(self, flat, after=None, tag="g"):
         """Sum `flat` over ranks on the side stream; returns an event to wait on (or None)."""
-        return self._reducer.allreduce_async(flat, after)
+        return self._reducer.allreduce_async(flat, after, tag)
 
     # ------------------------------------------------------------------ the step
     def train_step(self, orig0, orig45, orig90, orig135, origED, *, draws=None, style_factor=None, apply=True, next_batch=None):
@@ -378,7 +378,7 @@ class ShmGANwithSSpecSeg:
         if self.before_backward is not None:
             self.before_backward()
         D.backward_params(drf_d, dcls_d)
-        ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event())
+        ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event(), tag="d")
 
         # ---- G-loss gradient through D (data gradient only), then G backward
         # Both first layers are left through the channel-summed stencil (ops.conv3x3_dgrad_sum1): yuv_to_rgb's
@@ -427,21 +427,16 @@ class ShmGANwithSSpecSeg:
 
         # ---- clip + Adam  SHM.py:859-872
         if apply:
-            cur = torch.cuda.current_stream()
-            if ev_d is not None:
-                cur.wait_event(ev_d)
+            self._reducer.wait_on(ev_d)
             self.optimizer_D.apply(D.P, 1.0 / world)
             D.weights_dirty = True
             if update_g:
-                if ev_g is not None:
-                    cur.wait_event(ev_g)
+                self._reducer.wait_on(ev_g)
                 self.optimizer_G.apply(G.P, 1.0 / world)
                 G.weights_dirty = True
         elif world > 1:
-            cur = torch.cuda.current_stream()
             for ev in (ev_d, ev_g):
-                if ev is not None:
-                    cur.wait_event(ev)
+                self._reducer.wait_on(ev)
 
         # ---- attribute side effects (SHM.py:538-553, 620-624, 863, 872)
         self.gen_input, self.gen_Y, self.gen_rgb = gen_in, gen_Y, gen_rgb
@@ -549,19 +544,48 @@ class ShmGANwithSSpecSeg:
             dist.barrier()
 
     def _restore_latest(self):
-        """Load the newest checkpoint that reads back; a truncated / corrupt newest file (a run killed mid-write by an
-        older version, a full disk) falls back to the one before it.  A checkpoint of the other attention mode is a
-        configuration error and raises."""
+        """Load the newest checkpoint that reads back.  ONE rank decides: rank 0 reads every candidate completely (every array
+        decoded, i.e. CRC-checked, names and shapes checked against this trainer) WITHOUT touching any state, newest first,
+        skipping only files that are damaged as files (zipfile.BadZipFile / EOFError: a run killed mid-write by an older version,
+        a full disk); the chosen path (or None) is broadcast, every rank loads exactly that file, and the ranks then agree on a
+        success flag -- a rank that could not load what rank 0 chose ends the job (non-zero exit) instead of training on other
+        weights, Adam state and draw streams than its peers.  Anything else (EACCES, EIO, a checkpoint of another model
+        configuration or attention mode) is not a damaged file and propagates."""
         import zipfile
-        for path in reversed(self._checkpoints()):
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.G is None:
+            self.build()
+        chosen, payload = None, None
+        if self._rank() == 0:
+            for path in reversed(self._checkpoints()):
+                try:
+                    payload = self._read_npz(path)
+                    chosen = path
+                    break
+                except (zipfile.BadZipFile, EOFError) as e:
+                    print(f"checkpoint {path} is unreadable ({type(e).__name__}: {e}); trying the previous one")
+        if multi:
+            box = [chosen]
+            dist.broadcast_object_list(box, src=0)
+            chosen = box[0]
+        ok, err = 1, None
+        if chosen is not None:
             try:
-                self.load_npz(path)
-                return path
-            except (zipfile.BadZipFile, EOFError, OSError, KeyError) as e:
-                if isinstance(e, KeyError) and "attention" in str(e):
-                    raise
-                print(f"checkpoint {path} is unreadable ({type(e).__name__}: {e}); trying the previous one")
-        return None
+                if payload is None:
+                    payload = self._read_npz(chosen)
+                self._apply_npz(*payload)
+            except Exception as e:                      # reported after the ranks have compared notes, never swallowed
+                ok, err = 0, e
+        if multi:
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise RuntimeError(f"rank {self._rank()}: the ranks disagree about checkpoint {chosen} (this rank: "
+                                   f"{'loaded' if ok else repr(err)}); refusing to train on diverged replicas") from err
+        elif err is not None:
+            raise err
+        return chosen
 
     def _save_checkpoint(self, max_to_keep=3):
         """tf.train.CheckpointManager(ckpt, checkpoint_dir, max_to_keep=3).save() (SHM.py:944, 1127).  Rank 0 writes (to a
@@ -646,31 +670,59 @@ class ShmGANwithSSpecSeg:
             "rng": self._rng.bit_generator.state, "batch_step": int(getattr(self, "batch_step", 0))}))
         np.savez(path, **d)
 
-    def load_npz(self, path):
-        z = np.load(path)
-        state = None
-        if "trainer/state" in z.files:
-            import json
-            state = json.loads(str(z["trainer/state"]))
-            if state["attention"] != self.attention:
-                raise KeyError(f"checkpoint {path} holds an attention='{state['attention']}' model, this trainer was built with "
-                               f"attention='{self.attention}' (the live branch adds 20 + 4 variables)")
+    def _read_npz(self, path):
+        """Read and validate a save_npz file completely without mutating anything: every array this trainer's models need is
+        decoded (zipfile checks the CRC of each member as it is read) and shape-checked.  Returns (arrays, trainer state)."""
+        import json
         if self.G is None:
             self.build()
+        with np.load(path) as z:
+            state = None
+            if "trainer/state" in z.files:
+                state = json.loads(str(z["trainer/state"]))
+                if state["attention"] != self.attention:
+                    raise KeyError(f"checkpoint {path} holds an attention='{state['attention']}' model, this trainer was built with "
+                                   f"attention='{self.attention}' (the live branch adds 20 + 4 variables)")
+            arrays = {}
+            for name, M in (("G", self.G), ("D", self.D)):
+                for i, shape in enumerate(M.P.shapes[:len(M.P.vars)]):
+                    a = z[f"{name}/var{i:02d}"]
+                    if tuple(a.shape) != tuple(shape):
+                        raise KeyError(f"checkpoint {path}: {name}/var{i:02d} has shape {tuple(a.shape)}, this model's is {tuple(shape)}")
+                    arrays[f"{name}/var{i:02d}"] = a
+                for i in range(len(M.betas)):
+                    arrays[f"{name}/beta{i:02d}"] = z[f"{name}/beta{i:02d}"]
+                for k in ("adam_m", "adam_v"):
+                    a = z[f"{name}/{k}"]
+                    if a.size != M.P.m.numel():
+                        raise KeyError(f"checkpoint {path}: {name}/{k} has {a.size} elements, this model's flat buffer {M.P.m.numel()}")
+                    arrays[f"{name}/{k}"] = a
+                arrays[f"{name}/iterations"] = z[f"{name}/iterations"]
+            if "SpecSeg/var00" in z.files:
+                if self.SpecSeg is None:
+                    self.SpecSeg = self.build_specseg()
+                for i in range(len(self.SpecSeg.vars)):
+                    arrays[f"SpecSeg/var{i:02d}"] = z[f"SpecSeg/var{i:02d}"]
+        return arrays, state
+
+    def _apply_npz(self, z, state):
         for name, M in (("G", self.G), ("D", self.D)):
             M.set_weights([z[f"{name}/var{i:02d}"] for i in range(len(M.P.vars))])
             M.set_betas([z[f"{name}/beta{i:02d}"] for i in range(len(M.betas))])
             M.P.m.copy_(torch.from_numpy(z[f"{name}/adam_m"]))
             M.P.v.copy_(torch.from_numpy(z[f"{name}/adam_v"]))
             M.P.iterations = int(z[f"{name}/iterations"])
-        if "SpecSeg/var00" in z.files:
-            if self.SpecSeg is None:
-                self.SpecSeg = self.build_specseg()
+        if "SpecSeg/var00" in z:
             self.SpecSeg.set_weights([z[f"SpecSeg/var{i:02d}"] for i in range(len(self.SpecSeg.vars))])
         if state is not None:            # continue the draw streams instead of replaying the first run's opening steps
             self.epoch = int(state["epoch"])
             self._draw_count = int(state["draw_count"])
             self._rng.bit_generator.state = state["rng"]
+
+    def load_npz(self, path):
+        """Inverse of save_npz.  The file is read and validated as a whole first (`_read_npz`), so a damaged or mismatching
+        file raises before any weight, Adam moment or draw-stream state has been touched."""
+        self._apply_npz(*self._read_npz(path))
 
     def _img_ws(self, B):
         n = ops.image_losses_workspace(B, self.image_size)

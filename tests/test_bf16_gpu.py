@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import step_torch as st
-from util import conv_ref, cosine, host, nchw, nhwc, pad_c, rel_l2, t64
+from util import check_grad_fixture, conv_ref, cosine, grad_cosines, host, nchw, nhwc, pad_c, pin_kinks, pin_to_model, rel_l2, t64
 
 pytestmark = pytest.mark.gpu
 
@@ -421,10 +421,85 @@ def test_config3_s512_b4_against_the_oracle_fixture(dt):
         _check_forward_fixture(m, gold, B, sub, loss_tol=2e-2, y_tol=2e-2, ssim_tol=2e-2)
     else:
         _check_forward_fixture(m, gold, B, sub, loss_tol=1e-4, y_tol=1e-4, ssim_tol=1e-4)
-    assert bool(torch.isfinite(m.G.P.grad).all()) and bool(torch.isfinite(m.D.P.grad).all())
-    assert float(m.G.P.grad.norm()) > 0 and float(m.D.P.grad.norm()) > 0
-    del m
+    # ---- the backward of the same B=4 step (round 4; it was only checked to be finite): the B=4 grids select other variants, splits
+    # and block counts than B=1, so (a) the fp32 gradient must equal the mean of the four samples' B=1 gradients (batch rule; the
+    # B=1 dispatch at this size is held to the float64 fixture by test_config3_size_backward_fp32_against_the_oracle_fixture)
+    # and (b) the bf16 gradient must agree with the fp32 backward of the same step evaluated on the bf16 run's LeakyReLU sign
+    # pattern (util.pin_to_model) to SURVEY 8(c)'s bf16 bound, cosine >= 0.99 per kernel tensor.
+    inp, dr, sf = st.make_inputs(B, S), st.make_draws(step, B, S, F), st.style_factor_intended(S)
+    if dt == "float32":
+        g4, d4 = m.G.P.grad.clone(), m.D.P.grad.clone()
+        del m
+        torch.cuda.empty_cache()
+        m1 = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=1, compute_dtype=dt).build()
+        m1.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+        gs, dsum = torch.zeros_like(g4), torch.zeros_like(d4)
+        for b in range(B):
+            drb = st.StepDraws(dr.flags, dr.target_label, dr.noise[[b, B + b]], dr.keep_mask[[b, B + b]])
+            m1.train_step(*[a[b:b + 1] for a in inp], draws=drb, style_factor=sf, apply=False)
+            gs += m1.G.P.grad / B
+            dsum += m1.D.P.grad / B
+        torch.cuda.synchronize()
+        # as test_full_size_batch_rule: different tile variants per grid size put a handful of pre-activations on the other side
+        # of a kink
+        assert rel_l2(host(g4), host(gs)) < 3e-3 and cosine(host(g4), host(gs)) > 0.99999, rel_l2(host(g4), host(gs))
+        assert rel_l2(host(d4), host(dsum)) < 3e-3 and cosine(host(d4), host(dsum)) > 0.99999, rel_l2(host(d4), host(dsum))
+        del m1
+    else:
+        ref = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype="float32").build()
+        ref.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+        ref.before_backward, differ = pin_to_model(ref, m)
+        ref.train_step(*inp, draws=dr, style_factor=sf, apply=False)
+        torch.cuda.synchronize()
+        worst = grad_cosines(m, ref)
+        print(f"config3 bf16 vs fp32 on the bf16 sign pattern: worst tensor {worst}; signs differing: max {max(differ.values()):.4f}")
+        assert 0 < max(differ.values()) < 0.05            # bf16 rounding moves ~1 % of the pre-activations across zero
+        del ref, m
     torch.cuda.empty_cache()
+
+
+def test_config3_size_backward_fp32_against_the_oracle_fixture():
+    """BASELINE configs[3]'s image size, S=512 (F=64, B=1), one FULL step against the committed float64-oracle fixture
+    tests/golden/step_S512_F64_B1.npz (oracle/make_golden.py --s512-step: forward + both backward passes of one sample, ~36 GB /
+    10 min of CPU): every named loss, gen_Y, SSIM, and per-tensor gradient norms and projections of all 53 weight tensors,
+    kink-pinned (util.pin_kinks) to 1e-3.  The S=512 dispatch takes other grids, halo / DMA variant choices and split-K counts
+    than S=256, and the 1 310 720-weight Dense: this is where its backward kernels meet the oracle."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    from oracle import specseg_torch as sp
+    gold = _fixture("step_S512_F64_B1.npz")
+    S, F, B, step, sub = [int(v) for v in gold["meta"]]
+    assert (S, F, B) == (512, 64, 1)
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B).build()
+    m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    m.before_backward, pinned = pin_kinks(m, gold)
+    m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    _check_forward_fixture(m, gold, B, sub, loss_tol=1e-4, y_tol=1e-4, ssim_tol=1e-4)
+    listed, flipped = sum(v[0] for v in pinned.values()), sum(v[1] for v in pinned.values())
+    print(f"S=512 kink pins: {flipped} of {listed} listed near-kink elements had the other sign on the device")
+    assert listed > 0 and flipped < 0.2 * listed
+    errs = check_grad_fixture(m, gold, med_tol=1e-3, worst_tol=1e-3)
+    print("S=512 fp32 worst norm / projection error:", {k: (float(v[0].max()), float(v[1].max())) for k, v in errs.items()})
+    # the same size in bf16, against the same fixture, un-pinned (a committed fixture cannot take the device's sign pattern, and
+    # bf16 moves ~1 % of the pre-activations across zero: test_bf16_train_step): norms and projections to the loose bound that
+    # holds without pinning; the pinned comparison at this size is the bf16 leg of test_config3_s512_b4_against_the_oracle_fixture
+    mb = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype="bfloat16").build()
+    mb.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    mb.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    _check_forward_fixture(mb, gold, B, sub, loss_tol=2e-2, y_tol=2e-2, ssim_tol=2e-2)
+    eb = check_grad_fixture(mb, gold, med_tol=BF16_UNPINNED_MED, worst_tol=BF16_UNPINNED_WORST)
+    print("S=512 bf16 un-pinned norm / projection error (max, median):",
+          {k: (float(v[0].max()), float(np.median(v[0])), float(v[1].max()), float(np.median(v[1]))) for k, v in eb.items()})
+    del m, mb
+    torch.cuda.empty_cache()
+
+
+# Un-pinned bf16 gradients against a float64 fixture: per-tensor |norm ratio - 1| and |projection error| / norm.  A cosine of 0.99
+# is a relative error of 0.14; without pinning the kink events of bf16 (test_bf16_train_step: cosines 0.88-0.99 at S=64, better on
+# larger maps) add to that.  Calibrated on the S=512 and S=256 / B=32 runs (worst observed in the comment of each test), with margin.
+BF16_UNPINNED_MED = 0.15
+BF16_UNPINNED_WORST = 0.5
 
 
 def test_config4_b32_bf16_equals_the_b8_fixture_under_the_batch_rule():
@@ -456,6 +531,27 @@ def test_config4_b32_bf16_equals_the_b8_fixture_under_the_batch_rule():
         assert rel_l2(gy[b, ::sub, ::sub], gold["gen_Y_sub"][b % B8]) <= 2e-2, b
         assert np.array_equal(gy[b], gy[b % B8]), b
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() <= 2e-2
-    assert bool(torch.isfinite(m.G.P.grad).all()) and bool(torch.isfinite(m.D.P.grad).all())
+    # ---- the backward at B=32 (round 4; it was only checked to be finite).  Under the batch rule the B=32 gradient of the tiled
+    # batch IS the B=8 fixture's gradient.  (a) bf16 against the fixture's per-tensor norms and projections, un-pinned;
+    # (b) bf16 against the fp32 backward of the same B=32 step on the bf16 run's sign pattern: cosine >= 0.99 per kernel tensor;
+    # (c) that fp32 B=32 dispatch itself against the fixture, pinned to the float64 kinks (indices mapped to the four copies), 1e-3.
+    eb = check_grad_fixture(m, gold, med_tol=BF16_UNPINNED_MED, worst_tol=BF16_UNPINNED_WORST)
+    print("B=32 bf16 un-pinned norm / projection error (max, median):",
+          {k: (float(v[0].max()), float(np.median(v[0])), float(v[1].max()), float(np.median(v[1]))) for k, v in eb.items()})
+    ref = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype="float32").build()
+    ref.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
+    ref.before_backward, differ = pin_to_model(ref, m)
+    ref.train_step(*inp, draws=dr, style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    worst = grad_cosines(m, ref)
+    print(f"config4 bf16 vs fp32 on the bf16 sign pattern: worst tensor {worst}; signs differing: max {max(differ.values()):.4f}")
     del m
+    torch.cuda.empty_cache()
+    ref.before_backward, pinned = pin_kinks(ref, gold, tile=R)
+    ref.train_step(*inp, draws=dr, style_factor=st.style_factor_intended(S), apply=False)
+    torch.cuda.synchronize()
+    listed, flipped = sum(v[0] for v in pinned.values()), sum(v[1] for v in pinned.values())
+    assert listed > 0 and flipped < 0.2 * listed
+    check_grad_fixture(ref, gold, med_tol=1e-3, worst_tol=1e-3)
+    del ref
     torch.cuda.empty_cache()

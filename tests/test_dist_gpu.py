@@ -76,7 +76,75 @@ def test_two_ranks_on_one_gpu_equal_one_batch_of_two():
         # ... and clip + Adam with gscale = 1/world leaves the same weights on every rank
         # (first Adam step = lr * g / (|g| + 1e-6) with lr = 2e-5: a gradient element of ~1e-6 whose 1e-3-relative error flips
         # its sign moves its weight by up to 2 lr; everywhere else the replicas' weights match the single-process ones)
-        for w, r in ((wG, refs[2]), (wD, refs[3])):
+        # The 2 lr allowance is only for those near-zero gradient elements, selected from the REFERENCE gradient: wherever
+        # |g| exceeds 1e-4 of the model's largest gradient element a sign flip is impossible and a cross-rank scale error
+        # (a wrong 1/world, a bucket reduced twice) would show, so those weights are held to a tenth of a step.
+        for w, r, g in ((wG, refs[2], refs[0]), (wD, refs[3], refs[1])):
             e = np.abs(w - r)
+            big = np.abs(g) > 1e-4 * np.abs(g).max()
+            assert big.mean() > 0.5, big.mean()
+            assert e[big].max() <= 2e-6, (e[big].max(), int((e[big] > 2e-6).sum()))
             assert e.max() <= 2.02 * 2e-5 and (e > 2e-6).mean() < 1e-2, (e.max(), (e > 2e-6).mean())
     assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])     # replicas stay identical
+
+
+def _restore_worker(rank, world, port, q, ckdir, break_rank1):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m = ShmGANwithSSpecSeg(image_size=32, filter_size=16, batch_size=1, checkpoint_save_dir=ckdir)
+    if break_rank1 and rank == 1:
+        def boom(path):
+            raise OSError(5, "Input/output error", path)
+        m._read_npz = boom
+    try:
+        got = m._restore_latest()
+        q.put((rank, "ok", got, m.G.P.flat.cpu().numpy(), int(m.G.P.iterations), int(m._draw_count)))
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e), None, None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_rank1", [False, True])
+def test_ranks_restore_the_checkpoint_rank0_chose_or_fail_together(tmp_path, break_rank1):
+    """Round-3 advisor finding: every rank used to pick and load a checkpoint on its own and swallowed read errors, so a
+    transient error on one rank left replicas with different weights / Adam state / draw streams.  Now rank 0 validates
+    (newest first, skipping only damaged files), broadcasts its choice, every rank loads that file and the ranks compare a
+    success flag: with the newest file truncated both ranks end up on ckpt-1; with rank 1 unable to read it BOTH ranks
+    raise instead of training on."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    kw = dict(image_size=32, filter_size=16, batch_size=1, checkpoint_save_dir=str(tmp_path))
+    m = ShmGANwithSSpecSeg(**kw).build()
+    inp = st.make_inputs(1, 32)
+    m.train_step(*inp)
+    p1 = m._save_checkpoint()
+    w1 = host(m.G.P.flat).copy()
+    m.train_step(*inp)
+    p2 = m._save_checkpoint()
+    with open(p2, "r+b") as f:
+        f.truncate(1000)
+    torch.cuda.synchronize()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_restore_worker, args=(r, 2, port, q, str(tmp_path), break_rank1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=600)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if break_rank1:
+        assert got[0][0] == got[1][0] == "raised" and "disagree" in got[0][1] and "Input/output" in got[1][1], got
+    else:
+        for rank in (0, 1):
+            status, path, w, it, dc = got[rank]
+            assert status == "ok" and path == p1 and it == 1 and dc == 1
+            assert np.array_equal(w, w1)

@@ -8,7 +8,7 @@ import torch
 
 from oracle import specseg_torch as sp
 from oracle import step_torch as st
-from util import cosine, dev, host, rel_l2, t64
+from util import check_grad_fixture as _check_grad_fixture, pin_kinks as _pin_kinks, cosine, dev, host, rel_l2, t64
 
 pytestmark = pytest.mark.gpu
 
@@ -291,54 +291,6 @@ def test_golden_fixture_on_device(name):
     assert np.abs(host(m.gen_Y) - gold["gen_Y"]).max() < 1e-4
     assert np.abs(np.array(got["ssim"]) - gold["ssim"].mean(axis=1)).max() < 1e-4
     _check_grad_fixture(m, gold)
-
-
-def _pin_kinks(m, gold):
-    """Hook for trainer.before_backward: put the device on the float64 oracle's side of every LeakyReLU kink.  The
-    fixture lists, per pass and layer, the pre-activations with |z| < kink/thr in float64 and their sign
-    (oracle.step_torch.KinkRecorder); float32 rounding can only disagree about those.  Where the stored activation has
-    the other sign it is replaced by +-1e-30 (a forward change of at most 0.8*thr at a few elements of tensors that are
-    already consumed), so the backward pass differentiates the same piecewise-linear function as the oracle did.
-    Returns a dict that receives {(tag, layer): (listed, flipped)}."""
-    stats = {}
-
-    def hook():
-        tensors = {"g1": m.G.lrelu_tensors("g1"), "cyc": m.G.lrelu_tensors("cyc"), "d": m.D.lrelu_tensors()}
-        for key in gold.files:
-            if not key.startswith("kink/") or not key.endswith("/idx"):
-                continue
-            _, tag, layer, _ = key.split("/")
-            idx = torch.from_numpy(gold[key]).cuda()
-            pos = torch.from_numpy(gold[key[:-3] + "pos"]).cuda()
-            flat = tensors[tag][int(layer)].view(-1)
-            assert idx.numel() == 0 or int(idx.max()) < flat.numel()
-            cur = flat[idx]
-            bad = (cur > 0) != pos
-            # a disagreement may only concern a value float32 puts within rounding distance of zero
-            assert float(cur[bad].abs().max()) < 10 * float(gold["kink/thr"]) if bool(bad.any()) else True
-            flat[idx[bad]] = torch.where(pos[bad], 1e-30, -1e-30).to(flat.dtype)
-            stats[(tag, int(layer))] = (int(idx.numel()), int(bad.sum()))
-    return hook, stats
-
-
-def _check_grad_fixture(m, gold, med_tol=1e-3, worst_tol=5e-2):
-    """Per-tensor gradient norms and fixed random projections of the fixture (oracle/make_golden.py: one
-    default_rng(99) stream over the G tensors, then the D tensors).  A LeakyReLU kink event (see
-    test_train_step_parity: the fixture cannot pin the device's sign pattern) can move one layer by ~1e-2, so the
-    worst tensor is held to 5e-2 of its norm and the median to 1e-3 -- unless the caller pinned the kinks (_pin_kinks),
-    which holds every tensor to worst_tol = 1e-3."""
-    rng = np.random.default_rng(99)
-    for nm, P in (("gG", m.G.P), ("gD", m.D.P)):
-        n = np.array([float(t.norm()) for t in P.grads])
-        ref = gold[f"{nm}/norm"]
-        ok = ref > 1e-12
-        assert np.abs(n[ok] / ref[ok] - 1).max() < worst_tol, (nm, np.abs(n[ok] / ref[ok] - 1).max())
-        assert np.median(np.abs(n[ok] / ref[ok] - 1)) < med_tol
-        proj = np.array([float((t.detach().reshape(-1).double().cpu() * torch.from_numpy(rng.standard_normal(t.numel()))).sum())
-                         for t in P.grads])
-        err = np.abs(proj - gold[f"{nm}/proj"])[ok] / ref[ok]          # |<g - g_ref, r>| / |g_ref| ~ rel-L2 error
-        assert err.max() < worst_tol, (nm, err.max(), int(err.argmax()))
-        assert np.median(err) < med_tol, (nm, np.median(err))
 
 
 @pytest.mark.parametrize("name", ["step_S256_F64_B1.npz", "step_S256_F64_B8.npz"])

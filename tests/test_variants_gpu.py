@@ -197,6 +197,37 @@ def test_wreg_four_wave_bf16(n, h, cin, cout):
         SYMBOL["wreg"] = sym
 
 
+@pytest.mark.parametrize("dt,wreg16", [("f32", 1), ("bf16", 1), ("bf16", 0)])
+def test_wreg_kernels_keep_a_nan_a_nan(dt, wreg16):
+    """Round-3 advisor finding: the two-instruction LeakyReLU of the weights-in-registers kernels (common.h: shm_lrelu_max) was
+    v_med3(u, u * slope, FLT_MAX), which turns a NaN MFMA result into FLT_MAX -- a diverged activation became a finite number
+    and the fused statistics stayed finite.  One NaN input pixel must poison its 3 x 3 output neighbourhood (every channel) and
+    that sample's statistics, and nothing else."""
+    ops = _ops()
+    rng = np.random.default_rng(77)
+    n, h, cin, cout = 2, 32, 64, 64
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    x[1, 10, 20, 5] = np.nan
+    w = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = torch.zeros((n, h, h, cout), device="cuda", dtype=BF if dt == "bf16" else torch.float32)
+    stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+    ops.set_tuning("tapgemm.wreg16", wreg16)
+    ops.set_tuning("tapgemm.variant", "wreg")
+    ops.conv2d_in_fwd(_dev(x, dt), None, 0, cin, 0, _wk(w, cin, dt), torch.from_numpy(b).cuda(), y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    torch.cuda.synchronize()
+    assert ops.last_kernel().startswith("tapgemm_wreg"), ops.last_kernel()
+    got = host(y.float())
+    bad = np.isnan(got)
+    want = np.zeros_like(bad)
+    want[1, 9:12, 19:22, :] = True
+    assert np.array_equal(bad, want), (int(bad.sum()), int(want.sum()))
+    assert np.isfinite(got[~bad]).all() and np.abs(got[~bad]).max() < 1e3
+    s = host(stats).reshape(n, cout, 2)
+    assert np.isfinite(s[0]).all() and not np.isfinite(s[1][:, 0]).any()          # the poisoned sample's means
+
+
 @pytest.mark.parametrize("n,h,c1,c2,cout,sym", [
     (2, 32, 16, 0, 16, "tapgemm_wreg_f32_kernel<1, 1, false>"),      # SpecSeg 256-level layers: 16 output channels, 32-row patches
     (3, 64, 16, 16, 16, "tapgemm_wreg_f32_kernel<2, 1, true>"),     # Concatenate([up, skip]) of two 16-channel tensors, several patches per image
