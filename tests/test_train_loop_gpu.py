@@ -227,7 +227,9 @@ def test_conv_entry_points_are_bitwise_reproducible(dt):
     stats = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
     scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
     ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, c, c, 3) // 4 + 1024, device="cuda")
-    ref = None
+    dy2 = torch.randn((n, h // 2, h // 2, c), device="cuda").to(adt)            # stride-2 weight gradient of the same x (round 4: bf16 = the
+    ref = None                                                                  # eight-wave halo form with even / odd column runs)
+    ops.set_tuning("wgrad.bf16_wide", 4)                                        # ... and the eight-wave form at unit stride as well
     for r in range(30):
         y = torch.empty((n, h, h, c), device="cuda", dtype=adt)
         dx = torch.empty((n, h, h, c), device="cuda", dtype=adt)
@@ -235,8 +237,14 @@ def test_conv_entry_points_are_bitwise_reproducible(dt):
         ops.conv2d_in_fwd(x, None, 0, c, 0, wk, b, y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
         ops.conv2d_dgrad(dy, c, wop, dx, None, c, c, 0, n, h, h, c, c, 3, 1)
         ops.conv2d_wgrad(x, None, 0, c, 0, dy, c, dw, n, h, h, c, c, c, 3, 1, 0, ws)
+        k1 = ops.last_kernel()
+        dw2 = torch.empty((3, 3, c, c), device="cuda")
+        ops.conv2d_wgrad(x, None, 0, c, 0, dy2, c, dw2, n, h, h, c, c, c, 3, 2, 0, ws)
+        k2 = ops.last_kernel()
         torch.cuda.synchronize()
         if ref is None:
-            ref = (y, dx, dw)
+            ref = (y, dx, dw, dw2)
+            assert (k1, k2) == (("wgrad_halo8_bf16_kernel<false>", "wgrad_halo8_bf16_kernel<true>") if dt == "bf16" else ("wgrad_halo_kernel", "wgrad_halo_kernel<0, true>")), (k1, k2)
         else:
-            assert torch.equal(y, ref[0]) and torch.equal(dx, ref[1]) and torch.equal(dw, ref[2]), r
+            assert torch.equal(y, ref[0]) and torch.equal(dx, ref[1]) and torch.equal(dw, ref[2]) and torch.equal(dw2, ref[3]), r
+    ops.set_tuning("reset", 0)

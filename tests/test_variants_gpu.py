@@ -459,6 +459,7 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
     ref, = torch.autograd.grad(st.conv2d_same(nchw(_rnd(x[..., :cin], dt)), wt, 1), wt, nchw(_rnd(dy, dt)))
     ops.set_tuning("wgrad.variant", wv)
     ops.set_tuning("wgrad.blocks", blocks)
+    ops.set_tuning("wgrad.bf16_wide", 4)          # the eight-wave bf16 block at unit stride too (the automatic choice takes it at stride 2 only)
     ws = torch.empty(ops.conv2d_wgrad_workspace(n, h, h, cin, cout, 3) // 4 + 1024, device="cuda")
     for rows in ((0, 2) if dt == "bf16" and wv != 1 else (0,)):        # bf16 halo kernel: 4 (automatic here) and 2 pixel rows per stage
         ops.set_tuning("wgrad.bf16_rows", rows)
@@ -468,8 +469,17 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
         if wv == 1:
             assert k.startswith("wgrad_kernel<") or k.startswith("wgrad_bf16_kernel<"), k
         elif wv == 2:
-            assert k in ("wgrad_halo_kernel", f"wgrad_halo_bf16_kernel<{rows or 4}>"), k
+            # bf16 with >= 128 output channels on a map whose height is a multiple of four: the eight-wave 64 x 128 block (round 4)
+            wide = dt == "bf16" and cout >= 128 and rows == 0
+            assert k == ("wgrad_halo8_bf16_kernel<false>" if wide else "wgrad_halo_kernel" if dt == "f32" else f"wgrad_halo_bf16_kernel<{rows or 4}>"), k
         assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
+        if dt == "bf16" and wv == 2 and rows == 0 and cout >= 128:       # ... and the four-wave kernel on the same shape ("wgrad.bf16_wide" = 1)
+            ops.set_tuning("wgrad.bf16_wide", 1)
+            dw4 = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+            ops.conv2d_wgrad(_dev(x, dt), None, 0, ld, 0, _dev(dy, dt), cout, dw4, n, h, h, cin, ld, cout, 3, 1, 0, ws)
+            assert ops.last_kernel() == "wgrad_halo_bf16_kernel<4>", ops.last_kernel()
+            assert rel_l2(host(dw4), ref.numpy()) < 1e-4
+            ops.set_tuning("wgrad.bf16_wide", 4)
 
 
 # ---- stride-2 3x3 weight gradient: halo form (2 x 8 output patches, 5 x 17 input halo) against the generic kernel and float64
@@ -503,6 +513,60 @@ def test_wgrad_stride2_halo(n, h, cin, cout, c1, blocks):
         assert rel_l2(host(dw), 2 * ref.numpy()) < 1e-5
     ops.set_tuning("reset", 0)
     assert rel_l2(got[0], got[3]) < 1e-5
+
+
+# ---- bf16 stride-2 3x3 weight gradient (round 4): the eight-wave block on 2 x 16 output patches with the even / odd column runs of a
+# 5 x 33 input halo, against float64 on the bf16-rounded operands and against the generic kernel it replaces (wgrad_bf16_kernel<9>)
+@pytest.mark.parametrize("n,h,cin,cout,c1,blocks", [
+    (2, 32, 64, 128, 0, 0),        # one patch column, one 64 x 128 tile
+    (1, 64, 128, 256, 0, 0),       # two patch columns, 2 x 2 tiles
+    (2, 64, 128, 128, 64, 0),      # Concatenate split on a tile boundary
+    (3, 32, 96, 192, 0, 5),        # ragged ci (96) and co (192 = 128 + 64) tiles, odd batch, odd split count
+    (5, 32, 64, 128, 0, 3),        # blocks that cross image boundaries
+])
+def test_wgrad_stride2_bf16_wide(n, h, cin, cout, c1, blocks):
+    ops = _ops()
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((n, h, h, cin))
+    dy = rng.standard_normal((n, h // 2, h // 2, cout))
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(_rnd(x, "bf16")), wt, 2), wt, nchw(_rnd(dy, "bf16")))
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, cin, cout, 3) // 4 + 1024, device="cuda")
+    xa = _dev(np.ascontiguousarray(x[..., :c1] if c1 else x), "bf16")
+    xb = _dev(np.ascontiguousarray(x[..., c1:]), "bf16") if c1 else None
+    dyd = _dev(dy, "bf16")
+    got = {}
+    for wide in (0, 1):
+        ops.set_tuning("wgrad.bf16_wide", wide)
+        ops.set_tuning("wgrad.blocks", blocks)
+        ws.fill_(float("nan"))                    # every slab element a block owns must be written
+        dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+        ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
+        k = ops.last_kernel()
+        assert k == ("wgrad_halo8_bf16_kernel<true>" if wide == 0 else "wgrad_bf16_kernel<9, false>"), k
+        got[wide] = host(dw)
+        assert rel_l2(got[wide], ref.numpy()) < 1e-4, (k, rel_l2(got[wide], ref.numpy()))
+        ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 1, ws)     # accumulate
+        assert rel_l2(host(dw), 2 * ref.numpy()) < 1e-4
+    ops.set_tuning("reset", 0)
+    assert rel_l2(got[0], got[1]) < 1e-5          # both accumulate in fp32 from the same bf16 products: only the summation order differs
+
+
+def test_wgrad_stride2_bf16_wide_leaves_what_it_cannot_tile():
+    """an 8-column output map, 64 output channels and "wgrad.variant" 3 stay on the generic bf16 kernel"""
+    ops = _ops()
+    rng = np.random.default_rng(42)
+    for n, h, cin, cout, wv in ((2, 16, 64, 128, 0), (2, 32, 64, 64, 0), (2, 32, 64, 128, 3)):
+        x = rng.standard_normal((n, h, h, cin))
+        dy = rng.standard_normal((n, h // 2, h // 2, cout))
+        wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+        ref, = torch.autograd.grad(st.conv2d_same(nchw(_rnd(x, "bf16")), wt, 2), wt, nchw(_rnd(dy, "bf16")))
+        ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, cin, cout, 3) // 4 + 1024, device="cuda")
+        dw = torch.empty((3, 3, cin, cout), device="cuda")
+        ops.set_tuning("wgrad.variant", wv)
+        ops.conv2d_wgrad(_dev(x, "bf16"), None, 0, cin, 0, _dev(dy, "bf16"), cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
+        assert ops.last_kernel() == "wgrad_bf16_kernel<9, false>", ops.last_kernel()
+        assert rel_l2(host(dw), ref.numpy()) < 1e-4
 
 
 def test_wgrad_stride2_halo_refuses_what_it_cannot_tile():
