@@ -271,12 +271,46 @@ def main():
                              tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in ps.items()]
                 rows.sort(key=lambda r: -r["ms_per_step"])
                 Path(args.per_shape).write_text(json.dumps(rows, indent=1))
+        if not args.no_kernel_timer:
+            out["north_star_block"] = north_star_block(torch, ops, dev)
         if not args.no_cpu_baseline and world == 1:         # reported at N=1 only: the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def north_star_block(torch, ops, dev, n=40, h=256, c=64, reps=20):
+    """The block BASELINE.json's north star names -- fused 3x3 conv + bias + LeakyReLU + InstanceNorm statistics, 64 -> 64 channels at
+    256 x 256, in bf16, at the batch the step runs it with (n = 5 x 8 images of the cyclic generator pass) -- timed on its own after the
+    timed region: `reps` launches of shm_conv2d_in_fwd between two HIP events on the launch stream.  bytes = algorithmic traffic of one
+    launch (e * N*H*W*(Cin + Cout) + e * 9*Cin*Cout + 16 * N*Cout, e = 2), frac_hbm against the 8 TB/s HBM3E peak."""
+    dt = torch.bfloat16
+    x = torch.randn((n, h, h, c), device=dev).to(dt)
+    w = (torch.randn((3, 3, c, c), device=dev) * 0.05)
+    wk = torch.zeros(9 * c * c, device=dev, dtype=dt)
+    ops.transpose_taps(w, wk, 9, c, c, c)
+    b = torch.randn(c, device=dev)
+    y = torch.empty((n, h, h, c), device=dev, dtype=dt)
+    stats = torch.empty(n * c * 2, dtype=torch.float64, device=dev)
+    scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device=dev)
+    fn = lambda: ops.conv2d_in_fwd(x, None, 0, c, 0, wk, b, y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    for _ in range(3):
+        fn()
+    kernel = ops.last_kernel()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    nbytes = 2 * n * h * h * (c + c) + 2 * 9 * c * c + 16 * n * c
+    gbps = nbytes / us / 1e3
+    return {"block": f"conv3x3 {c}->{c} + bias + LeakyReLU + IN statistics, {h}x{h}, n={n}, bf16", "kernel": kernel, "bytes": nbytes,
+            "us": round(us, 2), "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "launches": reps,
+            "flops": 2.0 * n * h * h * 9 * c * c, "tflops": round(2.0 * n * h * h * 9 * c * c / us / 1e6, 1)}
 
 
 def launch_ranks(n):

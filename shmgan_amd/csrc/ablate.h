@@ -57,5 +57,10 @@ SHM_ABL_FLAG(wreg_prio, true);    // weights-in-registers kernel: s_setprio 1 ar
 #else
 SHM_ABL_FLAG(wreg_prio, false);
 #endif
+#ifdef SHM_ABL_STAMP
+SHM_ABL_FLAG(stamp, true);        // tapgemm_wreg16_bf16_kernel: s_memtime stamps at the phase boundaries of a patch; one block dumps its per-wave totals over the bias vector
+#else
+SHM_ABL_FLAG(stamp, false);
+#endif
 #undef SHM_ABL_FLAG
 }  // namespace abl

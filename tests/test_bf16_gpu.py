@@ -488,18 +488,42 @@ def test_config3_size_backward_fp32_against_the_oracle_fixture():
     mb.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
     torch.cuda.synchronize()
     _check_forward_fixture(mb, gold, B, sub, loss_tol=2e-2, y_tol=2e-2, ssim_tol=2e-2)
-    eb = check_grad_fixture(mb, gold, med_tol=BF16_UNPINNED_MED, worst_tol=BF16_UNPINNED_WORST)
-    print("S=512 bf16 un-pinned norm / projection error (max, median):",
-          {k: (float(v[0].max()), float(np.median(v[0])), float(v[1].max()), float(np.median(v[1]))) for k, v in eb.items()})
+    _check_unpinned_bf16(mb, gold, "S=512 B=1")
     del m, mb
     torch.cuda.empty_cache()
 
 
-# Un-pinned bf16 gradients against a float64 fixture: per-tensor |norm ratio - 1| and |projection error| / norm.  A cosine of 0.99
-# is a relative error of 0.14; without pinning the kink events of bf16 (test_bf16_train_step: cosines 0.88-0.99 at S=64, better on
-# larger maps) add to that.  Calibrated on the S=512 and S=256 / B=32 runs (worst observed in the comment of each test), with margin.
-BF16_UNPINNED_MED = 0.15
-BF16_UNPINNED_WORST = 0.5
+def _check_unpinned_bf16(m, gold, label):
+    """Un-pinned bf16 gradients against a float64 fixture: per tensor |norm ratio - 1| and |<g - g_ref, r>| / |g_ref| for the fixture's one
+    random direction r (a sample of the tensor's relative error: its standard deviation IS the relative error).  A cosine of 0.99 is a
+    relative error of 0.14; without pinning, the LeakyReLU kink events of a bf16 forward (test_train_step_bf16_vs_oracle: cosines 0.88-0.99
+    at S=64, better on larger maps) add to that, and bias vectors -- plain sums of dz, the part InstanceNorm's own backward cancels --
+    are noisier still.  Bounds: kernels (ndim > 1) median / worst, biases worst; calibrated on the S=512 and S=256 B=32 runs (observed
+    values are printed) with margin.  The pinned comparison -- cosine >= 0.99 per kernel tensor -- is grad_cosines against the fp32
+    backward on the bf16 sign pattern."""
+    rng = np.random.default_rng(99)
+    out = {}
+    for nm, P in (("gG", m.G.P), ("gD", m.D.P)):
+        ref = gold[f"{nm}/norm"]
+        n = np.array([float(t.norm()) for t in P.grads])
+        proj = np.array([float((t.detach().reshape(-1).double().cpu() * torch.from_numpy(rng.standard_normal(t.numel()))).sum()) for t in P.grads])
+        ok = ref > 1e-12
+        kern = np.array([t.dim() > 1 for t in P.grads]) & ok
+        bias = np.array([t.dim() == 1 for t in P.grads]) & ok
+        nerr, perr = np.abs(n / np.maximum(ref, 1e-300) - 1), np.abs(proj - gold[f"{nm}/proj"]) / np.maximum(ref, 1e-300)
+        out[nm] = dict(kern_norm=(float(nerr[kern].max()), float(np.median(nerr[kern]))), kern_proj=(float(perr[kern].max()), float(np.median(perr[kern]))),
+                       bias_norm=float(nerr[bias].max()) if bias.any() else 0.0, bias_proj=float(perr[bias].max()) if bias.any() else 0.0)
+    print(f"{label}: un-pinned bf16 vs float64 fixture (max, median):", out)
+    for nm, o in out.items():
+        assert o["kern_norm"][0] < BF16_UNPINNED["kern_norm_worst"] and o["kern_norm"][1] < BF16_UNPINNED["kern_norm_med"], (nm, o)
+        assert o["kern_proj"][0] < BF16_UNPINNED["kern_proj_worst"] and o["kern_proj"][1] < BF16_UNPINNED["kern_proj_med"], (nm, o)
+        assert o["bias_norm"] < BF16_UNPINNED["bias_norm_worst"] and o["bias_proj"] < BF16_UNPINNED["bias_proj_worst"], (nm, o)
+    return out
+
+
+# observed (S=512 B=1 / S=256 B=32): kernel norms max 0.0028 / 0.012, median 0.0009 / 0.0043; kernel projections max 0.63 / 0.55, median 0.10 / 0.14;
+# bias norms max 0.038 / 0.057, bias projections max 0.74 / 0.68
+BF16_UNPINNED = dict(kern_norm_worst=0.04, kern_norm_med=0.015, kern_proj_worst=1.5, kern_proj_med=0.35, bias_norm_worst=0.2, bias_proj_worst=2.0)
 
 
 def test_config4_b32_bf16_equals_the_b8_fixture_under_the_batch_rule():
@@ -535,9 +559,7 @@ def test_config4_b32_bf16_equals_the_b8_fixture_under_the_batch_rule():
     # batch IS the B=8 fixture's gradient.  (a) bf16 against the fixture's per-tensor norms and projections, un-pinned;
     # (b) bf16 against the fp32 backward of the same B=32 step on the bf16 run's sign pattern: cosine >= 0.99 per kernel tensor;
     # (c) that fp32 B=32 dispatch itself against the fixture, pinned to the float64 kinks (indices mapped to the four copies), 1e-3.
-    eb = check_grad_fixture(m, gold, med_tol=BF16_UNPINNED_MED, worst_tol=BF16_UNPINNED_WORST)
-    print("B=32 bf16 un-pinned norm / projection error (max, median):",
-          {k: (float(v[0].max()), float(np.median(v[0])), float(v[1].max()), float(np.median(v[1]))) for k, v in eb.items()})
+    _check_unpinned_bf16(m, gold, "S=256 B=32")
     ref = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, compute_dtype="float32").build()
     ref.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
     ref.before_backward, differ = pin_to_model(ref, m)

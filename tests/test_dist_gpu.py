@@ -76,14 +76,15 @@ def test_two_ranks_on_one_gpu_equal_one_batch_of_two():
         # ... and clip + Adam with gscale = 1/world leaves the same weights on every rank
         # (first Adam step = lr * g / (|g| + 1e-6) with lr = 2e-5: a gradient element of ~1e-6 whose 1e-3-relative error flips
         # its sign moves its weight by up to 2 lr; everywhere else the replicas' weights match the single-process ones)
-        # The 2 lr allowance is only for those near-zero gradient elements, selected from the REFERENCE gradient: wherever
-        # |g| exceeds 1e-4 of the model's largest gradient element a sign flip is impossible and a cross-rank scale error
-        # (a wrong 1/world, a bucket reduced twice) would show, so those weights are held to a tenth of a step.
+        # The 2 lr allowance is only for those near-zero gradient elements, selected from the REFERENCE gradient: where |g| is within a
+        # factor 100 of the model's largest gradient element (the tensors' 1e-3 relative error is then at most a tenth of the element: no
+        # sign flip, and the update lr * g / (|g| + 1e-6) is flat there) a cross-rank scale error -- a wrong 1/world, a bucket reduced
+        # twice -- would move the weight by a sizeable part of a step, so those weights are held to a tenth of a step.
         for w, r, g in ((wG, refs[2], refs[0]), (wD, refs[3], refs[1])):
             e = np.abs(w - r)
-            big = np.abs(g) > 1e-4 * np.abs(g).max()
-            assert big.mean() > 0.5, big.mean()
-            assert e[big].max() <= 2e-6, (e[big].max(), int((e[big] > 2e-6).sum()))
+            big = np.abs(g) > 1e-2 * np.abs(g).max()
+            assert big.sum() >= 100, int(big.sum())
+            assert e[big].max() <= 2e-6, (e[big].max(), int((e[big] > 2e-6).sum()), int(big.sum()))
             assert e.max() <= 2.02 * 2e-5 and (e > 2e-6).mean() < 1e-2, (e.max(), (e > 2e-6).mean())
     assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])     # replicas stay identical
 

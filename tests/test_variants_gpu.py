@@ -28,7 +28,7 @@ SYMBOL = {
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
-    "wreg": "tapgemm_wreg_f32_kernel<{nch}, 4, false, false, 0, {t}>",      # bf16: the eight-wave form ("tapgemm.wreg16", default on)
+    "wreg": "tapgemm_wreg16_bf16_kernel<{nch}>",                            # bf16: the eight-wave kernel with line-wide stores ("tapgemm.wreg16", default on)
     "wreg4": "tapgemm_wreg_kernel<{t}, {nch}>",                             # ... and the four-wave form with 32-column wave tiles
     "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 2>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true, 2>",
     "phase4": "tapgemm_phase4_kernel<{t}, {t}>", "halo128_st_w4": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 4>",

@@ -1,3 +1,3 @@
 set -o pipefail
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-shape gpurun_out/r4_pershape_f32.json > gpurun_out/r4_ps_f32.json 2> gpurun_out/r4_ps_f32.err; echo "f32 rc=$?"
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype bf16 --per-shape gpurun_out/r4_pershape_bf16.json > gpurun_out/r4_ps_bf16.json 2> gpurun_out/r4_ps_bf16.err; echo "bf16 rc=$?"
+timeout -k 10 900 python -m pytest tests/test_bf16_gpu.py tests/test_dist_gpu.py tests/test_variants_gpu.py -m gpu -q -s -k "config3 or config4 or ranks or nan" > gpurun_out/r4_t5.log 2>&1
+echo "pytest rc=$?"; grep -v "amdgpu.ids" gpurun_out/r4_t5.log | tail -40
