@@ -547,12 +547,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
     const int ho = a.h / IS, wo = a.w / IS;
     int n, pr, pc;
     {
-        const int ppr = wo / PW, ppi = (ho / 2) * ppr;
+        // Patches are numbered DOWN the columns of an image (round 4; until then along the rows): a block walks a contiguous range, and the
+        // halos of vertically adjacent patches share two of their four rows (half the halo) where horizontally adjacent ones share two of
+        // eighteen columns -- walking down, the shared rows were fetched one stage ago (L2 / L1 hits), walking along, 16 stages and a few
+        // hundred KiB per resident block ago, i.e. from beyond L2 (r03: 1291 MB HBM-side per launch for 805 MB of operands, L2 hit 0.19)
+        const int ppc = ho / 2, ppi = ppc * (wo / PW);
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
-        pr = (r / ppr) * 2;
-        pc = (r % ppr) * PW;
+        pc = (r / ppc) * PW;
+        pr = (r % ppc) * 2;
     }
     // DMA addressing, one v_add and one masked select per instruction: a lane's byte offset in item j is a per-lane constant plus the
     // patch origin, and whether its halo pixel lies outside the image depends only on which edges of the image the patch touches
@@ -596,12 +600,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 256), 16, (int)off, 0, 0, 0);
             }
         }
-        pc += PW;
-        if (pc == wo) {
-            pc = 0;
-            pr += 2;
-            if (pr == ho) {
-                pr = 0;
+        pr += 2;
+        if (pr == ho) {
+            pr = 0;
+            pc += PW;
+            if (pc == wo) {
+                pc = 0;
                 ++n;
             }
         }
@@ -674,12 +678,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradHaloArgs 
                 }
             }
         }
-        pc2 += PW;
-        if (pc2 == a.w) {
-            pc2 = 0;
-            pr2 += 2;
-            if (pr2 == a.h) {
-                pr2 = 0;
+        pr2 += 2;
+        if (pr2 == a.h) {
+            pr2 = 0;
+            pc2 += PW;
+            if (pc2 == a.w) {
+                pc2 = 0;
                 ++n2;
             }
         }
@@ -986,12 +990,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
 
     int n, pr, pc;
     {
-        const int ppr = a.w / PW, ppi = (a.h / R) * ppr;
+        const int ppc = a.h / R, ppi = ppc * (a.w / PW);           // patches numbered down the columns of an image, see wgrad_halo_kernel
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
-        pr = (r / ppr) * R;
-        pc = (r % ppr) * PW;
+        pc = (r / ppc) * PW;
+        pr = (r % ppc) * R;
     }
     // DMA addressing as in wgrad_halo_kernel: per-lane constant offset + patch origin, edge bits (five per item, one register)
     static_assert(NJ <= 6, "five mask bits per item in one register");
@@ -1026,12 +1030,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
             }
         }
-        pc += PW;
-        if (pc == a.w) {
-            pc = 0;
-            pr += R;
-            if (pr == a.h) {
-                pr = 0;
+        pr += R;
+        if (pr == a.h) {
+            pr = 0;
+            pc += PW;
+            if (pc == a.w) {
+                pc = 0;
                 ++n;
             }
         }
@@ -1101,12 +1105,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
             }
         }
         }
-        pc2 += PW;
-        if (pc2 == a.w) {
-            pc2 = 0;
-            pr2 += R;
-            if (pr2 == a.h) {
-                pr2 = 0;
+        pr2 += R;
+        if (pr2 == a.h) {
+            pr2 = 0;
+            pc2 += PW;
+            if (pc2 == a.w) {
+                pc2 = 0;
                 ++n2;
             }
         }
@@ -1274,12 +1278,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
 
     int n, pr, pc;                                      // patch origin in OUTPUT pixels
     {
-        const int ppr = wo / PW, ppi = (ho / R) * ppr;
+        const int ppc = ho / R, ppi = ppc * (wo / PW);             // patches numbered down the columns of an image, see wgrad_halo_kernel
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
-        pr = (r / ppr) * R;
-        pc = (r % ppr) * PW;
+        pc = (r / ppc) * PW;
+        pr = (r % ppc) * R;
     }
     // per-lane constants of this wave's items (item = wave + 8 j): byte offset inside the halo / patch, and five mask bits -- which
     // edges of the halo the lane's pixel sits on (1 top, 2 bottom, 4 left, 8 right) and 16 for lanes with nothing to fetch
@@ -1329,12 +1333,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
             }
         }
-        pc += PW;
-        if (pc == wo) {
-            pc = 0;
-            pr += R;
-            if (pr == ho) {
-                pr = 0;
+        pr += R;
+        if (pr == ho) {
+            pr = 0;
+            pc += PW;
+            if (pc == wo) {
+                pc = 0;
                 ++n;
             }
         }
