@@ -1,9 +1,12 @@
 """Where the wall time of a two-stream step goes: from a rocprofv3 kernel trace, per step (the last one in the trace)
 the union of kernel intervals, split into time with an MFMA kernel running, time with only other kernels, and idle gaps."""
 import csv
+import json
+import os
 import re
 import sys
 
+# usage: timeline.py <kernel_trace.csv> [out.json]   (the JSON distillate is what profiles/<tag>_timeline.json holds)
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 # steps are delimited by the Adam launches (two per step, the generator's is the last kernel of a step)
@@ -65,3 +68,11 @@ for s, e, n in step:
 print("exposed (no MFMA kernel running) by kernel:")
 for nm, v in sorted(exp.items(), key=lambda kv: -kv[1])[:25]:
     print(f"  {nm:42s} {v / 1e6:7.3f} ms")
+
+if len(sys.argv) > 2:
+    json.dump({"_meta": {"tree": os.environ.get("SHM_TREE_SHA", "unknown"), "csrc_sha16": os.environ.get("SHM_CSRC_SHA", "unknown"),
+                         "what": "rocprofv3 kernel trace of the PRODUCTION two-stream step (last complete step of the trace), tools/timeline.py"},
+               "wall_ms": round(wall, 3), "mfma_running_ms": round(acc["mfma"] / 1e6, 3), "elementwise_only_ms": round(acc["other_only"] / 1e6, 3),
+               "idle_ms": round(acc["idle"] / 1e6, 3), "kernels": len(step),
+               "exposed_ms_by_kernel": {nm: round(v / 1e6, 3) for nm, v in sorted(exp.items(), key=lambda kv: -kv[1])[:20] if v > 0}},
+              open(sys.argv[2], "w"), indent=1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace (timestamps) of the PRODUCTION step (two streams), for tools/timeline.py
-#   tools/trace_step.sh <tag> [bench.py arguments ...]
+#   SHM_TREE_SHA=<git sha> tools/trace_step.sh <tag> [bench.py arguments ...]   -> gpurun_out/trace_<tag>/distilled/<tag>_timeline.json
 set -e -o pipefail
 tag=$1; shift
 root=$(pwd)
@@ -10,7 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d "$out/t" -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer $* > "$out/log.txt" 2>&1
 cd "$root"
 f=$(find "$out/t" -name '*kernel_trace.csv' | head -1)
-python3 tools/timeline.py "$f" > "$out/timeline.txt"
+export SHM_CSRC_SHA=$(cat shmgan_amd/csrc/*.hip shmgan_amd/csrc/*.h | sha256sum | cut -c1-16)
+mkdir -p "$out/distilled"
+python3 tools/timeline.py "$f" "$out/distilled/${tag}_timeline.json" > "$out/timeline.txt"
+cp "$out/distilled/${tag}_timeline.json" profiles/ 2>/dev/null || true
 # keep only the distilled timeline (the raw trace is tens of MB)
 python3 - "$f" "$out/trace_small.csv" <<'PY'
 import csv, sys
