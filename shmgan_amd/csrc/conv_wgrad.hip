@@ -1235,14 +1235,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
 // (23 items) + 2 x 32 dY rows (8 items): the same 31 items and 31 KiB per stage as the unit-stride form, with 18 MFMAs per wave.
 // Against wgrad_bf16_kernel<9> (nine shifted tiles through registers and ds_write, a barrier per 16 pixels, MFMA busy 0.18): 5.2
 // input pixels fetched per output pixel instead of 9, no VGPR staging, a barrier per 32 pixels.
-template <bool S2>
+// MODE 0: unit stride, stages of 4 x 16 pixels.  MODE 1: stride 2, stages of 2 x 16 output pixels (5 x 33 halo).  MODE 2: stride 2 on maps
+// whose output width is only a multiple of 8 (the discriminator's last layer, 16 x 16 -> 8 x 8): stages of 4 x 8 output pixels, 9 x 17 halo
+// stored as [9 even | 3 unused | 8 odd] = 20 LDS rows per halo row -- the same 180 rows; a K step is two output rows of eight pixels, so the
+// lane half hh of a fragment sits two halo rows (40 LDS rows) further down instead of eight plane entries further on.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHaloArgs a) {
-    constexpr int R = S2 ? 2 : 4;                       // output rows per stage
-    constexpr int PW = 16;
-    constexpr int HP = 20;                              // S1: LDS pitch of a halo row (18 valid); S2: pitch of the even run
-    constexpr int HRP = S2 ? 36 : 20;                   // LDS rows per halo row
-    constexpr int NHROW = S2 ? 5 : R + 2;               // halo rows
-    constexpr int NHR = NHROW * HRP;                    // 180 | 120
+    constexpr bool S2 = MODE != 0;
+    constexpr int R = MODE == 1 ? 2 : 4;                // output rows per stage
+    constexpr int PW = MODE == 2 ? 8 : 16;
+    constexpr int HP = MODE == 2 ? 12 : 20;             // S1: LDS pitch of a halo row (18 valid); S2: pitch of the even run
+    constexpr int HRP = MODE == 1 ? 36 : 20;            // LDS rows per halo row
+    constexpr int NHROW = S2 ? 2 * R + 1 : R + 2;       // halo rows: 6 | 5 | 9
+    constexpr int NHR = NHROW * HRP;                    // 120 | 180 | 180
+    constexpr int KSTEPS = R * PW / 16;                 // K steps (16 output pixels) per stage
     constexpr int NXI = (NHR + 7) / 8, NDT = R * PW / 8;       // x items 23 | 15, dY items per co tile 4 | 8
     constexpr int NIT = NXI + 2 * NDT;                  // 31 | 31
     static_assert(NIT == 31, "31 items per stage: waves 0-6 issue four, wave 7 three");
@@ -1301,7 +1307,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
                 const int t = row - r_ * HRP;
                 c_ = t < HP ? 2 * t : 2 * (t - HP) + 1;
                 ok = row < NHR && (t < HP ? t <= PW : true);
-                bits = (r_ == 4 ? 2u : 0u) | (c_ == 2 * PW ? 8u : 0u);
+                bits = (r_ == NHROW - 1 ? 2u : 0u) | (c_ == 2 * PW ? 8u : 0u);
             } else {
                 r_ = row / HP;
                 c_ = row - r_ * HP;
@@ -1314,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
             const int d = item - NXI, tile = d / NDT;
             const int q = 8 * (d - tile * NDT) + drow;
             const int coD = co0 + 64 * tile + sch * 8;
-            off0[j] = (unsigned)(((q >> 4) * wo + (q & 15)) * a.lddy + coD) * 2u;
+            off0[j] = (unsigned)(((q / PW) * wo + (q % PW)) * a.lddy + coD) * 2u;
             bits = (coD < a.cout && item < NIT) ? 0u : 16u;
         }
         bm |= bits << (5 * j);
@@ -1353,23 +1359,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
     // transposed-read addresses (elements), as in wgrad_halo_bf16_kernel: the lane supplies row fq [+4 for the second read] and four
     // channels of its 16-channel block.  S1: one address per kw (kw shifts the row, and with it bit 1 of the row index); S2: kw = 0 and
     // kw = 1 are 20 rows apart (same bit 1: an immediate), kw = 2 is one row on
-    const int fq = 8 * hh + ((lane & 15) >> 2);
+    const int fq = 8 * hh + ((lane & 15) >> 2);                          // pixel of the K step this lane supplies (dY rows are in pixel order)
+    const int fqx = (MODE == 2 ? 2 * HRP * hh : 8 * hh) + ((lane & 15) >> 2);     // ... and its row in the x image (every term but the last is 0 mod 4)
     const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     int fa[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int row = fq + (S2 ? (kw == 2 ? 1 : 0) : kw);
+        const int row = fqx + (S2 ? (kw == 2 ? 1 : 0) : kw);
         fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5)) + ((S2 && kw == 1) ? HP * 64 : 0);
     }
     const int fb = fq * 64 + ((ni * 32 + fcol) ^ (((fq >> 1) & 1) << 5)) + (XROWS + cot * DROWS) * 64;
     auto compute = [&](int stage) {
         const unsigned short* X = smem + stage * STAGE;
 #pragma unroll
-        for (int qr = 0; qr < R; ++qr) {
-            const bf16x8 bv = tr_frag(X + fb + qr * PW * 64);
+        for (int qr = 0; qr < KSTEPS; ++qr) {
+            const bf16x8 bv = tr_frag(X + fb + qr * 16 * 64);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int hrow = S2 ? 2 * qr + t / 3 : qr + t / 3;
+                const int hrow = MODE == 0 ? qr + t / 3 : MODE == 1 ? 2 * qr + t / 3 : 4 * qr + t / 3;
                 const bf16x8 av = tr_frag(X + fa[t % 3] + hrow * HRP * 64);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
             }
@@ -1591,7 +1598,9 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     // bf16, eight-wave block over 64 ci x 128 co (round 4): unit stride on maps whose height is a multiple of four, stride 2 on even maps
     // whose output width is a multiple of 16; "wgrad.bf16_wide" = 1 keeps the four-wave kernels
     const bool w8_s1 = halo_ok && hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2;
-    const bool w8_s2 = ksize == 3 && stride == 2 && pt == 0 && pl == 0 && hi % 2 == 0 && wi % 2 == 0 && wo % 16 == 0 && ho % 2 == 0 && !straddle && !no_halo && wv != 3;
+    const bool w8_s2_any = ksize == 3 && stride == 2 && pt == 0 && pl == 0 && hi % 2 == 0 && wi % 2 == 0 && !straddle && !no_halo && wv != 3;
+    const bool w8_s2_16 = w8_s2_any && wo % 16 == 0 && ho % 2 == 0, w8_s2_8 = w8_s2_any && !w8_s2_16 && wo % 8 == 0 && ho % 4 == 0;
+    const bool w8_s2 = w8_s2_16 || w8_s2_8;
     // "wgrad.bf16_wide": 0 automatic = stride 2 only, 1 never, 2 stride 2 only, 3 unit stride only, 4 both.  Unit stride is NOT the
     // automatic choice although the eight-wave block is 9-27 % faster than wgrad_halo_bf16_kernel<4> launch for launch (tools/bench_wgrad_bf16.py):
     // in the two-stream step the weight gradients run on the second stream beside the input-gradient chain, which is the critical path;
@@ -1601,7 +1610,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     // needs 30-43 % more time on every layer and is no lighter on a CU.
     const int wide = shm_tune(SHM_TUNE_WGRAD_BF16_WIDE);
     const bool wide_s1 = wide == 3 || wide == 4, wide_s2 = wide == 0 || wide == 2 || wide == 4;
-    if (dtype == SHM_BF16 && ((w8_s1 && wide_s1) || (w8_s2 && wide_s2)) && cout >= 128 && !want_nm) {
+    // (64 output channels -- the discriminator's 3-channel first layer -- stay on wgrad_bf16_kernel<9>: with the pair's second co tile empty
+    // the eight-wave block measured 296 us against 271)
+    const bool w8_take_s1 = w8_s1 && wide_s1 && cout >= 128, w8_take_s2 = w8_s2 && wide_s2 && cout >= 128 && !w8_take_s1;
+    if (dtype == SHM_BF16 && (w8_take_s1 || w8_take_s2) && !want_nm) {
         WgradHaloArgs hgs{};
         hgs.x = x;
         hgs.x2 = x2;
@@ -1616,8 +1628,9 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.cin_ld = cin_ld;
         hgs.cin = cin;
         hgs.cout = cout;
-        const int rows = w8_s1 ? 4 : 2;                 // output rows per stage
-        hgs.npatch = batch * (ho / rows) * (wo / 16);
+        const int w8_mode = w8_take_s1 ? 0 : w8_s2_16 ? 1 : 2;
+        const int rows = w8_mode == 1 ? 2 : 4, pw = w8_mode == 2 ? 8 : 16;       // output rows / columns per stage
+        hgs.npatch = batch * (ho / rows) * (wo / pw);
         // one block per CU (93 KiB of LDS): the block target counts 64 x 128 tiles, i.e. twice the splits of the four-wave kernel's choice
         int nsh;
         {
@@ -1638,16 +1651,19 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.dybytes = a.dybytes;
         ns = nsh;
         constexpr unsigned kLds8 = 3u * 248u * 128u;    // 93 KiB
-        static const hipError_t attr_a = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
-        static const hipError_t attr_b = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
-        SHM_REQUIRE(attr_a == hipSuccess && attr_b == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 93 KiB of LDS: %s",
-                    hipGetErrorString(attr_a != hipSuccess ? attr_a : attr_b));
+        static const hipError_t attr_a = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+        static const hipError_t attr_b = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+        static const hipError_t attr_c = hipFuncSetAttribute((const void*)wgrad_halo8_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+        SHM_REQUIRE(attr_a == hipSuccess && attr_b == hipSuccess && attr_c == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 93 KiB of LDS: %s",
+                    hipGetErrorString(attr_a != hipSuccess ? attr_a : attr_b != hipSuccess ? attr_b : attr_c));
         const dim3 grid8(shm_cdiv(cin, 64), shm_cdiv(cout, 128), nsh);
-        if (w8_s1)
-            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<false>), grid8, dim3(512), kLds8, st, hgs);
+        if (w8_mode == 0)
+            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<0>), grid8, dim3(512), kLds8, st, hgs);
+        else if (w8_mode == 1)
+            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<1>), grid8, dim3(512), kLds8, st, hgs);
         else
-            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<true>), grid8, dim3(512), kLds8, st, hgs);
-        shm_set_last_kernel("wgrad_halo8_bf16_kernel<%s>", w8_s1 ? "false" : "true");
+            hipLaunchKernelGGL((wgrad_halo8_bf16_kernel<2>), grid8, dim3(512), kLds8, st, hgs);
+        shm_set_last_kernel("wgrad_halo8_bf16_kernel<%d>", w8_mode);
     } else if (dtype == SHM_BF16 && halo_ok) {
         WgradHaloArgs hgs{};
         hgs.x = x;

@@ -244,7 +244,7 @@ def test_conv_entry_points_are_bitwise_reproducible(dt):
         torch.cuda.synchronize()
         if ref is None:
             ref = (y, dx, dw, dw2)
-            assert (k1, k2) == (("wgrad_halo8_bf16_kernel<false>", "wgrad_halo8_bf16_kernel<true>") if dt == "bf16" else ("wgrad_halo_kernel", "wgrad_halo_kernel<0, true>")), (k1, k2)
+            assert (k1, k2) == (("wgrad_halo8_bf16_kernel<0>", "wgrad_halo8_bf16_kernel<1>") if dt == "bf16" else ("wgrad_halo_kernel", "wgrad_halo_kernel<0, true>")), (k1, k2)
         else:
             assert torch.equal(y, ref[0]) and torch.equal(dx, ref[1]) and torch.equal(dw, ref[2]) and torch.equal(dw2, ref[3]), r
     ops.set_tuning("reset", 0)

@@ -471,7 +471,7 @@ def test_wgrad_forced_variant(dt, wv, expect, n, h, cin, cout, blocks):
         elif wv == 2:
             # bf16 with >= 128 output channels on a map whose height is a multiple of four: the eight-wave 64 x 128 block (round 4)
             wide = dt == "bf16" and cout >= 128 and rows == 0
-            assert k == ("wgrad_halo8_bf16_kernel<false>" if wide else "wgrad_halo_kernel" if dt == "f32" else f"wgrad_halo_bf16_kernel<{rows or 4}>"), k
+            assert k == ("wgrad_halo8_bf16_kernel<0>" if wide else "wgrad_halo_kernel" if dt == "f32" else f"wgrad_halo_bf16_kernel<{rows or 4}>"), k
         assert rel_l2(host(dw), ref.numpy()) < (1e-4 if dt == "bf16" else 1e-5), (k, rel_l2(host(dw), ref.numpy()))
         if dt == "bf16" and wv == 2 and rows == 0 and cout >= 128:       # ... and the four-wave kernel on the same shape ("wgrad.bf16_wide" = 1)
             ops.set_tuning("wgrad.bf16_wide", 1)
@@ -523,6 +523,8 @@ def test_wgrad_stride2_halo(n, h, cin, cout, c1, blocks):
     (2, 64, 128, 128, 64, 0),      # Concatenate split on a tile boundary
     (3, 32, 96, 192, 0, 5),        # ragged ci (96) and co (192 = 128 + 64) tiles, odd batch, odd split count
     (5, 32, 64, 128, 0, 3),        # blocks that cross image boundaries
+    (3, 16, 128, 256, 0, 0),       # 8-column output map: stages of 4 x 8 output pixels (wgrad_halo8_bf16_kernel<2>), one patch per image
+    (2, 48, 64, 128, 0, 5),        # 24 x 24 outputs: three 8-column patch columns, six patch rows
 ])
 def test_wgrad_stride2_bf16_wide(n, h, cin, cout, c1, blocks):
     ops = _ops()
@@ -543,7 +545,7 @@ def test_wgrad_stride2_bf16_wide(n, h, cin, cout, c1, blocks):
         dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
         ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
         k = ops.last_kernel()
-        assert k == ("wgrad_halo8_bf16_kernel<true>" if wide == 0 else "wgrad_bf16_kernel<9, false>"), k
+        assert k == (f"wgrad_halo8_bf16_kernel<{1 if (h // 2) % 16 == 0 else 2}>" if wide == 0 else "wgrad_bf16_kernel<9, false>"), k
         got[wide] = host(dw)
         assert rel_l2(got[wide], ref.numpy()) < 1e-4, (k, rel_l2(got[wide], ref.numpy()))
         ops.conv2d_wgrad(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, dyd, cout, dw, n, h, h, cin, cin, cout, 3, 2, 1, ws)     # accumulate
@@ -553,10 +555,10 @@ def test_wgrad_stride2_bf16_wide(n, h, cin, cout, c1, blocks):
 
 
 def test_wgrad_stride2_bf16_wide_leaves_what_it_cannot_tile():
-    """an 8-column output map, 64 output channels and "wgrad.variant" 3 stay on the generic bf16 kernel"""
+    """a 4-column output map, 64 output channels and "wgrad.variant" 3 stay on the generic bf16 kernel"""
     ops = _ops()
     rng = np.random.default_rng(42)
-    for n, h, cin, cout, wv in ((2, 16, 64, 128, 0), (2, 32, 64, 64, 0), (2, 32, 64, 128, 3)):
+    for n, h, cin, cout, wv in ((2, 8, 64, 128, 0), (2, 32, 64, 64, 0), (2, 32, 64, 128, 3)):
         x = rng.standard_normal((n, h, h, cin))
         dy = rng.standard_normal((n, h // 2, h // 2, cout))
         wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
