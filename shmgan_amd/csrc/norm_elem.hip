@@ -1843,6 +1843,124 @@ __global__ __launch_bounds__(256) void dgrad_sum1_tiled_kernel(const T* __restri
     }
 }
 
+// MFMA form of the tiled kernel's phase A (round 4).  P[pixel][tap] = sum_k sum_c dz_k[pixel][c] * weff_k[tap][c] is a GEMM with M = the dz pixels of
+// the tile (<= 18 x 18), N = 9 taps (16 MFMA columns) and K = nk * c: the phase above spends 36 FMAs and 36 shuffle-adds per lane and pixel on it
+// (150 us in bf16 / 215 us in fp32 for a launch that moves 335 / 671 MB: vector bound, 2.2-3.1 TB/s).  Here a wave takes 16 pixels per step;
+// a lane's 16-byte global load IS its A fragment (bf16: eight channels = one v_mfma_f32_16x16x32_bf16 K block; fp32: four channels = four
+// v_mfma_f32_16x16x4_f32 with the channel permutation of tapgemm_wreg_f32_kernel), the weights sit in registers as the B operand -- in bf16 split
+// into a high and a low bf16 part (two MFMAs), which keeps the fp32 weights' accuracy (2^-17) -- and the accumulator's four pixels of tap l15 go
+// straight into the P image.  Phase B is unchanged.  c % 32 == 0 (bf16) / c % 16 == 0 (fp32), nk * c <= 320.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T, int NKC>          // NKC = nk * c / (sizeof(T) == 2 ? 32 : 16): K blocks, compile time so that the weights stay in registers
+__global__ __launch_bounds__(256) void dgrad_sum1_mfma_kernel(const T* __restrict__ dz, int lddz, const float* __restrict__ weff, float* __restrict__ out,
+                                                              int nk, int batch, int hi, int wi, int ho, int wo, int c, int stride, int pt, int pl,
+                                                              int accumulate) {
+    constexpr int TO = 16, RMAX = TO + 2, KB = sizeof(T) == 2 ? 32 : 16;
+    __shared__ float P[9][RMAX * RMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int tiles_x = (wi + TO - 1) / TO, tiles_y = (hi + TO - 1) / TO;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TO, x0 = (tr % tiles_x) * TO;
+    auto fdiv = [](int a, int d) { return a >= 0 ? a / d : -((-a + d - 1) / d); };
+    const int oy_lo = fdiv(y0 + pt - 2, stride), oy_hi = fdiv(y0 + TO - 1 + pt, stride);
+    const int ox_lo = fdiv(x0 + pl - 2, stride), ox_hi = fdiv(x0 + TO - 1 + pl, stride);
+    const int R = oy_hi - oy_lo + 1, Cn = ox_hi - ox_lo + 1;             // <= 18 each
+    const int kpc = c / KB;                                               // K blocks per dz tensor
+    // ---- weights -> registers: B[k][n = tap l15]; taps 9..15 are zero columns
+    f32x4 wb[NKC];                       // fp32: four channels 4 lq + e; bf16: the high parts of eight channels 8 lq ..
+    [[maybe_unused]] f32x4 wlo[sizeof(T) == 2 ? NKC : 1];
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+        const int k = j / kpc, cb = (j - k * kpc) * KB;
+        if constexpr (sizeof(T) == 2) {
+            unsigned hi4[4] = {0, 0, 0, 0}, lo4[4] = {0, 0, 0, 0};
+            if (l15 < 9) {
+                const float* wp = weff + ((size_t)k * 9 + l15) * c + cb + lq * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float w = wp[e];
+                    const bf16_t h = (bf16_t)w;
+                    const bf16_t l = (bf16_t)(w - (float)h);
+                    hi4[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, h) << (16 * (e & 1));
+                    lo4[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, l) << (16 * (e & 1));
+                }
+            }
+            wb[j] = __builtin_bit_cast(f32x4, u32x4_t{hi4[0], hi4[1], hi4[2], hi4[3]});
+            wlo[j] = __builtin_bit_cast(f32x4, u32x4_t{lo4[0], lo4[1], lo4[2], lo4[3]});
+        } else {
+            wb[j] = l15 < 9 ? *(const f32x4*)(weff + ((size_t)k * 9 + l15) * c + cb + lq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- phase A: 16 dz pixels per wave and step
+    const int npx = R * Cn;
+    for (int g = wave; g * 16 < npx; g += 4) {
+        const int j = g * 16 + l15;
+        const int r = j / Cn, q = j - r * Cn;
+        const int oy = oy_lo + r, ox = ox_lo + q;
+        const bool ok = j < npx && (unsigned)oy < (unsigned)ho && (unsigned)ox < (unsigned)wo;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // every lane loads (lanes without a pixel read pixel 0 of their tensor and are zeroed afterwards): a load under a per-lane
+        // condition inside the unrolled loop would be a branch and a full vmcnt drain per K block
+        const size_t pixoff = ok ? ((size_t)oy * wo + ox) * lddz : 0;
+        u32x4_t araw[NKC];
+#pragma unroll
+        for (int jj = 0; jj < NKC; ++jj) {
+            const int k = jj / kpc, cb = (jj - k * kpc) * KB;
+            araw[jj] = *(const u32x4_t*)(dz + (size_t)(k * batch + b) * ho * wo * lddz + pixoff + cb + lq * (sizeof(T) == 2 ? 8 : 4));
+        }
+#pragma unroll
+        for (int jj = 0; jj < NKC; ++jj) {
+            u32x4_t a = araw[jj];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = ok ? a[e] : 0u;
+            if constexpr (sizeof(T) == 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, wb[jj]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, wlo[jj]), acc, 0, 0, 0);
+            } else {
+                const f32x4 af = __builtin_bit_cast(f32x4, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wb[jj][e], acc, 0, 0, 0);
+            }
+        }
+        // accumulator register e = pixel 16 g + 4 lq + e, column l15 = tap
+        if (l15 < 9) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jp = g * 16 + 4 * lq + e;
+                if (jp < npx) {
+                    const int rp = jp / Cn;
+                    P[l15][rp * RMAX + (jp - rp * Cn)] = acc[e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: one output pixel per thread (as in dgrad_sum1_tiled_kernel)
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < hi && x < wi) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ny = y + pt - kh;
+            if (ny < 0 || (stride == 2 && (ny & 1))) continue;
+            const int oy = stride == 2 ? ny >> 1 : ny;
+            if (oy >= ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int nx = x + pl - kw;
+                if (nx < 0 || (stride == 2 && (nx & 1))) continue;
+                const int ox = stride == 2 ? nx >> 1 : nx;
+                if (ox >= wo) continue;
+                v += P[kh * 3 + kw][(oy - oy_lo) * RMAX + (ox - ox_lo)];
+            }
+        }
+        const size_t qo = ((size_t)b * hi + y) * wi + x;
+        out[qo] = accumulate ? out[qo] + v : v;
+    }
+}
+
 extern "C" int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* weff, float* out, int nk, int batch, int hi, int wi, int c, int stride,
                                       int accumulate, int dtype, void* stream) {
     SHM_REQUIRE(dz && weff && out, SHM_E_SHAPE, "shm_conv3x3_dgrad_sum1: null pointer");
@@ -1854,6 +1972,30 @@ extern "C" int shm_conv3x3_dgrad_sum1(const void* dz, int lddz, const float* wef
     const size_t npx = (size_t)batch * hi * wi;
     if (npx == 0 || nk == 0) return SHM_OK;
     const int PP = 256 / (c / 4);
+    {                                    // MFMA phase A: the step's shapes (nk = 1 or 5 tensors of 64 channels); K blocks are a template parameter
+        const int kb = dtype == SHM_F32 ? 16 : 32;
+        const int nkc = c % kb == 0 ? nk * c / kb : 0;
+        const int tiles = shm_cdiv(hi, 16) * shm_cdiv(wi, 16);
+        const dim3 grid(batch * tiles);
+#define SHM_SUM1_MFMA(T_, NKC_)                                                                                                                           \
+    hipLaunchKernelGGL((dgrad_sum1_mfma_kernel<T_, NKC_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)dz, lddz, weff, out, nk, batch, hi, wi, ho, wo, c, \
+                       stride, pt, pl, accumulate)
+        bool done = true;
+        if (dtype == SHM_F32 && nkc == 4) SHM_SUM1_MFMA(float, 4);
+        else if (dtype == SHM_F32 && nkc == 20) SHM_SUM1_MFMA(float, 20);
+        else if (dtype == SHM_F32 && nkc == 1) SHM_SUM1_MFMA(float, 1);
+        else if (dtype == SHM_F32 && nkc == 5) SHM_SUM1_MFMA(float, 5);
+        else if (dtype == SHM_BF16 && nkc == 2) SHM_SUM1_MFMA(bf16_t, 2);
+        else if (dtype == SHM_BF16 && nkc == 10) SHM_SUM1_MFMA(bf16_t, 10);
+        else if (dtype == SHM_BF16 && nkc == 1) SHM_SUM1_MFMA(bf16_t, 1);
+        else if (dtype == SHM_BF16 && nkc == 5) SHM_SUM1_MFMA(bf16_t, 5);
+        else done = false;
+#undef SHM_SUM1_MFMA
+        if (done) {
+            SHM_LAUNCH_CHECK("shm_conv3x3_dgrad_sum1");
+            return SHM_OK;
+        }
+    }
     if (nk * c <= 5 * 64) {              // weights fit the tiled kernel's LDS staging
         const int tiles = shm_cdiv(hi, 16) * shm_cdiv(wi, 16);
         SHM_DISPATCH(dtype, "shm_conv3x3_dgrad_sum1",
