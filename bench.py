@@ -271,7 +271,7 @@ def main():
                              tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in ps.items()]
                 rows.sort(key=lambda r: -r["ms_per_step"])
                 Path(args.per_shape).write_text(json.dumps(rows, indent=1))
-        if not args.no_kernel_timer:
+        if not args.no_kernel_timer and world == 1:      # a single-GPU property; at N > 1 the other ranks would wait behind it
             out["north_star_block"] = north_star_block(torch, ops, dev)
         if not args.no_cpu_baseline and world == 1:         # reported at N=1 only: the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)

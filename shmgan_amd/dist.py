@@ -20,6 +20,15 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def exchange_active():
+    """Does train_step exchange gradients?  With more than one rank always; with a ONE-rank process group only under SHM_DP_FORCE=1 --
+    the rehearsal a 1-GPU box allows: every bucket goes through RCCL's all-reduce on the side stream, behind the same events, as it
+    would on 8 GPUs (the sum over one rank changes nothing), so the nccl branch of this module runs under test before the first
+    multi-GPU job does (tests/test_dist_gpu.py::test_one_rank_rccl_exchange...)."""
+    w = world_size()
+    return w > 1 or (w == 1 and dist.is_available() and dist.is_initialized() and os.environ.get("SHM_DP_FORCE") == "1")
+
+
 class GradExchangeError(RuntimeError):
     """A gradient collective failed or timed out (a peer rank died or hung).  The step cannot be completed: the process
     must end with a non-zero exit code so that the launcher tears the job down -- never retried, never re-exec'ed."""
@@ -57,7 +66,7 @@ class GradReducer:
     def allreduce_async(self, flat, after=None, tag="g"):
         """`after`: optional extra event (e.g. the wgrad lane) the collective must also wait for.  tag: bucket family ("d" / "g")
         for the probe."""
-        if world_size() == 1:
+        if not exchange_active():
             return None
         if not flat.is_cuda:
             self._reduce(flat)

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist import GradReducer, world_size
+from .dist import GradReducer, exchange_active, world_size
 from .model import Arena, Discriminator, Generator, WgradLane, pad_channels
 from .specseg import SpecSeg
 
@@ -397,7 +397,7 @@ class ShmGANwithSSpecSeg:
         update_g = self.epoch >= self.train_G_after
         # no collective for a gradient nobody applies (it would also still be in flight when the next step
         # zeroes the bucket)
-        reduce_g = world > 1 and (update_g or not apply)
+        reduce_g = exchange_active() and (update_g or not apply)
         # The G(1) backward is the last pass that touches the generator's weight gradients, and it finishes the layers last
         # to first: each stage's slice of the flat gradient is all-reduced as soon as the weight gradient of its lowest
         # layer has been issued on the wgrad lane (the collective waits for that lane event on the reducer stream), under
@@ -434,7 +434,7 @@ class ShmGANwithSSpecSeg:
                 self._reducer.wait_on(ev_g)
                 self.optimizer_G.apply(G.P, 1.0 / world)
                 G.weights_dirty = True
-        elif world > 1:
+        elif exchange_active():
             for ev in (ev_d, ev_g):
                 self._reducer.wait_on(ev)
 

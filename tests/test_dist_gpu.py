@@ -149,3 +149,47 @@ def test_ranks_restore_the_checkpoint_rank0_chose_or_fail_together(tmp_path, bre
             status, path, w, it, dc = got[rank]
             assert status == "ok" and path == p1 and it == 1 and dc == 1
             assert np.array_equal(w, w1)
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SHM_DP_FORCE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    from shmgan_amd.dist import exchange_active, init_process_group
+    init_process_group("nccl", device=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and exchange_active()
+    from shmgan_amd import ShmGANwithSSpecSeg
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=2).build()
+    m._reducer.probe = []
+    inp, sf = st.make_inputs(2, S), st.style_factor_intended(S)
+    for step in (1, 2):
+        m.train_step(*inp, draws=st.make_draws(step, 2, S, F), style_factor=sf, apply=True, next_batch=inp)
+    torch.cuda.synchronize()
+    comm = m._reducer.comm_summary(2)
+    q.put((m.G.P.flat.cpu().numpy(), m.D.P.flat.cpu().numpy(), comm, m._reducer.stream is not None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_exchange_runs_the_nccl_branch_and_changes_nothing():
+    """The nccl (= RCCL) branch of shmgan_amd.dist had never executed: RCCL refuses two ranks on one device and the test boxes have one
+    GPU.  A ONE-rank RCCL group under SHM_DP_FORCE=1 sends every gradient bucket of two optimizer steps through RCCL's all-reduce on
+    the reducer stream, behind the weight-gradient lane's events, with the comm probe on, as an 8-GPU job would -- and, the sum over one
+    rank being the identity, must leave exactly the weights of the same two steps without a process group."""
+    from shmgan_amd import ShmGANwithSSpecSeg
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    m = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=2).build()
+    inp, sf = st.make_inputs(2, S), st.style_factor_intended(S)
+    for step in (1, 2):
+        m.train_step(*inp, draws=st.make_draws(step, 2, S, F), style_factor=sf, apply=True, next_batch=inp)
+    torch.cuda.synchronize()
+    wG, wD, comm, side = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert side and comm["collectives"] == 6 and comm["bytes"] == 4 * (m.G.P.n + m.D.P.n), comm
+    assert comm["d_bucket_ms"] > 0 and comm["g_buckets_ms"] > 0 and comm["exposed_ms"] >= 0
+    # the step's only run-to-run variation is the order of float64 statistics atomics (test_step_is_reproducible_run_to_run: 1e-6)
+    assert rel_l2(wG, host(m.G.P.flat)) < 1e-6 and rel_l2(wD, host(m.D.P.flat)) < 1e-6
