@@ -769,7 +769,9 @@ class ShmGANwithSSpecSeg:
 
     @property
     def gen_rgb_output(self):
-        """SHM.py:548-550: yuv_to_rgb(gen_YCbCr * mean(stddev_arr) * 255) (display only)."""
+        """SHM.py:548-550: yuv_to_rgb(gen_YCbCr * mean(stddev_arr) * 255) (display only).  Plain torch tensor arithmetic on purpose: like
+        `custom_per_image_standardization` and `gram_matrix` this is an API-parity helper OFF the hot path (nothing in `train_step` / `infer`
+        calls it) -- the three are the only torch compute in the package; the step itself runs on the library's kernels alone."""
         L = self._last
         avg = torch.stack([s.mean() for s in self.stddev_arr]).mean()
         yuv = torch.cat([self.gen_Y, L.cbcr], dim=3) * avg * 255.0
