@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SHM_LIB_PATH"]) if os.environ.get("SHM_LIB_PATH") else _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_rgb.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
 F32, BF16 = 0, 1                 # SHM_F32 / SHM_BF16 of include/shmgan_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-local-typedef"]
@@ -113,7 +113,7 @@ def build(force=False, verbose=False, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
     shared = [CSRC / "common.h", CSRC / "ablate.h", HEADER]
-    deps = srcs + shared
+    deps = srcs + shared + [Path(__file__)]           # (this file: the source list)
     if not force and LIB_PATH.exists():
         newest = max(p.stat().st_mtime for p in deps)
         if LIB_PATH.stat().st_mtime >= newest:

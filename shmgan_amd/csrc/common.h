@@ -15,6 +15,13 @@ typedef __bf16 bf16_t;            // activation element type of the bf16 path (S
 void shm_set_error(const char* fmt, ...);
 void shm_set_last_kernel(const char* fmt, ...);        // symbol of the MFMA kernel a convolution entry point chose
 
+// conv_rgb.hip: the 3-channel stride-2 first layer on the compact image layout (one 16-byte chunk per pixel).  1 = launched, 0 = not that
+// shape (the caller goes on to its generic kernels), < 0 = SHM_E_*.
+int shm_rgb_s2_fwd_launch(const void* x, int ldx, const void* wk, int K, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cout, float slope,
+                          double* stats, int stats_slots, unsigned stats_stride, size_t xbytes, size_t ybytes, int dtype, hipStream_t st);
+int shm_rgb_s2_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* part, size_t ws_bytes, int batch, int hi, int wi, int cin, int cout,
+                            size_t xbytes, size_t dybytes, int dtype, int* nsplit_out, hipStream_t st);
+
 // Dispatch knobs behind shm_set_tuning()/shm_get_tuning() (include/shmgan_hip.h lists the keys).  Process-wide
 // atomics read at every launch; the initial value comes from the environment variable named in the table of
 // norm_elem.hip (so tools/ablate_conv.py keeps working), -1/0 = the built-in choice.
@@ -171,7 +178,12 @@ __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.
 // LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions (v_mul, v_max): fmaxf costs a third -- hipcc quiets a possible signalling NaN in u first
 // (v_max u, u, u), which for an MFMA result it cannot rule out; the instruction itself already does that in the kernels' IEEE mode.  Same bits as shm_lrelu for every
 // finite u; a NaN stays a NaN (both operands are NaN then), so a diverged activation still shows in the statistics and the losses (round 3 used
-// v_med3(u, u * slope, FLT_MAX), which turned a NaN into FLT_MAX: advisor finding).  A plain VALU instruction whose inputs hipcc sees: no memory operation, no hazard of its own.
+// v_med3(u, u * slope, FLT_MAX), which turned a NaN into FLT_MAX: advisor finding).
+// HAZARD (round 4): a 16- or 12-byte store reads its data VGPRs after it has issued, and a VALU write into one of them must stay two wait states
+// away.  hipcc spaces that out itself, except after a BUFFER store whose soffset is an SGPR (its table exempts those; the MI355X does not): there this
+// helper's v_max of the NEXT tile landed in a register of the tile just stored, and ~4e-4 of conv3x3s2_rgb_fwd_kernel's values of that register went out
+// wrong, only under load.  Keep the offsets of wide buffer stores in the immediate field; tools/check_isa_hazards.py scans the built library for
+// the pattern (tests/test_abi.py runs it).
 __device__ __forceinline__ float shm_lrelu_max(float u, float slope) {
     const float m = u * slope;
     float r;

@@ -3051,6 +3051,16 @@ static int launch_tapgemm(TapGemmArgs& a, int batch, int nphase, int dtype, hipS
         a.ybytes = (yb < lim && !flat) ? (unsigned)yb : 0u;
         a.y2bytes = (y2b < lim && !flat) ? (unsigned)y2b : 0u;
     }
+    // the 3-channel stride-2 first layer of the discriminator on the compact image layout (conv_rgb.hip); a forced tapgemm.variant keeps
+    // the generic kernels (which read K channels per tap from the 16-byte pixels: the neighbours' values times the zero weight columns)
+    if (nphase == 1 && a.is == 2 && a.os == 1 && a.ph[0].ntaps == 9 && a.ph[0].dh[0] == 0 && a.ph[0].dw[0] == 0 && !a.x2 && !a.y2 && !a.gred[0] && !a.gred[1] &&
+        !a.nt && !g_norm.query && a.ldx * esz == 16 && a.K * esz == 64 && a.ybytes != 0 && dtype != SHM_BF16_GF32 &&
+        shm_tune(SHM_TUNE_TAPGEMM_VARIANT) == SHM_TG_AUTO) {
+        const int r = shm_rgb_s2_fwd_launch(a.x, a.ldx, a.w, a.K, a.bias, a.y, a.ldy, batch, a.hi, a.wi, a.nout, a.slope, a.stats, a.stats_slots, a.stats_stride,
+                                            a.xbytes, a.ybytes, dtype, st);
+        if (r < 0) return r;
+        if (r == 1) return SHM_OK;
+    }
     int rc;
     if (dtype == SHM_BF16)
         rc = launch_tapgemm_t<bf16_t, bf16_t>(a, batch, nphase, st, who);

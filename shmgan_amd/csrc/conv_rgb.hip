@@ -1,0 +1,417 @@
+// The discriminator's first layer -- Conv2D(3x3, stride 2, 'same', no bias) + LeakyReLU on a 3-channel image, Keras `Conv_LReLU_IN`
+// (/root/reference/ShmGANwithSSpecSeg.py:353, 386-389) -- and its weight gradient, on a COMPACT image layout: one 16-byte chunk per pixel
+// (float32: r, g, b, 0; bfloat16: r, g, b and five zeros) instead of the 64-byte MFMA staging row the tap-GEMM kernels read.
+//
+// Why (round 4): through the generic kernels the layer multiplied 3 real channels inside a 16- / 32-channel K block (17-19 TFLOP/s on the
+// MFMA, 290-320 us per step and dtype) and the padded image tensor was 403 MB written by the colour kernels and read twice (forward, weight
+// gradient) for 38-75 MB of pixels.  Both products are tiny (5.4 GFLOP at 96 images of 256 x 256): what they need is to stream.
+//
+// Forward: (tap, channel) pairs packed into the MFMA's K -- float32: nine v_mfma_f32_16x16x4_f32 per 16 pixels and 16 output channels, one
+// tap (4 channels) each; bfloat16: three v_mfma_f32_16x16x32_bf16, four taps (8 channels each) at a time.  Transposed product (weights = A
+// operand): a lane ends up with four consecutive output channels of one pixel -> 16-byte (fp32) / 8-byte (bf16) stores.  The image is read
+// straight from global memory into the B operand (a lane's 4-byte / 16-byte load is its fragment), next group prefetched; InstanceNorm sums
+// are carried per lane in float over the wave's run of pixel groups and flushed per image.
+// Weight gradient: pixels are the contraction index; float32 MFMA for both dtypes (bf16 values are exact in fp32): rows = the 27 (tap, ci)
+// pairs in two 16-row tiles, columns = output channels in the permutation co = 4 * lane + tile so that a lane's 16-byte dz load feeds the four
+// column tiles; split over blocks into the slabs shm_conv2d_wgrad_reduce sums.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct RgbFwdArgs {
+    const void* x;
+    const void* wk;          // [9][cout][K] (the layer's K-contiguous weight copy; K = 16 fp32 / 32 bf16, channels >= 3 are zero)
+    const float* bias;       // [cout] or null
+    void* y;
+    int ldx, K, ldy, batch, hi, wi, ho, wo, cout;
+    float slope;
+    double* stats;           // optional [slot][batch][cout][2]
+    int stats_slots;
+    unsigned stats_stride;
+    unsigned xbytes, ybytes;
+    int groups_per_wave;
+};
+
+__device__ __forceinline__ float rgb_row16_sum(float v) {           // sum over the 16 lanes of a DPP row, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));      // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));      // row_mirror
+    return v;
+}
+
+// NT = cout / 16 column tiles (1..4)
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs a) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int NM = ESZ == 4 ? 9 : 3;                 // K blocks: 9 taps x 4 channels | 3 x (4 taps x 8 channels)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int gpr = a.wo >> 4, gpi = a.ho * gpr, total = a.batch * gpi;
+    const int g0 = (blockIdx.x * 4 + wave) * a.groups_per_wave, g1 = min(total, g0 + a.groups_per_wave);
+    if (g0 >= g1) return;
+
+    // ---- weights -> registers (A operand: row = output channel 16 j + l15, k = lq of the K block)
+    f32x4 wa4[ESZ == 2 ? NM * NT : 1];                   // bf16: eight channels of tap 4 m + lq
+    float wa1[ESZ == 4 ? NM * NT : 1];                   // fp32: channel lq of tap m
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = 16 * j + l15;
+            if constexpr (ESZ == 4) {
+                wa1[m * NT + j] = ((const float*)a.wk)[((size_t)m * a.cout + co) * a.K + lq];
+            } else {
+                const int tap = 4 * m + lq;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (tap < 9) v = *(const f32x4*)((const bf16_t*)a.wk + ((size_t)tap * a.cout + co) * a.K);
+                wa4[m * NT + j] = v;
+            }
+        }
+    f32x4 bias4[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[j][r] = a.bias ? a.bias[16 * j + 4 * lq + r] : 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+    const unsigned pixb = (unsigned)a.ldx * ESZ;         // 16 bytes
+
+    // image fragment of group g: fp32 -- nine floats (tap m, channel lq of pixel l15); bf16 -- three 16-byte chunks (tap 4 m + lq)
+    auto load_x = [&](int g, u32x4 (&xb)[ESZ == 2 ? NM : 1], float (&xf)[ESZ == 4 ? NM : 1]) {
+        const int img = g / gpi, rem = g - img * gpi;
+        const int oh = rem / gpr, ow = ((rem - oh * gpr) << 4) + l15;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int tap = ESZ == 4 ? m : 4 * m + lq;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int iy = 2 * oh + kh, ix = 2 * ow + kw;                 // SAME padding of an even map: nothing before, one row / column after
+            const bool ok = tap < 9 && iy < a.hi && ix < a.wi;
+            const unsigned off = ok ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (ESZ == 4 ? (unsigned)lq * 4u : 0u) : 0xffffffffu;
+            if constexpr (ESZ == 4) xf[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)off, 0, 0));
+            else xb[m] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
+        }
+    };
+
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
+    int simg = g0 / gpi;
+    auto flush = [&](int img) {
+        if (!a.stats) return;
+        double* base = a.stats + (size_t)((blockIdx.x * 4 + wave) % a.stats_slots) * a.stats_stride + ((size_t)img * a.cout + 4 * lq) * 2;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float mine = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t1 = rgb_row16_sum(s1[j][r]), t2 = rgb_row16_sum(s2[j][r]);
+                mine = l15 == 2 * r ? t1 : l15 == 2 * r + 1 ? t2 : mine;
+                s1[j][r] = s2[j][r] = 0.f;
+            }
+            if (l15 < 8) atomicAdd(base + (size_t)16 * j * 2 + l15, (double)mine);       // channels 16 j + 4 lq + (l15 >> 1), sum / sum of squares
+        }
+    };
+
+    u32x4 xb[ESZ == 2 ? NM : 1], nb[ESZ == 2 ? NM : 1];
+    float xf[ESZ == 4 ? NM : 1], nf[ESZ == 4 ? NM : 1];
+    load_x(g0, xb, xf);
+    for (int g = g0; g < g1; ++g) {
+        if (g + 1 < g1) load_x(g + 1, nb, nf);           // next group's fragment under this group's MFMAs and stores
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = bias4[j];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (ESZ == 4)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[m * NT + j], xf[m], acc[j], 0, 0, 0);
+                else
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa4[m * NT + j]), __builtin_bit_cast(bf16x8, xb[m]), acc[j], 0, 0, 0);
+            }
+        const int img = g / gpi, rem = g - img * gpi;
+        if (img != simg) {
+            flush(simg);
+            simg = img;
+        }
+        const int oh = rem / gpr, ow = ((rem - oh * gpr) << 4) + l15;
+        const unsigned yo = (unsigned)((img * a.ho + oh) * a.wo + ow) * (unsigned)a.ldy * ESZ + (unsigned)(4 * lq) * ESZ;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (ESZ == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = shm_lrelu_max(acc[j][r], a.slope);
+                    s1[j][r] += v[r];
+                    s2[j][r] = __builtin_fmaf(v[r], v[r], s2[j][r]);
+                }
+                // (the tile's offset in the instruction's immediate field, NOT as an SGPR soffset: see shm_lrelu_max in common.h)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
+            } else {
+                unsigned pk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float u0 = shm_lrelu_max(acc[j][2 * h], a.slope), u1 = shm_lrelu_max(acc[j][2 * h + 1], a.slope);
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[h]) : "v"(u0), "v"(u1));
+                    const float v0 = __uint_as_float(pk[h] << 16), v1 = __uint_as_float(pk[h] & 0xffff0000u);       // the values as stored
+                    s1[j][2 * h] += v0;
+                    s2[j][2 * h] = __builtin_fmaf(v0, v0, s2[j][2 * h]);
+                    s1[j][2 * h + 1] += v1;
+                    s2[j][2 * h + 1] = __builtin_fmaf(v1, v1, s2[j][2 * h + 1]);
+                }
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if constexpr (ESZ == 4) xf[m] = nf[m];
+            else xb[m] = nb[m];
+        }
+    }
+    flush(simg);
+}
+
+// returns 1 = launched, 0 = this shape is not this kernel's (the caller goes on to the generic path), < 0 = error
+int shm_rgb_s2_fwd_launch(const void* x, int ldx, const void* wk, int K, const float* bias, void* y, int ldy, int batch, int hi, int wi, int cout, float slope,
+                          double* stats, int stats_slots, unsigned stats_stride, size_t xbytes, size_t ybytes, int dtype, hipStream_t st) {
+    const int esz = dtype == SHM_BF16 ? 2 : 4;
+    if (dtype != SHM_F32 && dtype != SHM_BF16) return 0;
+    if (ldx * esz != 16 || K * esz != 64 || hi % 2 || wi % 2 || (wi / 2) % 16 || cout % 16 || cout > 64 || cout < 16) return 0;
+    if (ldy % (16 / esz) || ((size_t)y & 15) || ((size_t)x & 15) || ((size_t)wk & 15)) return 0;
+    if (!(slope >= 0.f && slope <= 1.f) || xbytes >= 0xfffffff0ull || ybytes >= 0xfffffff0ull) return 0;
+    if (batch == 0) return 1;
+    RgbFwdArgs a{};
+    a.x = x;
+    a.wk = wk;
+    a.bias = bias;
+    a.y = y;
+    a.ldx = ldx;
+    a.K = K;
+    a.ldy = ldy;
+    a.batch = batch;
+    a.hi = hi;
+    a.wi = wi;
+    a.ho = hi / 2;
+    a.wo = wi / 2;
+    a.cout = cout;
+    a.slope = slope;
+    a.stats = stats;
+    a.stats_slots = stats_slots < 1 ? 1 : stats_slots;
+    a.stats_stride = stats_stride;
+    a.xbytes = (unsigned)xbytes;
+    a.ybytes = (unsigned)ybytes;
+    // a wave walks a run of 16-pixel groups inside (mostly) one image: 32 groups = 512 output pixels; at least ~4 blocks per CU
+    const long total = (long)batch * a.ho * (a.wo / 16);
+    int gpw = 32;
+    while (gpw > 4 && total / (4 * gpw) < 1024) gpw >>= 1;
+    a.groups_per_wave = gpw;
+    const dim3 grid((unsigned)((total + 4 * gpw - 1) / (4 * gpw)));
+#define SHM_RGB_FWD(T_, NT_) hipLaunchKernelGGL((conv3x3s2_rgb_fwd_kernel<T_, NT_>), grid, dim3(256), 0, st, a)
+    const int nt = cout / 16;
+    if (dtype == SHM_F32) {
+        if (nt == 4) SHM_RGB_FWD(float, 4);
+        else if (nt == 3) SHM_RGB_FWD(float, 3);
+        else if (nt == 2) SHM_RGB_FWD(float, 2);
+        else SHM_RGB_FWD(float, 1);
+    } else {
+        if (nt == 4) SHM_RGB_FWD(bf16_t, 4);
+        else if (nt == 3) SHM_RGB_FWD(bf16_t, 3);
+        else if (nt == 2) SHM_RGB_FWD(bf16_t, 2);
+        else SHM_RGB_FWD(bf16_t, 1);
+    }
+#undef SHM_RGB_FWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        shm_set_error("conv3x3s2_rgb_fwd: launch failed: %s", hipGetErrorString(e));
+        return SHM_E_HIP;
+    }
+    shm_set_last_kernel("conv3x3s2_rgb_fwd_kernel<%s, %d>", dtype == SHM_BF16 ? "__bf16" : "float", nt);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct RgbWgradArgs {
+    const void* x;
+    const void* dy;
+    float* part;             // [blocks][9][cin][cout]
+    int ldx, lddy, batch, hi, wi, ho, wo, cin, cout;
+    int quads_per_wave;      // a wave walks this many runs of four consecutive output pixels
+    unsigned xbytes, dybytes;
+};
+
+// NT = cout / 16.  Row tile i, lane row l15 = (tap, ci) pair 16 i + l15 of the 9 * cin <= 32; column tile j, lane column l15 = output channel
+// 4 * l15 + j (so that the lane's four consecutive dz values are the B operands of the four tiles).
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv3x3s2_rgb_wgrad_kernel(const RgbWgradArgs a) {
+    constexpr int ESZ = sizeof(T);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int qpr = a.wo >> 2, qpi = a.ho * qpr, total = a.batch * qpi;                  // quads per row / image
+    const int q0 = min(total, (blockIdx.x * 4 + wave) * a.quads_per_wave), q1 = min(total, q0 + a.quads_per_wave);
+    const int rows = 9 * a.cin;
+    // this lane's two A rows: (tap, ci) -> input displacement and channel
+    int rdy[2], rdx[2], rci[2];
+    bool rok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + l15;
+        rok[i] = row < rows;
+        const int tap = rok[i] ? row / a.cin : 0;
+        rci[i] = rok[i] ? row - tap * a.cin : 0;
+        rdy[i] = tap / 3;
+        rdx[i] = tap - 3 * rdy[i];
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](int q, float (&xa)[2], f32x4& dz) {
+        const int img = q / qpi, rem = q - img * qpi;
+        const int oh = rem / qpr, ow = ((rem - oh * qpr) << 2) + lq;                    // this lane's pixel of the quad (K index lq)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = 2 * oh + rdy[i], ix = 2 * ow + rdx[i];
+            const bool ok = rok[i] && iy < a.hi && ix < a.wi;
+            const unsigned off = ok ? (unsigned)(((img * a.hi + iy) * a.wi + ix) * a.ldx + rci[i]) * ESZ : 0xffffffffu;
+            if constexpr (ESZ == 4) xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)off, 0, 0));
+            else xa[i] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsx, (int)off, 0, 0) << 16);
+        }
+        // dz[pixel][4 l15 .. 4 l15 + 3]: columns 4 l15 + j of the NT (= cout / 16) column tiles -> needs 4 l15 + 3 < cout, i.e. NT == 4; narrower
+        // layers read channel 16 * (4 l15 + j) / ... one value per tile instead (below)
+        const unsigned pix = (unsigned)((img * a.ho + oh) * a.wo + ow) * (unsigned)a.lddy;
+        if constexpr (NT == 4) {
+            if constexpr (ESZ == 4) dz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)((pix + 4u * l15) * 4u), 0, 0));
+            else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rsd, (int)((pix + 4u * l15) * 2u), 0, 0);
+                dz = f32x4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+                if (j < NT) {
+                    const unsigned off = (pix + (unsigned)(NT * l15 + j)) * ESZ;
+                    if constexpr (ESZ == 4) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsd, (int)off, 0, 0));
+                    else v = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsd, (int)off, 0, 0) << 16);
+                }
+                dz[j] = v;
+            }
+        }
+    };
+    // two quads per step (all six loads of a step in flight together), the next step's loads under this step's MFMAs
+    float xa[2][2], xn[2][2];
+    f32x4 dz[2], dn[2];
+    auto load2 = [&](int q, float (&x2)[2][2], f32x4 (&d2)[2]) {
+        load(q, x2[0], d2[0]);
+        if (q + 1 < q1) load(q + 1, x2[1], d2[1]);
+        else {
+            x2[1][0] = x2[1][1] = 0.f;
+            d2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (q0 < q1) {
+        load2(q0, xa, dz);
+        for (int q = q0; q < q1; q += 2) {
+            if (q + 2 < q1) load2(q + 2, xn, dn);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i], dz[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                xa[u][0] = xn[u][0];
+                xa[u][1] = xn[u][1];
+                dz[u] = dn[u];
+            }
+        }
+    }
+    // the block's slab = the sum of its four waves' tiles, in a fixed order (deterministic): accumulator register r of tile (i, j) = row
+    // 16 i + 4 lq + r, column l15 -> channel NT * l15 + j
+    __shared__ float red[4][32][16 * NT + 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][16 * i + 4 * lq + r][NT * l15 + j] = acc[i][j][r];
+    __syncthreads();
+    float* out = a.part + (size_t)blockIdx.x * rows * a.cout;
+    for (int e = threadIdx.x; e < rows * a.cout; e += 256) {
+        const int row = e / a.cout, co = e - row * a.cout;
+        out[e] = (red[0][row][co] + red[1][row][co]) + (red[2][row][co] + red[3][row][co]);
+    }
+}
+
+// returns 1 = launched (*nsplit_out slabs written), 0 = not this kernel's shape, < 0 = error
+int shm_rgb_s2_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* part, size_t ws_bytes, int batch, int hi, int wi, int cin, int cout,
+                            size_t xbytes, size_t dybytes, int dtype, int* nsplit_out, hipStream_t st) {
+    const int esz = dtype == SHM_BF16 ? 2 : 4;
+    if (dtype != SHM_F32 && dtype != SHM_BF16) return 0;
+    if (ldx * esz != 16 || 9 * cin > 32 || cin < 1 || hi % 2 || wi % 2 || (wi / 2) % 4 || cout % 16 || cout > 64 || cout < 16) return 0;
+    if (lddy % (16 / esz) || ((size_t)dy & 15) || xbytes >= 0xfffffff0ull || dybytes >= 0xfffffff0ull) return 0;
+    const long total = (long)batch * (hi / 2) * (wi / 2 / 4);
+    if (total == 0) return 0;
+    // one slab per block of four waves: as many blocks as the workspace allows, at most 2048, at least 32 quads (128 pixels) per wave
+    const size_t slab = (size_t)9 * cin * cout * sizeof(float);
+    long nblk_l = (long)(ws_bytes / slab);
+    if (nblk_l > 2048) nblk_l = 2048;
+    if (nblk_l > total / 128) nblk_l = total / 128 > 0 ? total / 128 : 1;
+    if (nblk_l < 1) return 0;
+    long qpw = (total + 4 * nblk_l - 1) / (4 * nblk_l);
+    qpw = (qpw + 1) / 2 * 2;
+    RgbWgradArgs a{};
+    a.x = x;
+    a.dy = dy;
+    a.part = part;
+    a.ldx = ldx;
+    a.lddy = lddy;
+    a.batch = batch;
+    a.hi = hi;
+    a.wi = wi;
+    a.ho = hi / 2;
+    a.wo = wi / 2;
+    a.cin = cin;
+    a.cout = cout;
+    a.quads_per_wave = (int)qpw;
+    a.xbytes = (unsigned)xbytes;
+    a.dybytes = (unsigned)dybytes;
+    const int nblk = (int)((total + 4 * qpw - 1) / (4 * qpw));
+    if ((size_t)nblk * slab > ws_bytes) return 0;
+    const dim3 grid(nblk);
+#define SHM_RGB_WG(T_, NT_) hipLaunchKernelGGL((conv3x3s2_rgb_wgrad_kernel<T_, NT_>), grid, dim3(256), 0, st, a)
+    const int nt = cout / 16;
+    if (dtype == SHM_F32) {
+        if (nt == 4) SHM_RGB_WG(float, 4);
+        else if (nt == 3) SHM_RGB_WG(float, 3);
+        else if (nt == 2) SHM_RGB_WG(float, 2);
+        else SHM_RGB_WG(float, 1);
+    } else {
+        if (nt == 4) SHM_RGB_WG(bf16_t, 4);
+        else if (nt == 3) SHM_RGB_WG(bf16_t, 3);
+        else if (nt == 2) SHM_RGB_WG(bf16_t, 2);
+        else SHM_RGB_WG(bf16_t, 1);
+    }
+#undef SHM_RGB_WG
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        shm_set_error("conv3x3s2_rgb_wgrad: launch failed: %s", hipGetErrorString(e));
+        return SHM_E_HIP;
+    }
+    *nsplit_out = nblk;
+    shm_set_last_kernel("conv3x3s2_rgb_wgrad_kernel<%s, %d>", dtype == SHM_BF16 ? "__bf16" : "float", nt);
+    return 1;
+}

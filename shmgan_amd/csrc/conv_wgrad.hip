@@ -1491,6 +1491,7 @@ static int wgrad_splits(int batch, int ho, int wo, int cin, int cout, int esz = 
 extern "C" size_t shm_conv2d_wgrad_workspace(int batch, int ho, int wo, int cin, int cout, int ksize) {
     int ns = wgrad_splits(batch, ho, wo, cin, cout);
     if (9 * cin <= 96) ns *= 2;                          // wgrad_halo_thin_kernel writes two slabs per split
+    if (9 * cin <= 32 && ns < 1024) ns = 1024;           // conv3x3s2_rgb_wgrad_kernel (conv_rgb.hip): one slab per block, streaming -- blocks are what it needs
     if (shm_tune(SHM_TUNE_WGRAD_BLOCKS)) ns *= 2;        // wgrad_halo8_bf16_kernel: half as many (ci, co) tiles, twice the splits for a given block target
     return (size_t)ns * ksize * ksize * cin * cout * sizeof(float);
 }
@@ -1571,6 +1572,12 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
     ns = shm_cdiv(a.M, pps);
     a.pix_per_split = pps;
     hipStream_t st = (hipStream_t)stream;
+    // the 3-channel stride-2 first layer on the compact image layout (conv_rgb.hip); wgrad.variant 1 keeps the generic kernel
+    if (ksize == 3 && stride == 2 && !x2 && ldx * esz == 16 && !g_wnorm.nt && !g_wnorm.query && shm_tune(SHM_TUNE_WGRAD_VARIANT) != 1) {
+        const int r = shm_rgb_s2_wgrad_launch(x, ldx, dy, lddy, (float*)workspace, ws_bytes, batch, hi, wi, cin, cout, a.xbytes, a.dybytes, dtype, nsplit_out, st);
+        if (r < 0) return r;
+        if (r == 1) return SHM_OK;
+    }
     const bool straddle = x2 && (c1 % 64 != 0);
     const int wv = shm_tune(SHM_TUNE_WGRAD_VARIANT);       // 0 automatic, 1 generic kernels only, 2 no thin-input packing, 3 no stride-2 halo form
     const int no_halo = wv == 1;

@@ -857,6 +857,13 @@ class Discriminator(_ModelBase):
         self.adt = dtype
         self.gdt = (grad_dtype or dtype) if dtype != torch.float32 else torch.float32
         self.pad = pad_channels(dtype)
+        # pitch of the 3-channel input images (elements): ONE 16-byte chunk per pixel -- r, g, b, 0 in float32; r, g, b and five zeros in
+        # bfloat16 -- instead of the 64-byte MFMA staging row (round 4: the padded tensor was 403 MB written and read twice per step for
+        # 38-75 MB of pixels).  The first layer's forward and weight gradient have kernels for this layout (csrc: conv3x3s2_rgb_*); the
+        # generic kernels also read it correctly (the channels they see beyond the pixel's own are its neighbours', against zero weights)
+        self.in_pitch = 4 if dtype == torch.float32 else 8
+        if os.environ.get("SHM_D_INPUT") == "staging":       # A/B against the round-3 layout (tools/README.md)
+            self.in_pitch = self.pad
         self.gsum = ops.gsum_default(dtype)
         self.dropout = dropout
         assert image_size % 32 == 0
@@ -955,7 +962,7 @@ class Discriminator(_ModelBase):
         """The five Conv(3x3, s2) -> LeakyReLU -> InstanceNorm blocks on samples [r0, r1)."""
         xd16, bufs = self._pending["xd16"], self._pending["bufs"]
         nb = r1 - r0
-        cur, ld, h = xd16[r0:r1], self.pad, self.S
+        cur, ld, h = xd16[r0:r1], xd16.shape[-1], self.S
         for i in range(5):
             cin, cout = self.chan[i], self.chan[i + 1]
             ho = h // 2
@@ -979,7 +986,7 @@ class Discriminator(_ModelBase):
         keep_mask, mask_rows = pd["keep_mask"], pd["mask_rows"]
         A = self.arena
         recs = []
-        cur, ld, h = xd16, self.pad, self.S
+        cur, ld, h = xd16, xd16.shape[-1], self.S
         for i in range(5):
             a, ahat, stats = bufs[i]
             recs.append(dict(x=cur, ldx=ld, a=a, stats=stats, h=h))
@@ -1083,7 +1090,7 @@ class Discriminator(_ModelBase):
     def __call__(self, x, training=False, noise=None, keep_mask=None):
         """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""
         n = x.shape[0]
-        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, self.pad), self.adt)
+        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, self.in_pitch), self.adt)
         ops.pack_rgb16(x.contiguous(), noise if training else None, xd, n * self.S * self.S)
         rows = [(0, n, 0)] if (training and keep_mask is not None) else []
         return self.forward(xd, keep_mask, rows)

@@ -336,7 +336,7 @@ class ShmGANwithSSpecSeg:
         gen_Y = G.forward(gen_in, "g1", attn=attn_g)
 
         # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
-        xd = A.get("d/x16", (12 * B, S, S, PAD_C), adt)
+        xd = A.get("d/x16", (12 * B, S, S, D.in_pitch), adt)          # one 16-byte chunk per pixel (Discriminator.in_pitch)
         gen_rgb = A.get("g1/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, noise[:B], gen_rgb, xd[0:B], B, B, npix)                  # SHM.py:544-559
 

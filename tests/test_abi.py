@@ -125,6 +125,24 @@ def test_every_pipeline_barrier_waits_for_its_lds_reads():
     assert body.index("s_waitcnt lgkmcnt(0)") < body.index("__builtin_amdgcn_s_barrier()")
 
 
+def test_built_library_has_no_store_data_hazard():
+    """ISA lint for the fault found in round 4 (tools/check_isa_hazards.py): no VALU write into the data registers of a 12- / 16-byte store
+    within two wait states of it, anywhere in the library's gfx950 code -- hipcc does not space that out after buffer stores with an SGPR
+    soffset, and an inline-asm v_max landed there.  The scanner itself is checked on a crafted listing."""
+    import importlib.util
+    from pathlib import Path
+    root = Path(_lib.__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("check_isa_hazards", root / "tools" / "check_isa_hazards.py")
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = "0000 <k>:\n\tbuffer_store_dwordx4 v[16:19], v104, s[36:39], s66 offen\n\tv_max_f32_e32 v17, v12, v0\n"
+    ok1 = "0000 <k>:\n\tbuffer_store_dwordx4 v[16:19], v104, s[36:39], s66 offen\n\ts_nop 1\n\tv_max_f32_e32 v17, v12, v0\n"
+    ok2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_lshl_add_u64 v[16:17], v[16:17], 0, 16\n\tv_mov_b32_e32 v1, v2\n\tv_mov_b32_e32 v20, v2\n"
+    bad2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_mov_b32_e32 v1, v2\n\tv_pk_add_f32 v[22:23], v[2:3], v[4:5]\n"
+    assert len(chk.scan(bad)) == 1 and len(chk.scan(bad2)) == 1 and not chk.scan(ok1) and not chk.scan(ok2)
+    assert chk.main(["check_isa_hazards.py", str(_lib.LIB_PATH)]) == 0
+
+
 def test_bench_refuses_a_rank_count_that_disagrees_with_the_launcher():
     """bench.py --gpus N is the contract the driver computes scaling from: with WORLD_SIZE != N it must not print a line at all
     (round 2 printed n_gpus: 1 for `--gpus 8` launched as plain python).  The check runs before anything touches the GPU."""

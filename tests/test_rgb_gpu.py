@@ -1,0 +1,147 @@
+"""The discriminator's first layer on the compact image layout (csrc/conv_rgb.hip): Conv2D(3x3, stride 2, 'same') + LeakyReLU +
+InstanceNorm statistics of a 3-channel image stored one 16-byte chunk per pixel, and its weight gradient
+(/root/reference/ShmGANwithSSpecSeg.py:353, 386-389: Conv_LReLU_IN of the first discriminator block).
+
+Checked against the float64 oracle convolution, and the generic tap-GEMM / split-K kernels are run on the same compact buffers
+(a forced variant keeps them: they read K channels per tap across the neighbouring pixels, times the zero weight columns)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_torch as st
+from util import conv_ref, dev, host, nchw, pad_c, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _ops():
+    from shmgan_amd import ops
+    return ops
+
+
+def rb(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(BF).double().numpy()
+
+
+def _wk(w_hwio, cin_pad, dt):
+    ops = _ops()
+    k, _, cin, cout = w_hwio.shape
+    wt = torch.zeros(k * k * cout * cin_pad, device="cuda", dtype=dt)
+    ops.transpose_taps(dev(w_hwio), wt, k * k, cin, cout, cin_pad)
+    return wt
+
+
+def _x(x, dt):
+    """[n, h, w, 3] -> the compact layout: one 16-byte chunk per pixel"""
+    return dev(pad_c(x, 4 if dt == torch.float32 else 8)).to(dt).contiguous()
+
+
+# (12 x 256 x 256: a grid that fills the chip -- the size at which a store-data hazard of the first version showed, see tools/check_isa_hazards.py)
+CASES = [(3, 32, 64, True), (2, 64, 32, False), (1, 32, 16, True), (5, 96, 48, False), (7, 32, 64, False), (12, 256, 64, False)]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("n,h,cout,with_bias", CASES)
+def test_first_layer_forward_on_the_compact_image(dt, n, h, cout, with_bias):
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, h, h, 3))
+    w = rng.standard_normal((3, 3, 3, cout)) * 0.3
+    b = rng.standard_normal(cout) if with_bias else None
+    q = (lambda a: a) if dt == torch.float32 else rb
+    ref = conv_ref(q(x), q(w), 2) + (b if with_bias else 0.0)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    ho = h // 2
+    kpad = 16 if dt == torch.float32 else 32
+    wk, xd = _wk(w, kpad, dt), _x(x, dt)
+    bias = dev(b) if with_bias else None
+    tol = 1e-5 if dt == torch.float32 else 4e-3
+    try:
+        y = torch.full((n, ho, ho, cout), 7.0, device="cuda", dtype=dt)
+        stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda") if n % 2 else None
+        ops.conv2d_in_fwd(xd, None, 0, xd.shape[-1], 0, wk, bias, y, cout, n, h, h, kpad, cout, 3, 2, 0.2, stats, 1e-6, scratch=scr)
+        assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<"), ops.last_kernel()
+        assert rel_l2(host(y.float()), ref) < tol
+        yy = host(y.float()).astype(np.float64).reshape(n, -1, cout)
+        s = host(stats).reshape(n, cout, 2)
+        assert np.abs(s[..., 0] - yy.mean(1)).max() < 1e-4
+        assert np.abs(s[..., 1] - 1.0 / np.sqrt(yy.var(1) + 1e-6)).max() < 1e-3 * s[..., 1].max()
+        # without statistics, slope 1 (no activation)
+        y1 = torch.empty_like(y)
+        ops.conv2d_fwd(xd, None, 0, xd.shape[-1], 0, wk, bias, y1, cout, n, h, h, kpad, cout, 3, 2, 1.0)
+        assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<")
+        assert rel_l2(host(y1.float()), conv_ref(q(x), q(w), 2) + (b if with_bias else 0.0)) < tol
+        # the generic kernels on the same compact buffer
+        ops.set_tuning("tapgemm.variant", "dma128x64")
+        y2 = torch.empty_like(y)
+        stats2 = torch.empty_like(stats)
+        ops.conv2d_in_fwd(xd, None, 0, xd.shape[-1], 0, wk, bias, y2, cout, n, h, h, kpad, cout, 3, 2, 0.2, stats2, 1e-6)
+        assert ops.last_kernel().startswith("tapgemm_dma_kernel<"), ops.last_kernel()
+        assert rel_l2(host(y2.float()), ref) < tol
+        assert np.abs(host(stats2) - host(stats)).max() < 2e-3 * np.abs(host(stats)).max()
+    finally:
+        ops.set_tuning("reset", 0)
+
+
+def test_first_layer_forward_propagates_nan_and_handles_odd_shapes_elsewhere():
+    """a NaN pixel reaches exactly the outputs whose window holds it; a map the compact kernel does not take (width / 2 not a multiple of 16)
+    runs on the generic kernels with the same buffers"""
+    ops = _ops()
+    rng = np.random.default_rng(12)
+    n, h, cout = 2, 32, 64
+    x = rng.standard_normal((n, h, h, 3))
+    x[1, 10, 21, 1] = np.nan
+    w = rng.standard_normal((3, 3, 3, cout)) * 0.3
+    y = torch.empty((n, h // 2, h // 2, cout), device="cuda")
+    xd = _x(x, torch.float32)
+    ops.conv2d_fwd(xd, None, 0, 4, 0, _wk(w, 16, torch.float32), None, y, cout, n, h, h, 16, cout, 3, 2, 0.2)
+    assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<")
+    bad = np.isnan(host(y)).any(-1)
+    want = np.zeros_like(bad)
+    want[1, 4:6, 10:11] = True              # output (oh, ow) reads rows 2 oh .. 2 oh + 2, columns 2 ow .. 2 ow + 2
+    assert (bad == want).all()
+    h = 24                                  # 12 output columns
+    x = rng.standard_normal((n, h, h, 3))
+    y = torch.empty((n, h // 2, h // 2, cout), device="cuda")
+    ops.conv2d_fwd(_x(x, torch.float32), None, 0, 4, 0, _wk(w, 16, torch.float32), None, y, cout, n, h, h, 16, cout, 3, 2, 0.2)
+    assert not ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<")
+    ref = conv_ref(x, w, 2)
+    assert rel_l2(host(y), np.where(ref > 0, ref, 0.2 * ref)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("n,h,cout", [(3, 64, 64), (2, 32, 16), (1, 32, 32), (5, 40, 48), (8, 128, 64)])
+def test_first_layer_weight_gradient_on_the_compact_image(dt, n, h, cout):
+    ops = _ops()
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((n, h, h, 3))
+    ho = h // 2
+    dy = rng.standard_normal((n, ho, ho, cout))
+    q = (lambda a: a) if dt == torch.float32 else rb
+    wt = torch.zeros(3, 3, 3, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(q(x)), wt, 2), wt, nchw(q(dy)))
+    kpad = 16 if dt == torch.float32 else 32
+    xd, dz = _x(x, dt), dev(dy).to(dt)
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, ho, ho, 3, cout, 3) // 4 + 1024, device="cuda")
+    try:
+        dw = torch.full((3, 3, 3, cout), 3.0, device="cuda")
+        ops.conv2d_wgrad(xd, None, 0, xd.shape[-1], 0, dz, cout, dw, n, h, h, 3, kpad, cout, 3, 2, 0, ws)
+        assert ops.last_kernel().startswith("conv3x3s2_rgb_wgrad_kernel<"), ops.last_kernel()
+        assert rel_l2(host(dw), ref.numpy()) < 1e-5           # float32 products and sums of (exactly representable) operands in both dtypes
+        first = host(dw).copy()
+        ops.conv2d_wgrad(xd, None, 0, xd.shape[-1], 0, dz, cout, dw, n, h, h, 3, kpad, cout, 3, 2, 1, ws)
+        assert rel_l2(host(dw), 2 * ref.numpy()) < 1e-5
+        dw2 = torch.empty_like(dw)
+        ops.conv2d_wgrad(xd, None, 0, xd.shape[-1], 0, dz, cout, dw2, n, h, h, 3, kpad, cout, 3, 2, 0, ws)
+        assert (host(dw2) == first).all()                      # fixed summation order: bitwise repeatable
+        # the generic split-K kernel on the same compact buffer
+        ops.set_tuning("wgrad.variant", 1)
+        dw3 = torch.empty_like(dw)
+        ops.conv2d_wgrad(xd, None, 0, xd.shape[-1], 0, dz, cout, dw3, n, h, h, 3, kpad, cout, 3, 2, 0, ws)
+        assert not ops.last_kernel().startswith("conv3x3s2_rgb_wgrad_kernel<")
+        assert rel_l2(host(dw3), ref.numpy()) < (1e-5 if dt == torch.float32 else 2e-5)
+    finally:
+        ops.set_tuning("reset", 0)
