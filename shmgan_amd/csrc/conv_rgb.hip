@@ -15,6 +15,7 @@
 // pairs in two 16-row tiles, columns = output channels in the permutation co = 4 * lane + tile so that a lane's 16-byte dz load feeds the four
 // column tiles; split over blocks into the slabs shm_conv2d_wgrad_reduce sums.
 #include "common.h"
+#include "ablate.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -29,8 +30,8 @@ struct RgbFwdArgs {
     double* stats;           // optional [slot][batch][cout][2]
     int stats_slots;
     unsigned stats_stride;
-    unsigned xbytes, ybytes;
-    int groups_per_wave;
+    unsigned ybytes;
+    int groups_per_wave;     // divides the groups of an image: a wave's run lies in one image
 };
 
 __device__ __forceinline__ float rgb_row16_sum(float v) {           // sum over the 16 lanes of a DPP row, in every lane
@@ -41,27 +42,50 @@ __device__ __forceinline__ float rgb_row16_sum(float v) {           // sum over 
     return v;
 }
 
-// NT = cout / 16 column tiles (1..4)
-template <typename T, int NT>
+// NT = cout / 16 column tiles (1..4); PD = groups whose image fragments are in flight ahead of the one being multiplied.
+// A wave walks `groups_per_wave` runs of 16 consecutive output pixels of ONE image.  Its buffer descriptor covers that image alone, so the
+// window row below the image (2 oh + 2 == hi: SAME padding of an even map puts one row after, none before) is out of range by itself
+// and reads 0; the column right of the image is sent out of range by a per-lane select.  No branch in the loop: the image loads of the
+// next groups, the MFMAs and the stores overlap (a first version with `cond ? offset : ~0u` was compiled into scalar branches with
+// s_waitcnt vmcnt(0) inside and ran at 2 TB/s).
+template <typename T, int NT, bool HAS_BIAS, int PD, int UNR, bool STAGED>
 __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs a) {
     constexpr int ESZ = sizeof(T);
-    constexpr int NM = ESZ == 4 ? 9 : 3;                 // K blocks: 9 taps x 4 channels | 3 x (4 taps x 8 channels)
+    // The image arrives as 16-byte pixels, one window tap per lane quarter: load g (of NL) brings tap 4 g + lq.
+    // bfloat16: three loads (taps 0-3, 4-7, 8 and three dead quarters) are the B operands of three v_mfma_f32_16x16x32_bf16 as they come (K slot =
+    // (tap, channel 0..7)).  float32: seven v_mfma_f32_16x16x4_f32 -- K block m < 6 = channel m % 3 of load m / 3 (K slot lq = tap 4 (m / 3) + lq: a
+    // component of the loaded pixel, no shuffling), K block 6 = the three channels of tap 8 (slot lq = channel lq), fetched as one dword per lane.
+    // (A first version gathered all 27 (tap, channel) pairs as dwords: ~37 cycles of the texture path per wave-load, 41 us of 114.)
+    constexpr int NM = ESZ == 4 ? 7 : 3, NL = ESZ == 4 ? 2 : 3;
+    constexpr unsigned OOB = 0x80000000u;                // added to an offset: past any image (the launcher keeps images below 2 GiB)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int gpr = a.wo >> 4, gpi = a.ho * gpr, total = a.batch * gpi;
-    const int g0 = (blockIdx.x * 4 + wave) * a.groups_per_wave, g1 = min(total, g0 + a.groups_per_wave);
-    if (g0 >= g1) return;
+    const int gpr = a.wo >> 4, gpi = a.ho * gpr, rpi = gpi / a.groups_per_wave;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= a.batch * rpi) return;
+    const int img = wid / rpi, gl0 = (wid - img * rpi) * a.groups_per_wave;
 
-    // ---- weights -> registers (A operand: row = output channel 16 j + l15, k = lq of the K block)
-    f32x4 wa4[ESZ == 2 ? NM * NT : 1];                   // bf16: eight channels of tap 4 m + lq
-    float wa1[ESZ == 4 ? NM * NT : 1];                   // fp32: channel lq of tap m
+    // ---- weights -> registers (A operand: row = output channel 16 j + l15, k = lq of the K block); this lane's window displacements
+    f32x4 wa4[ESZ == 2 ? NM * NT : 1];
+    float wa1[ESZ == 4 ? NM * NT : 1];
+    unsigned cin_[NL], cedge[NL];                        // byte displacement of this lane's tap of load g from the window's first pixel
+#pragma unroll
+    for (int g = 0; g < NL; ++g) {
+        const int tap = 4 * g + lq;
+        const bool live = tap < 9;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        cin_[g] = live ? (unsigned)((kh * a.wi + kw) * 16) : OOB;
+        cedge[g] = (live && kw < 2) ? cin_[g] : OOB;     // for the pixel in the last column of the map
+    }
+    const unsigned c8 = (unsigned)((2 * a.wi + 2) * 16 + 4 * lq);          // float32: channel lq of tap 8 (out of the map for the last column)
 #pragma unroll
     for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = 16 * j + l15;
             if constexpr (ESZ == 4) {
-                wa1[m * NT + j] = ((const float*)a.wk)[((size_t)m * a.cout + co) * a.K + lq];
+                const int tap = m < 6 ? 4 * (m / 3) + lq : 8, ch = m < 6 ? m % 3 : lq;      // (the K-padded weight copy holds zeros in channel 3)
+                wa1[m * NT + j] = ((const float*)a.wk)[((size_t)tap * a.cout + co) * a.K + ch];
             } else {
                 const int tap = 4 * m + lq;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -69,29 +93,46 @@ __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs
                 wa4[m * NT + j] = v;
             }
         }
-    f32x4 bias4[NT];
+    f32x4 bias4[HAS_BIAS ? NT : 1];
+    if constexpr (HAS_BIAS) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[j][r] = a.bias ? a.bias[16 * j + 4 * lq + r] : 0.f;
-
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+            for (int r = 0; r < 4; ++r) bias4[j][r] = a.bias[16 * j + 4 * lq + r];
+    }
+    const unsigned imgbytes = (unsigned)a.hi * a.wi * 16u;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((char*)a.x + (size_t)img * imgbytes, 0, imgbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
-    const unsigned pixb = (unsigned)a.ldx * ESZ;         // 16 bytes
+    const unsigned lane_x = (unsigned)l15 * 32u;                                              // pixel 2 (owb + l15) of the row
+    const unsigned lane_y = ((unsigned)l15 * a.ldy + 4u * lq) * ESZ;
 
-    // image fragment of group g: fp32 -- nine floats (tap m, channel lq of pixel l15); bf16 -- three 16-byte chunks (tap 4 m + lq)
-    auto load_x = [&](int g, u32x4 (&xb)[ESZ == 2 ? NM : 1], float (&xf)[ESZ == 4 ? NM : 1]) {
-        const int img = g / gpi, rem = g - img * gpi;
-        const int oh = rem / gpr, ow = ((rem - oh * gpr) << 4) + l15;
+    // the walk over the run: (oh, owb) of group gl, advanced without divisions
+    struct Pos {
+        int oh, owb;
+    };
+    auto advance = [&](Pos& p) {
+        p.owb += 16;
+        if (p.owb == a.wo) {
+            p.owb = 0;
+            ++p.oh;
+        }
+    };
+    // image fragment of a group: fp32 -- seven floats; bf16 -- three 16-byte chunks
+    struct Frag {
+        u32x4 b[NL];
+        float f8;
+    };
+    auto load_x = [&](const Pos& p, Frag& fr) {
+        const unsigned base = (unsigned)(2 * p.oh * a.wi + 2 * p.owb) * 16u + lane_x;
+        const bool edge = p.owb + l15 + 1 == a.wo;       // per lane: v_cndmask, not a branch
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int tap = ESZ == 4 ? m : 4 * m + lq;
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            const int iy = 2 * oh + kh, ix = 2 * ow + kw;                 // SAME padding of an even map: nothing before, one row / column after
-            const bool ok = tap < 9 && iy < a.hi && ix < a.wi;
-            const unsigned off = ok ? (unsigned)((img * a.hi + iy) * a.wi + ix) * pixb + (ESZ == 4 ? (unsigned)lq * 4u : 0u) : 0xffffffffu;
-            if constexpr (ESZ == 4) xf[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)off, 0, 0));
-            else xb[m] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
+        for (int g = 0; g < NL; ++g) {
+            const unsigned off = abl::noload ? OOB : base + (edge ? cedge[g] : cin_[g]);
+            fr.b[g] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0);
+        }
+        if constexpr (ESZ == 4) {
+            const unsigned off = abl::noload ? OOB : base + (edge ? OOB : c8);
+            fr.f8 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)off, 0, 0));
         }
     };
 
@@ -100,49 +141,61 @@ __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
-    int simg = g0 / gpi;
-    auto flush = [&](int img) {
-        if (!a.stats) return;
-        double* base = a.stats + (size_t)((blockIdx.x * 4 + wave) % a.stats_slots) * a.stats_stride + ((size_t)img * a.cout + 4 * lq) * 2;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float mine = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t1 = rgb_row16_sum(s1[j][r]), t2 = rgb_row16_sum(s2[j][r]);
-                mine = l15 == 2 * r ? t1 : l15 == 2 * r + 1 ? t2 : mine;
-                s1[j][r] = s2[j][r] = 0.f;
-            }
-            if (l15 < 8) atomicAdd(base + (size_t)16 * j * 2 + l15, (double)mine);       // channels 16 j + 4 lq + (l15 >> 1), sum / sum of squares
-        }
-    };
+    // STAGED (ldy == cout): a pixel's NT * 16 channels are PIXB contiguous bytes, staged at a pitch of PIXB + 16 (the 16 lanes of
+    // a write pass -- one lq, 16 pixels -- then fall into 16 different bank quads)
+    constexpr int PIXB = NT * 16 * ESZ, PITCH = PIXB + 16;
+    __shared__ __attribute__((aligned(16))) char stage_all[STAGED ? 4 * 16 * PITCH : 16];
+    char* const stg = stage_all + (STAGED ? wave * 16 * PITCH : 0);
 
-    u32x4 xb[ESZ == 2 ? NM : 1], nb[ESZ == 2 ? NM : 1];
-    float xf[ESZ == 4 ? NM : 1], nf[ESZ == 4 ? NM : 1];
-    load_x(g0, xb, xf);
-    for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1) load_x(g + 1, nb, nf);           // next group's fragment under this group's MFMAs and stores
+    Pos pl;                                              // position of the next group to load
+    pl.oh = gl0 / gpr;
+    pl.owb = (gl0 - pl.oh * gpr) << 4;
+    Pos pc = pl;                                         // position of the group being computed
+    static_assert(UNR > PD, "ring");                     // the loop is unrolled over the fragment ring (no register copies); groups_per_wave % UNR == 0
+    Frag fr[UNR];
+    const int ng = a.groups_per_wave;
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        load_x(pl, fr[d]);
+        advance(pl);
+    }
+    // (entering the loop with the first fragments landed: otherwise hipcc merges "pending, nothing younger" from here with "pending, four stores
+    // younger" from the back edge into s_waitcnt vmcnt(0) at the top of the loop -- a drain of the stores in every round)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    auto compute = [&](const Frag& f) {
         f32x4 acc[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = bias4[j];
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if constexpr (ESZ == 4)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[m * NT + j], xf[m], acc[j], 0, 0, 0);
-                else
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa4[m * NT + j]), __builtin_bit_cast(bf16x8, xb[m]), acc[j], 0, 0, 0);
-            }
-        const int img = g / gpi, rem = g - img * gpi;
-        if (img != simg) {
-            flush(simg);
-            simg = img;
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (HAS_BIAS) acc[j] = bias4[j];
+            else acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int oh = rem / gpr, ow = ((rem - oh * gpr) << 4) + l15;
-        const unsigned yo = (unsigned)((img * a.ho + oh) * a.wo + ow) * (unsigned)a.ldy * ESZ + (unsigned)(4 * lq) * ESZ;
+        if constexpr (ESZ == 4) {
+            float bop[NM];                               // the B operands: the three channels of the two loaded pixels, then tap 8's
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const u32x4 px = f.b[g];
+                bop[3 * g] = __uint_as_float(px.x);
+                bop[3 * g + 1] = __uint_as_float(px.y);
+                bop[3 * g + 2] = __uint_as_float(px.z);
+            }
+            bop[6] = f.f8;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[m * NT + j], bop[m], acc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa4[m * NT + j]), __builtin_bit_cast(bf16x8, f.b[m]), acc[j], 0, 0, 0);
+        }
+        const unsigned yg = (unsigned)((img * a.ho + pc.oh) * a.wo + pc.owb) * (unsigned)a.ldy * ESZ;       // the group's first pixel
+        const unsigned yo = yg + lane_y;
+        advance(pc);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            // (the tile's offset in the instruction's immediate field, NOT as an SGPR soffset: see shm_lrelu_max in common.h)
             if constexpr (ESZ == 4) {
                 f32x4 v;
 #pragma unroll
@@ -151,8 +204,9 @@ __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs
                     s1[j][r] += v[r];
                     s2[j][r] = __builtin_fmaf(v[r], v[r], s2[j][r]);
                 }
-                // (the tile's offset in the instruction's immediate field, NOT as an SGPR soffset: see shm_lrelu_max in common.h)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
+                if constexpr (STAGED) *(f32x4*)(stg + l15 * PITCH + 64 * j + 16 * lq) = v;
+                else if constexpr (!abl::nostore)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
             } else {
                 unsigned pk[2];
 #pragma unroll
@@ -166,16 +220,48 @@ __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs
                     s2[j][2 * h + 1] = __builtin_fmaf(v1, v1, s2[j][2 * h + 1]);
                 }
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
+                if constexpr (STAGED) *(u32x2*)(stg + l15 * PITCH + 32 * j + 8 * lq) = u32x2{pk[0], pk[1]};
+                else if constexpr (!abl::nostore)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rsy, yo + (unsigned)(16 * j) * ESZ, 0, 0);
             }
         }
+        if constexpr (STAGED) {
+            // the group's 16 pixels are PIXB * 16 contiguous bytes of y: back out of the wave's staging rows in linear order, 1 KiB per store
+            // instruction (same wave, LDS operations complete in order: no barrier).  Partial-line stores -- 64 (fp32) or 32 (bf16) bytes of
+            // each pixel per instruction -- ran the kernel at 2.4 TB/s; see LABNOTES 10.7
+            constexpr int TOTAL = 16 * PIXB;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            if constexpr (ESZ == 4) xf[m] = nf[m];
-            else xb[m] = nb[m];
+            for (int i = 0; i < (TOTAL + 1023) / 1024; ++i) {
+                const int off = i * 1024 + lane * 16;
+                if (TOTAL % 1024 == 0 || off < TOTAL) {
+                    const u32x4 v = *(const u32x4*)(stg + (off / PIXB) * PITCH + off % PIXB);
+                    if constexpr (!abl::nostore) __builtin_amdgcn_raw_buffer_store_b128(v, rsy, yg + (unsigned)off, 0, 2);      // aux 2 = nt: written once, read by the next kernel
+                }
+            }
+        }
+    };
+    for (int g = 0; g < ng; g += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            // (past the run's end the loads still go out -- inside the image or out of range, both harmless -- so that the loop has no branch)
+            load_x(pl, fr[(u + PD) % UNR]);
+            advance(pl);
+            compute(fr[u]);
         }
     }
-    flush(simg);
+    if (a.stats) {
+        double* base = a.stats + (size_t)(wid % a.stats_slots) * a.stats_stride + ((size_t)img * a.cout + 4 * lq) * 2;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float mine = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t1 = rgb_row16_sum(s1[j][r]), t2 = rgb_row16_sum(s2[j][r]);
+                mine = l15 == 2 * r ? t1 : l15 == 2 * r + 1 ? t2 : mine;
+            }
+            if (l15 < 8) atomicAdd(base + (size_t)16 * j * 2 + l15, (double)mine);       // channels 16 j + 4 lq + (l15 >> 1), sum / sum of squares
+        }
+    }
 }
 
 // returns 1 = launched, 0 = this shape is not this kernel's (the caller goes on to the generic path), < 0 = error
@@ -185,7 +271,7 @@ int shm_rgb_s2_fwd_launch(const void* x, int ldx, const void* wk, int K, const f
     if (dtype != SHM_F32 && dtype != SHM_BF16) return 0;
     if (ldx * esz != 16 || K * esz != 64 || hi % 2 || wi % 2 || (wi / 2) % 16 || cout % 16 || cout > 64 || cout < 16) return 0;
     if (ldy % (16 / esz) || ((size_t)y & 15) || ((size_t)x & 15) || ((size_t)wk & 15)) return 0;
-    if (!(slope >= 0.f && slope <= 1.f) || xbytes >= 0xfffffff0ull || ybytes >= 0xfffffff0ull) return 0;
+    if (!(slope >= 0.f && slope <= 1.f) || (size_t)hi * wi * 16 >= 0x7fffff00ull || ybytes >= 0xfffffff0ull) return 0;
     if (batch == 0) return 1;
     RgbFwdArgs a{};
     a.x = x;
@@ -205,28 +291,46 @@ int shm_rgb_s2_fwd_launch(const void* x, int ldx, const void* wk, int K, const f
     a.stats = stats;
     a.stats_slots = stats_slots < 1 ? 1 : stats_slots;
     a.stats_stride = stats_stride;
-    a.xbytes = (unsigned)xbytes;
     a.ybytes = (unsigned)ybytes;
-    // a wave walks a run of 16-pixel groups inside (mostly) one image: 32 groups = 512 output pixels; at least ~4 blocks per CU
-    const long total = (long)batch * a.ho * (a.wo / 16);
-    int gpw = 32;
-    while (gpw > 4 && total / (4 * gpw) < 1024) gpw >>= 1;
-    a.groups_per_wave = gpw;
-    const dim3 grid((unsigned)((total + 4 * gpw - 1) / (4 * gpw)));
-#define SHM_RGB_FWD(T_, NT_) hipLaunchKernelGGL((conv3x3s2_rgb_fwd_kernel<T_, NT_>), grid, dim3(256), 0, st, a)
+    // a wave walks a run of 16-pixel groups of one image: the largest power of two up to 32 that divides the groups of an image and leaves
+    // ~1024 blocks (four per CU)
+    const int gpi = a.ho * (a.wo / 16);
     const int nt = cout / 16;
+    // prefetch distance / ring: float32 one group ahead (2 slots), bfloat16 two (4 slots) -- round-4 sweep at n = 96, 256 x 256: fp32 99 / 100 / 96 us
+    // for 1 / 2 / 3 ahead, bf16 63 / 60 / 61
+    const int unr = dtype == SHM_F32 ? 2 : 4;
+    if (gpi % unr) return 0;
+    // a wave walks a run of 16-pixel groups of one image: the largest power of two up to 32 that divides the groups of an image and leaves
+    // 4096 waves (four blocks per CU)
+    int gpw = unr;
+    while (gpw < 32 && gpi % (2 * gpw) == 0 && (long)batch * (gpi / (2 * gpw)) >= 4096) gpw *= 2;
+    a.groups_per_wave = gpw;
+    const long waves = (long)batch * (gpi / gpw);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const bool staged = ldy == cout;                      // a group's 16 pixels are contiguous in y: linear stores out of LDS
+#define SHM_RGB_FWD4(T_, NT_, B_, PD_, UNR_)                                                                                  \
+    do {                                                                                                                      \
+        if (staged) hipLaunchKernelGGL((conv3x3s2_rgb_fwd_kernel<T_, NT_, B_, PD_, UNR_, true>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((conv3x3s2_rgb_fwd_kernel<T_, NT_, B_, PD_, UNR_, false>), grid, dim3(256), 0, st, a);        \
+    } while (0)
+#define SHM_RGB_FWD3(T_, NT_, PD_, UNR_)                  \
+    do {                                                  \
+        if (bias) SHM_RGB_FWD4(T_, NT_, true, PD_, UNR_); \
+        else SHM_RGB_FWD4(T_, NT_, false, PD_, UNR_);     \
+    } while (0)
     if (dtype == SHM_F32) {
-        if (nt == 4) SHM_RGB_FWD(float, 4);
-        else if (nt == 3) SHM_RGB_FWD(float, 3);
-        else if (nt == 2) SHM_RGB_FWD(float, 2);
-        else SHM_RGB_FWD(float, 1);
+        if (nt == 4) SHM_RGB_FWD3(float, 4, 1, 2);
+        else if (nt == 3) SHM_RGB_FWD3(float, 3, 1, 2);
+        else if (nt == 2) SHM_RGB_FWD3(float, 2, 1, 2);
+        else SHM_RGB_FWD3(float, 1, 1, 2);
     } else {
-        if (nt == 4) SHM_RGB_FWD(bf16_t, 4);
-        else if (nt == 3) SHM_RGB_FWD(bf16_t, 3);
-        else if (nt == 2) SHM_RGB_FWD(bf16_t, 2);
-        else SHM_RGB_FWD(bf16_t, 1);
+        if (nt == 4) SHM_RGB_FWD3(bf16_t, 4, 2, 4);
+        else if (nt == 3) SHM_RGB_FWD3(bf16_t, 3, 2, 4);
+        else if (nt == 2) SHM_RGB_FWD3(bf16_t, 2, 2, 4);
+        else SHM_RGB_FWD3(bf16_t, 1, 2, 4);
     }
-#undef SHM_RGB_FWD
+#undef SHM_RGB_FWD3
+#undef SHM_RGB_FWD4
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         shm_set_error("conv3x3s2_rgb_fwd: launch failed: %s", hipGetErrorString(e));

@@ -74,6 +74,11 @@ def test_first_layer_forward_on_the_compact_image(dt, n, h, cout, with_bias):
         ops.conv2d_fwd(xd, None, 0, xd.shape[-1], 0, wk, bias, y1, cout, n, h, h, kpad, cout, 3, 2, 1.0)
         assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<")
         assert rel_l2(host(y1.float()), conv_ref(q(x), q(w), 2) + (b if with_bias else 0.0)) < tol
+        # into a wider tensor (output pitch > cout: the kernel's direct stores instead of the linear ones out of LDS)
+        yw = torch.full((n, ho, ho, 2 * cout), 7.0, device="cuda", dtype=dt)
+        ops.conv2d_in_fwd(xd, None, 0, xd.shape[-1], 0, wk, bias, yw, 2 * cout, n, h, h, kpad, cout, 3, 2, 0.2, stats, 1e-6, scratch=scr)
+        assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<")
+        assert (yw[..., :cout] == y).all() and (yw[..., cout:] == 7.0).all()
         # the generic kernels on the same compact buffer
         ops.set_tuning("tapgemm.variant", "dma128x64")
         y2 = torch.empty_like(y)
