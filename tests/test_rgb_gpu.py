@@ -118,7 +118,7 @@ def test_first_layer_forward_propagates_nan_and_handles_odd_shapes_elsewhere():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
-@pytest.mark.parametrize("n,h,cout", [(3, 64, 64), (2, 32, 16), (1, 32, 32), (5, 40, 48), (8, 128, 64)])
+@pytest.mark.parametrize("n,h,cout", [(3, 64, 64), (2, 32, 16), (1, 32, 32), (5, 96, 48), (8, 128, 64), (2, 512, 64), (13, 256, 64)])
 def test_first_layer_weight_gradient_on_the_compact_image(dt, n, h, cout):
     ops = _ops()
     rng = np.random.default_rng(13)
@@ -150,3 +150,19 @@ def test_first_layer_weight_gradient_on_the_compact_image(dt, n, h, cout):
         assert rel_l2(host(dw3), ref.numpy()) < (1e-5 if dt == torch.float32 else 2e-5)
     finally:
         ops.set_tuning("reset", 0)
+
+
+def test_first_layer_weight_gradient_of_other_widths_takes_the_generic_kernels():
+    """an output row that is not a multiple of 16 pixels is not the compact kernels' shape: same buffers, generic kernels, same result"""
+    ops = _ops()
+    rng = np.random.default_rng(14)
+    n, h, cout = 3, 40, 32
+    x = rng.standard_normal((n, h, h, 3))
+    dy = rng.standard_normal((n, h // 2, h // 2, cout))
+    wt = torch.zeros(3, 3, 3, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(x), wt, 2), wt, nchw(dy))
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, 3, cout, 3) // 4 + 1024, device="cuda")
+    dw = torch.empty((3, 3, 3, cout), device="cuda")
+    ops.conv2d_wgrad(_x(x, torch.float32), None, 0, 4, 0, dev(dy), cout, dw, n, h, h, 3, 16, cout, 3, 2, 0, ws)
+    assert not ops.last_kernel().startswith("conv3x3s2_rgb_wgrad_kernel<")
+    assert rel_l2(host(dw), ref.numpy()) < 1e-5
