@@ -133,7 +133,10 @@ int shm_cast_f32(const float* src, void* dst, size_t n, int dtype, void* stream)
  * input-gradient of a Conv2DTranspose).  Input = channel concat of x (c1 channels,
  * pitch ldx) and optional x2 (cin-c1 channels, pitch ldx2): Concatenate() SHM.py:299,306,
  * 313,320 is never materialised.  wk = [k*k][cout][cin] (shm_transpose_taps of HWIO, in the call's dtype),
- * cin and c1 multiples of 16 (fp32) / 32 (bf16).  bias may be NULL; slope 1.0f = no activation, 0.0f = ReLU. */
+ * cin and c1 multiples of 16 (fp32) / 32 (bf16).  bias may be NULL; slope 1.0f = no activation, 0.0f = ReLU.
+ * Compact 3-channel images (the discriminator's input, SHM.py:353): x may hold ONE 16-byte chunk per pixel -- ldx = 4 (fp32: r, g, b, 0) or 8
+ * (bf16: r, g, b, five zeros) -- under a weight copy of cin = 16 / 32 whose channels >= 3 are zero; k = 3, stride 2 and an output width that is a
+ * multiple of 16 then run the streaming kernels of conv_rgb.hip (forward and shm_conv2d_wgrad alike), other shapes the generic ones. */
 int shm_conv2d_fwd(const void* x, const void* x2, int c1, int ldx, int ldx2, const void* wk,
                    const float* bias, void* y, int ldy, int batch, int hi, int wi, int cin,
                    int cout, int ksize, int stride, float slope, int dtype, void* stream);
