@@ -2306,7 +2306,9 @@ __global__ __launch_bounds__(512, 4) void tapgemm_wreg16_bf16_kernel(const TapGe
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const u32x4 v = *(const u32x4*)(stg + st_r + j * 1024);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsy, yo, (unsigned)(8 * j) * ldyb, 0);
+                // aux 2 = nt: 1 KiB of whole lines per instruction, read next by another kernel (round 4 A/B: the block 257 -> 242 us, step -0.09 ms;
+                // the same hint on the halo kernels' 64-byte pieces and on the elementwise kernels' stores changed nothing)
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsy, yo, (unsigned)(8 * j) * ldyb, 2);
             }
             stamp(5);                        // [5] staging reads + store issue
             // halo(q + 1) was issued at the top of this patch; younger: the two stores (and the rare flush, which only makes the wait stricter)
