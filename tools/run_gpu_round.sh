@@ -1,15 +1,14 @@
 set -o pipefail
-run() { tag=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/end4_$tag.json 2> gpurun_out/end4_$tag.err || { echo FAIL $tag; tail -3 gpurun_out/end4_$tag.err; exit 1; }
-python - <<PY
+timeout -k 10 900 python -m pytest tests/test_step_gpu.py tests/test_train_loop_gpu.py tests/test_bf16_gpu.py tests/test_dist_gpu.py tests/test_norm_fold_gpu.py -m gpu -q -x > gpurun_out/r4_rs.log 2>&1
+rc=$?
+echo "pytest rc=$rc"; grep -v amdgpu.ids gpurun_out/r4_rs.log | tail -4
+[ $rc -eq 0 ] || exit 1
+for dt in bf16 f32; do
+for v in 0 1 0 1; do
+  SHM_WGRAD_REDUCE_STREAM=$v timeout -k 10 300 python bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > gpurun_out/r4_ab_$v.json 2>gpurun_out/r4_ab_$v.err || exit 1
+  python - <<PY
 import json
-j=json.loads([l for l in open("gpurun_out/end4_$tag.json") if l.startswith("{")][0])
-r=j.get("roofline",{})
-print("$tag", j["ms_per_step"], j["value"], j["unit"], "roofline", r.get("kernel"), r.get("frac"), "conv", r.get("whole_step_conv_tflops"), "cpu", (j.get("cpu_baseline") or {}).get("value"), "north*", (j.get("north_star_block") or {}).get("us"))
+j=json.loads([l for l in open("gpurun_out/r4_ab_$v.json") if l.startswith("{")][0])
+print("$dt reduce-stream=$v", j["ms_per_step"], j["value"])
 PY
-}
-run f32 --steps 10 --warmup 3
-run bf16 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
-run s512_b4_bf16 --dtype bf16 --image-size 512 --batch 4 --steps 8 --warmup 2 --no-cpu-baseline
-run b32_bf16 --dtype bf16 --batch 32 --steps 8 --warmup 2 --no-cpu-baseline
-run s512_b4_f32 --image-size 512 --batch 4 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer
-run b32_f32 --batch 32 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timer
+done; done
