@@ -140,6 +140,11 @@ def test_built_library_has_no_store_data_hazard():
     ok2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_lshl_add_u64 v[16:17], v[16:17], 0, 16\n\tv_mov_b32_e32 v1, v2\n\tv_mov_b32_e32 v20, v2\n"
     bad2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_mov_b32_e32 v1, v2\n\tv_pk_add_f32 v[22:23], v[2:3], v[4:5]\n"
     assert len(chk.scan(bad)) == 1 and len(chk.scan(bad2)) == 1 and not chk.scan(ok1) and not chk.scan(ok2)
+    # ... and its second rule: no VALU read of an MFMA's VGPR result within four wait states (another MFMA may chain on it)
+    bad3 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\tv_mov_b32_e32 v7, v8\n\tv_max_f32_e32 v9, v1, v2\n"
+    ok3 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\ts_nop 4\n\tv_max_f32_e32 v9, v1, v2\n"
+    ok4 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\tv_mfma_f32_16x16x4_f32 v[0:3], v6, v7, v[0:3]\n\tv_mfma_f32_16x16x4_f32 a[0:3], v6, v7, a[0:3]\n"
+    assert len(chk.scan(bad3)) == 1 and not chk.scan(ok3) and not chk.scan(ok4)
     assert chk.main(["check_isa_hazards.py", str(_lib.LIB_PATH)]) == 0
 
 

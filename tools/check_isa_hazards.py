@@ -10,6 +10,8 @@ The MI355X does not: round 4's conv3x3s2_rgb_fwd_kernel had `buffer_store_dwordx
 v_max_f32 into v17 (the next tile's LeakyReLU), and ~4e-4 of that register's values were stored as the next tile's -- lanes 12-15 of a row only,
 only at sizes that fill the chip, differently from run to run.  With the tile offset in the instruction's immediate field the compiler spaces
 the write out itself.  The scan applies the rule to every wide store, whatever its soffset.
+The scan also applies the neighbouring rule inline asm escapes the same way: no VALU read of an MFMA's VGPR result within four wait states (the
+shortest MFMA wants five; hipcc pads its own instructions).
 (Linear scan of the disassembly: a store at the very end of a loop body against a write at its top is not seen.)
 
     python tools/check_isa_hazards.py [path/to/libshmgan_hip.so]      exit 0 = clean, 1 = findings (printed with kernel and lines)
@@ -64,13 +66,28 @@ def nop_states(ins, ops):
     return 1
 
 
+MFMA_WAIT_STATES = 4              # a lower bound: the shortest (2-pass) MFMA wants 5 wait states before a VALU reads its VGPR result
+
+
+def all_vregs(ops):
+    out = set()
+    for o in ops:
+        for m in REG.finditer(o):
+            if m.group(1) is not None:
+                out.add(int(m.group(1)))
+            else:
+                out |= set(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
 def scan(text):
     findings, kernel = [], "?"
     pending = []                  # [(data regs, wait states left, store line)]
+    mfma = []                     # [(result VGPRs, wait states left, mfma line)]: results in arch VGPRs a VALU must not read yet
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
         if m:
-            kernel, pending = m.group(1), []
+            kernel, pending, mfma = m.group(1), [], []
             continue
         body = line.split("//")[0].strip()
         if not body or body.startswith("Disassembly") or body.endswith(":"):
@@ -86,8 +103,20 @@ def scan(text):
             for regs, left, where in pending:
                 if dst & regs:
                     findings.append((kernel, where, body))
+        # second rule (same blind spot: hipcc counts the wait states for its own instructions, not for inline asm): a VALU instruction -- not another
+        # MFMA, which the matrix pipe orders itself -- reading the VGPR result of an MFMA within MFMA_WAIT_STATES of it
+        if ins.startswith("v_") and not (ins.startswith("v_mfma") or ins.startswith("v_smfmac")) and len(ops) > 1:
+            src = all_vregs(ops[1:])
+            for regs, left, where in mfma:
+                if src & regs:
+                    findings.append((kernel, where, body))
         states = nop_states(ins, ops)
         pending = [(r, left - states, w) for r, left, w in pending if left - states > 0]
+        mfma = [(r, left - states, w) for r, left, w in mfma if left - states > 0]
+        if (ins.startswith("v_mfma") or ins.startswith("v_smfmac")) and ops:
+            dst = vregs(ops[0])       # empty for AGPR destinations
+            if dst:
+                mfma.append((dst, MFMA_WAIT_STATES, body))
         wide = ins.endswith("dwordx3") or ins.endswith("dwordx4")
         if wide and "store" in ins:
             # buffer_store: vdata, vaddr, srsrc, soffset; global / flat / scratch: vaddr, vdata, saddr
@@ -114,7 +143,7 @@ def main(argv):
             bad += scan(text)
     for kernel, store, writer in bad:
         print(f"HAZARD {kernel}\n    {store}\n    {writer}")
-    print(f"{lib.name}: {len(objs)} code objects, {nk} symbols, {len(bad)} store-data hazards")
+    print(f"{lib.name}: {len(objs)} code objects, {nk} symbols, {len(bad)} store-data / MFMA-result hazards")
     return 1 if bad else 0
 
 
