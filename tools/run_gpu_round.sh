@@ -1,10 +1,6 @@
 set -o pipefail
-for cfg in "0 0" "4 128" "4 192" "4 384" "3 128" "0 0"; do
-  set -- $cfg
-  SHM_WGRAD_BF16_WIDE=$1 SHM_WGRAD_BLOCKS=$2 timeout -k 10 300 python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > gpurun_out/r4_ab.json 2>gpurun_out/r4_ab.err || { tail -3 gpurun_out/r4_ab.err; exit 1; }
-  python - <<PY
-import json
-j=json.loads([l for l in open("gpurun_out/r4_ab.json") if l.startswith("{")][0])
-print("bf16 wide=$1 blocks=$2", j["ms_per_step"], j["value"])
-PY
-done
+export SHM_TREE_SHA=4d76f4f
+bash tools/profile_round.sh r04_b32_bf16 --dtype bf16 --batch 32 || exit 1
+bash tools/trace_step.sh r04_b32_bf16 --dtype bf16 --batch 32 || exit 1
+mkdir -p gpurun_out/profiles_new && cp profiles/r04_b32_bf16* gpurun_out/profiles_new/
+ls gpurun_out/profiles_new | grep b32
