@@ -254,3 +254,34 @@ def test_first_layer_degenerate_calls():
     ws = torch.empty(1 << 20, device="cuda")
     ops.conv2d_wgrad(x, None, 0, 4, 0, y, 16, dw, 1, 32, 32, 3, 16, 16, 3, 2, 0, ws)        # zero image: zero gradient, whatever dz
     assert ops.last_kernel().startswith("conv3x3s2_rgb_wgrad_kernel<") and float(dw.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("n,hi,wi,cout", [(2, 64, 96, 64), (3, 96, 32, 32), (1, 32, 128, 16)])
+def test_first_layer_on_non_square_images(dt, n, hi, wi, cout):
+    """rows and columns are independent in the kernels' indexing: forward and weight gradient on rectangular images against the oracle"""
+    ops = _ops()
+    rng = np.random.default_rng(15)
+    x = rng.standard_normal((n, hi, wi, 3))
+    w = rng.standard_normal((3, 3, 3, cout)) * 0.3
+    ho, wo = hi // 2, wi // 2
+    dy = rng.standard_normal((n, ho, wo, cout))
+    q = (lambda a: a) if dt == torch.float32 else rb
+    ref = conv_ref(q(x), q(w), 2)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    wt = torch.zeros(3, 3, 3, cout, dtype=torch.float64, requires_grad=True)
+    gref, = torch.autograd.grad(st.conv2d_same(nchw(q(x)), wt, 2), wt, nchw(q(dy)))
+    kpad = 16 if dt == torch.float32 else 32
+    xd, wk = _x(x, dt), _wk(w, kpad, dt)
+    y = torch.empty((n, ho, wo, cout), device="cuda", dtype=dt)
+    stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+    ops.conv2d_in_fwd(xd, None, 0, xd.shape[-1], 0, wk, None, y, cout, n, hi, wi, kpad, cout, 3, 2, 0.2, stats, 1e-6)
+    assert ops.last_kernel().startswith("conv3x3s2_rgb_fwd_kernel<"), ops.last_kernel()
+    assert rel_l2(host(y.float()), ref) < (1e-5 if dt == torch.float32 else 4e-3)
+    yy = host(y.float()).astype(np.float64).reshape(n, -1, cout)
+    assert np.abs(host(stats).reshape(n, cout, 2)[..., 0] - yy.mean(1)).max() < 1e-4
+    ws = torch.empty(ops.conv2d_wgrad_workspace(n, ho, wo, 3, cout, 3) // 4 + 1024, device="cuda")
+    dw = torch.empty((3, 3, 3, cout), device="cuda")
+    ops.conv2d_wgrad(xd, None, 0, xd.shape[-1], 0, dev(dy).to(dt), cout, dw, n, hi, wi, 3, kpad, cout, 3, 2, 0, ws)
+    assert ops.last_kernel().startswith("conv3x3s2_rgb_wgrad_kernel<"), ops.last_kernel()
+    assert rel_l2(host(dw), gref.numpy()) < 1e-5
