@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--filter-size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the bf16 configs[3] / configs[4] runs behind the fp32 headline")
     ap.add_argument("--serialize", action="store_true", help="no second stream for weight gradients (profiling)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median), after one warm-up")
     ap.add_argument("--per-shape", type=str, default="", help="write per-(kernel,shape) timings to this JSON file")
@@ -273,12 +274,80 @@ def main():
                 Path(args.per_shape).write_text(json.dumps(rows, indent=1))
         if not args.no_kernel_timer and world == 1:      # a single-GPU property; at N > 1 the other ranks would wait behind it
             out["north_star_block"] = north_star_block(torch, ops, dev)
+        if world == 1 and not args.no_extra_configs and (S, B, F, args.dtype) == (256, 8, 64, "f32"):
+            # BASELINE configs[3] and [4] (per GPU) on the same clock as the headline: two more trainers in this process, one after the
+            # other, each after the previous arena has been freed
+            del inputs, noise_buf, keep_buf
+            model.release()
+            del model, lane
+            torch.cuda.empty_cache()
+            out["extra_configs"] = [extra_config(torch, np, ops, dev, ShmGANwithSSpecSeg, F, *cfg, note)
+                                    for cfg in ((512, 4, "BASELINE configs[3]"), (256, 32, "BASELINE configs[4], per GPU"))]
         if not args.no_cpu_baseline and world == 1:         # reported at N=1 only: the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(S, F, args.cpu_steps, note)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def extra_config(torch, np, ops, dev, Model, F, S, B, tag, note, steps=10, warmup=3, replay=3):
+    """One of BASELINE.json's bf16 configurations, timed as the headline is: `warmup` untimed steps, `steps` timed steps of the production
+    two-stream step between synchronisations, then a serialized replay of `replay` steps under the HIP-event kernel timer for the dominant
+    MFMA kernel's roofline fraction."""
+    model = Model(image_size=S, filter_size=F, batch_size=B, device=dev, compute_dtype="bfloat16").build()
+    rng = np.random.default_rng(1234)
+    inputs = [torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).to(dev) for _ in range(5)]
+    s = S // 32
+    noise_buf = torch.empty((2 * B, S, S, 3), device=dev)
+    keep_buf = torch.empty((2 * B, s, s, 16 * F), device=dev)
+
+    class Draws:
+        pass
+
+    def draws_for(step):
+        r = np.random.default_rng(7 + step)
+        d = Draws()
+        d.flags = tuple(bool(u < 0.5) for u in r.random(5))
+        d.target_label = float(r.uniform(0.8, 1.2))
+        ops.randn(noise_buf, 0.1, 7 + step, 0)
+        ops.keep_mask(keep_buf, 0.2, 7 + step, 1)
+        d.noise, d.keep_mask = noise_buf, keep_buf
+        return d
+    for i in range(warmup):
+        model.train_step(*inputs, draws=draws_for(i), next_batch=inputs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model.train_step(*inputs, draws=draws_for(warmup + i), next_batch=inputs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / steps * 1e3
+    lane = model._get_lane()
+    lane_stream, lane.stream = lane.stream, None
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    for i in range(replay):
+        model.train_step(*inputs, draws=draws_for(warmup + steps + i), next_batch=inputs)
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    lane.stream = lane_stream
+    summ = timer.summary()
+    dom = max((k for k in summ if summ[k]["flops"] > 0), key=lambda k: summ[k]["ms"])
+    ach = summ[dom]["flops"] / (summ[dom]["ms"] * 1e-3) / 1e12
+    finite = all(np.isfinite(v) for k, v in model.losses().items() if k != "ssim")
+    res = {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, bf16 operands / fp32 accumulate ({tag})",
+           "dtype": "bf16", "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "value": round(B * steps / dt, 3), "unit": "images/sec",
+           "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "ms_per_step": round(summ[dom]["ms"] / replay, 3),
+                        "region": f"serialized replay of {replay} steps, same process"},
+           "whole_step_conv_tflops": round(sum(v["flops"] for v in summ.values()) / replay / (ms * 1e-3) / 1e12, 1),
+           "losses_finite": bool(finite)}
+    note(f"extra config {tag}: {ms:.2f} ms/step")
+    model.release()
+    del model, lane, inputs, noise_buf, keep_buf
+    torch.cuda.empty_cache()
+    return res
 
 
 def north_star_block(torch, ops, dev, n=40, h=256, c=64, reps=20):
@@ -308,9 +377,68 @@ def north_star_block(torch, ops, dev, n=40, h=256, c=64, reps=20):
     us = e0.elapsed_time(e1) / reps * 1e3
     nbytes = 2 * n * h * h * (c + c) + 2 * 9 * c * c + 16 * n * c
     gbps = nbytes / us / 1e3
-    return {"block": f"conv3x3 {c}->{c} + bias + LeakyReLU + IN statistics, {h}x{h}, n={n}, bf16", "kernel": kernel, "bytes": nbytes,
-            "us": round(us, 2), "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "launches": reps,
-            "flops": 2.0 * n * h * h * 9 * c * c, "tflops": round(2.0 * n * h * h * 9 * c * c / us / 1e6, 1)}
+    flops = 2.0 * n * h * h * 9 * c * c
+    out = {"block": f"conv3x3 {c}->{c} + bias + LeakyReLU + IN statistics, {h}x{h}, n={n}, bf16", "kernel": kernel, "bytes": nbytes,
+           "us": round(us, 2), "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "launches": reps,
+           "flops": flops, "tflops": round(flops / us / 1e6, 1)}
+    out.update(north_star_ceiling(torch, dev, flops, 2 * n * h * h * c, us, reps))
+    return out
+
+
+def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps):
+    """What the chip can do on the block's two resources taken one at a time, in this process, right after the product kernel
+    (tools/probes/ceiling_ns_block.hip): the block's FLOPs as a bare v_mfma_f32_16x16x32_bf16 loop on random operands in registers (the
+    product's launch geometry: 512 eight-wave blocks, four waves per SIMD) and the block's bytes as a 16-byte-per-lane streaming copy.
+    ceiling_us = max of the two; frac_of_ceiling = ceiling_us / us.  clock_ghz: d(s_memtime) / d(s_memrealtime) x 100 MHz around the MFMA loop."""
+    import ctypes as C
+    lib_path = ROOT / "tools" / "probes" / "libceiling_ns_block.so"
+    if not lib_path.exists():
+        import __graft_entry__ as ge
+        ge.build_probes()
+    L = C.CDLL(str(lib_path))
+    L.ceil_mfma_bf16.restype = C.c_int
+    L.ceil_mfma_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ceil_copy.restype = C.c_int
+    L.ceil_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks = 2 * ncu
+    waves = blocks * 8
+    per_wave = int(flops / 16384 / waves) // 8 * 8              # 16 x 16 x 32 x 2 FLOP per MFMA
+    ops_ = torch.randn(4 * 64 * 8, device=dev).to(torch.bfloat16)
+    sink = torch.empty(blocks * 512, device=dev)
+    stamps = torch.zeros(2 * waves, dtype=torch.int64, device=dev)
+    src = torch.randn(tensor_bytes // 4, device=dev)
+    dst = torch.empty_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    def mfma():
+        if L.ceil_mfma_bf16(ops_.data_ptr(), sink.data_ptr(), stamps.data_ptr(), blocks, per_wave, st) < 0:
+            raise RuntimeError("ceiling probe: MFMA launch failed")
+
+    def copy():
+        if L.ceil_copy(src.data_ptr(), dst.data_ptr(), tensor_bytes, 16 * ncu, st) != 0:
+            raise RuntimeError("ceiling probe: copy launch failed")
+    mfma_us = timed(mfma) * (flops / (per_wave * waves * 16384.0))          # scaled to the block's exact FLOPs (rounding of per_wave)
+    sv = stamps.view(-1, 2).double()
+    clock = float((sv[:, 0] / sv[:, 1].clamp(min=1)).median()) * 0.1            # cycles per 10 ns tick -> GHz
+    copy_us = timed(copy)
+    ceil_us = max(mfma_us, copy_us)
+    return {"ceiling": {"mfma_us": round(mfma_us, 2), "mfma_tflops": round(flops / mfma_us / 1e6, 1), "mfma_clock_ghz": round(clock, 3),
+                        "copy_us": round(copy_us, 2), "copy_GBps": round(2 * tensor_bytes / copy_us / 1e3, 1),
+                        "what": "bare 16x16x32 bf16 MFMA loop with the block's FLOPs (random operands in registers, 4 waves per SIMD) / 16-byte "
+                                "streaming copy of the block's activation bytes; same process, after the product kernel"},
+            "ceiling_us": round(ceil_us, 2), "frac_of_ceiling": round(ceil_us / us, 4)}
 
 
 def launch_ranks(n):

@@ -175,21 +175,18 @@ static inline void shm_same_pad(int in, int k, int s, int* out, int* before) {
 }
 
 __device__ __forceinline__ float shm_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-// LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions (v_mul, v_max): fmaxf costs a third -- hipcc quiets a possible signalling NaN in u first
-// (v_max u, u, u), which for an MFMA result it cannot rule out; the instruction itself already does that in the kernels' IEEE mode.  Same bits as shm_lrelu for every
-// finite u; a NaN stays a NaN (both operands are NaN then), so a diverged activation still shows in the statistics and the losses (round 3 used
-// v_med3(u, u * slope, FLT_MAX), which turned a NaN into FLT_MAX: advisor finding).
+// LeakyReLU for 0 <= slope <= 1 as max(u, u * slope) in TWO instructions, both visible to the compiler: v_mul_f32 + v_maximum3_f32 (the IEEE-754-2019
+// `maximum`, a gfx950 instruction: NaN-propagating, so hipcc does not quiet a possible signalling NaN in u first -- the third instruction that fmaxf costs on
+// an MFMA result).  Same bits as shm_lrelu for every finite u (u and u * slope never differ in sign); a NaN stays a NaN, so a diverged activation still shows
+// in the statistics and the losses; u = -inf at slope 0 gives NaN, as shm_lrelu does (-inf * 0).  Rounds 3-4 spelled the max as inline asm (v_med3 / v_max_f32):
+// opaque to the scheduler and to hipcc's hazard recogniser -- the round-4 store-data fault below was such an asm write, and an asm READ of an MFMA result gets
+// no wait states (advisor findings, round 4).  No inline-asm arithmetic is left in the kernels.
 // HAZARD (round 4): a 16- or 12-byte store reads its data VGPRs after it has issued, and a VALU write into one of them must stay two wait states
-// away.  hipcc spaces that out itself, except after a BUFFER store whose soffset is an SGPR (its table exempts those; the MI355X does not): there this
-// helper's v_max of the NEXT tile landed in a register of the tile just stored, and ~4e-4 of conv3x3s2_rgb_fwd_kernel's values of that register went out
+// away.  hipcc spaces that out itself, except after a BUFFER store whose soffset is an SGPR (its table exempts those; the MI355X does not): there the
+// next tile's LeakyReLU landed in a register of the tile just stored, and ~4e-4 of conv3x3s2_rgb_fwd_kernel's values of that register went out
 // wrong, only under load.  Keep the offsets of wide buffer stores in the immediate field; tools/check_isa_hazards.py scans the built library for
 // the pattern (tests/test_abi.py runs it).
-__device__ __forceinline__ float shm_lrelu_max(float u, float slope) {
-    const float m = u * slope;
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(m));
-    return r;
-}
+__device__ __forceinline__ float shm_lrelu_max(float u, float slope) { return __builtin_elementwise_maximum(u, u * slope); }
 
 // InstanceNormalization apply, (x - mean) * inv + beta, in ONE spelling for the stand-alone pass (shm_in_apply) and for the
 // consumers that normalise their operand tile in LDS ("fused block", shm_conv2d_in_fwd_norm / shm_conv2d_wgrad_norm): a

@@ -1,0 +1,488 @@
+// The north-star block as a PING-PONG kernel (round 5): conv3x3 64 -> 64, unit stride, bf16, + bias + LeakyReLU + InstanceNorm statistics
+// (ShmGANwithSSpecSeg.py:244-245), and its input gradient.
+//
+// Why another kernel.  tapgemm_wreg16_bf16_kernel (conv_wreg16.hip) runs two eight-wave blocks per CU whose waves move in lockstep through
+// [halo DMA issue | MFMA loop | epilogue | staging barrier | stores]; its timing ablations are ADDITIVE (LABNOTES 10.2: remove the MFMAs, the
+// LDS reads, the DMA or the stores and it loses 50-75 us each, any two ~150 of 240), and round 5's cut of its epilogue from ~215 to ~150
+// non-MFMA vector instructions per patch and wave left the forward launch where it was (225 -> 216-225 us, same box): the phases do not overlap,
+// the matrix pipe idles whenever both resident blocks are outside their MFMA loops.  Here the overlap is built in:
+//
+//   * ONE eight-wave block per CU (two waves per SIMD, 256 registers each), split into two GROUPS of four waves.  A group owns a stream of
+//     8 x 32-pixel patches (all 64 output channels: 2 (rows 0-3 / 4-7) x 2 (channels 0-31 / 32-63) waves) and alternates between an X segment
+//     -- the patch's 144 v_mfma_f32_32x32x16_bf16 per wave, operands: weights in 144 registers, activation fragments from the group's halo
+//     image in LDS -- and a Y segment: halo DMA of its NEXT patch, epilogue of the patch just computed (bias, LeakyReLU, bf16, LDS staging),
+//     whole-line stores, statistics.  The two groups run half a period apart, separated by workgroup barriers: on every SIMD one wave is in X
+//     while its partner is in Y, by construction.  An X segment is 4 608 matrix-pipe cycles; a Y segment issues ~450 vector instructions.
+//   * 32x32x16 tiles: a fragment read (1 KiB per wave) feeds up to three MFMAs of 32 cycles (halo-row walk: halo row R, column shift cs serves
+//     patch rows R - kh), so the X wave needs an LDS read per ~64-96 pipe cycles and one step of look-ahead hides its latency; the MFMA holds the
+//     vector issue port 8 of its 32 cycles, which leaves the port to the partner's epilogue.
+//   * Halo image per group: [10 rows][34 pixels][128 bytes], single-buffered (it is refilled in the group's Y segment, after the barrier that ends
+//     its X segment), filled by LDS-DMA: wave w4 of the group fetches the 8-pixel column segment w4 of every halo row (ten 1 KiB items whose
+//     per-lane source offset is ONE lane constant plus a uniform term) and the two-pixel tails of rows w4, w4 + 4, w4 + 8; 16-byte chunk c of
+//     halo column hc sits at position c ^ ((hc >> 1) & 7): the 32-pixel fragment read (two chunks per pixel) and the linear DMA write are both
+//     conflict-free.  Out-of-image rows fall outside a per-image buffer descriptor (zeros), out-of-image columns get an out-of-range offset.
+//   * The X wave is alone on its SIMD's matrix pipe (its partner is in Y), so its fragment reads are issued TWO steps ahead of their use
+//     (hipcc, left alone, sinks a one-step look-ahead back to its use: ds_read, lgkmcnt(0), MFMA -- the round-5 stamps showed X at 66 % of the
+//     pipe) and the halo rows are walked in the order 0/2 interleaved, 1 | 5/3 interleaved, 4, so that a fragment with one MFMA (rows 0, 5) is
+//     followed by one with three.
+//   * Epilogue as in conv_wreg16.hip: a lane's accumulator quads are four consecutive channels of one pixel -> 8-byte pieces into a
+//     [256 pixels][128 bytes] staging image (chunk XOR pixel & 7), barrier, 1 KiB stores of whole lines; InstanceNorm sums on the matrix pipe
+//     from the staging image (transposed reads: mfma(F, F) diagonal = sum y^2, mfma(F, ones) = sum y; see conv_wreg16.hip).
+//
+// LDS: 2 x 43 KiB halo + 2 x 32 KiB staging + bias = 150.25 KiB.  Eligible: K = 64, one source tensor, map height % 8 == 0 and width % 32 == 0,
+// Cout % 64 == 0 with 64-channel blocks inside one output part, outputs below 4 GiB, an image below 2 GiB.
+#include "tapgemm.h"
+
+#include <stdlib.h>
+
+namespace {
+constexpr int PP_PH = 8, PP_PW = 32, PP_HR = PP_PH + 2, PP_HC = PP_PW + 2;
+constexpr int PP_ITEMS = (PP_HR * PP_HC + 7) / 8;                     // 43 DMA items of 8 pixels x 128 bytes
+constexpr int PP_HALO = PP_ITEMS * 1024;                               // bytes per group
+constexpr int PP_STG = PP_PH * PP_PW * 128;                            // 32 KiB per group
+constexpr unsigned PP_LDS = 2u * PP_HALO + 2u * PP_STG + 256u;
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// the X segment's walk over (halo row rr, column shift cs, k step ks): rows 0 / 2 interleaved, row 1 | rows 5 / 3 interleaved, row 4
+struct PPStep {
+    int rr, cs, ks;
+};
+constexpr PPStep pp_step(int t) {
+    const int half = t / 36, u = t % 36;
+    const int idx = u < 24 ? u >> 1 : u - 24;
+    const int rr = half == 0 ? (u < 24 ? ((u & 1) ? 2 : 0) : 1) : (u < 24 ? ((u & 1) ? 3 : 5) : 4);
+    return PPStep{rr, idx >> 2, idx & 3};
+}
+// is step t the first one that accumulates into patch row m (its MFMA then takes C = 0)?
+constexpr bool pp_touches(int m, int t) { return pp_step(t).rr - m >= 0 && pp_step(t).rr - m <= 2; }
+constexpr bool pp_first(int m, int t) {
+    if (!pp_touches(m, t)) return false;
+    for (int u = 0; u < t; ++u)
+        if (pp_touches(m, u)) return false;
+    return true;
+}
+template <int V>
+struct PPInt {
+    static constexpr int value = V;
+};
+}  // namespace
+
+template <bool EPI, int XSPLIT>
+__global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmArgs a, const int npatch, const int prio) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    [[maybe_unused]] unsigned long long tk0 = 0, rk0 = 0, tl0 = 0, rl0 = 0;
+    if constexpr (abl::stamp) {
+        tk0 = __builtin_amdgcn_s_memtime();
+        rk0 = __builtin_amdgcn_s_memrealtime();
+    }
+    const TapPhase& P = a.ph[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 64;
+    char* const halo = smem + G * PP_HALO;
+    char* const stg = smem + 2 * PP_HALO + G * PP_STG;
+    float* const sbias = (float*)(smem + 2 * PP_HALO + 2 * PP_STG);
+
+    // patch ranges: group gi of 2 * gridDim.x walks [q0, q1); blocks that share an XCD (blockIdx.x % 8 equal) get neighbouring ranges
+    const int nb = gridDim.x;
+    const int bx = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int per = (npatch + 2 * nb - 1) / (2 * nb);
+    const int q0 = min(npatch, (2 * bx + G) * per), q1 = min(npatch, q0 + per);
+    const int ppr = a.wi / PP_PW, ppi = (a.hi / PP_PH) * ppr;
+
+    // ---- weights -> registers: A operand of v_mfma_f32_32x32x16_bf16, lane (r, h) holds row n0 + 32 wn + r, k = 16 ks + 8 h ... + 7
+    const bool flip = P.dh[0] > 0;                       // input-gradient launch: taps arrive as (1 - kh, 1 - kw)
+    f32x4 bw[9][4];
+    {
+        const bf16_t* wp = (const bf16_t*)a.w;
+        const int ncol = n0 + 32 * wn + r;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int wsl = flip ? P.widx[8 - u] : P.widx[u];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bw[u][ks] = *(const f32x4*)(wp + ((size_t)wsl * a.nout + ncol) * a.K + ks * 16 + h * 8);
+        }
+    }
+    if (tid < 64) sbias[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+
+    // ---- halo DMA of patch q into the group's image (header comment).  Full item (row j, segment w4): LDS halo + j * 4352 + w4 * 1024; lane =
+    // (pixel p8 = lane >> 3 of the segment, position lane & 7): halo column 8 w4 + p8, source chunk position ^ ((4 (w4 & 1) + (p8 >> 1)) & 7)
+    const unsigned pixb = (unsigned)a.ldx * 2u;
+    const unsigned imgb = (unsigned)(a.hi * a.wi) * pixb;
+    auto dma = [&](int q) {
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PP_PH, x0 = (prem % ppr) * PP_PW;
+        // rows above / below the image lie outside this descriptor (the offset wraps below zero or passes imgb): zeros
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((char*)a.x + (size_t)img * imgb, 0, imgb, 0x00020000);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                     // the lane constants are re-formed per patch, not kept across the MFMA segment
+        const int p8 = ln >> 3, pos = ln & 7;
+        const unsigned base = (unsigned)((y0 - 1) * a.wi + x0 - 1) * pixb;           // halo (0, 0); wraps below zero on the first row / column
+        const unsigned lc = base + (unsigned)(8 * w4 + p8) * pixb + (unsigned)((pos ^ ((4 * (w4 & 1) + (p8 >> 1)) & 7)) << 4);
+        // column -1 (segment 0, p8 = 0) of a patch on the left edge: the previous row's last pixel, not padding -> out of range by hand
+        const bool lcut = w4 == 0 && x0 == 0;            // wave-uniform
+        const unsigned rowb = (unsigned)a.wi * pixb;
+#pragma unroll
+        for (int j = 0; j < PP_HR; ++j) {
+            unsigned off = lc + (unsigned)j * rowb;
+            if (lcut) off = p8 == 0 ? 0xffffffffu : off;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(halo + j * (PP_HC * 128) + w4 * 1024), 16, (int)off, 0, 0, 0);
+        }
+        // tails: halo columns 32, 33 of rows w4, w4 + 4, w4 + 8 (sixteen lanes; chunk = position: ((32 + p8) >> 1) & 7 = 0)
+        if (ln < 16) {
+            const bool rcut = x0 + PP_PW == a.wi;        // column wi: the next row's first pixel
+            const unsigned lt = base + (unsigned)(32 + p8) * pixb + (unsigned)(pos << 4);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int hr = w4 + 4 * j;               // wave-uniform
+                if (j < 2 || hr < PP_HR) {
+                    const unsigned off = (rcut && p8 == 1) ? 0xffffffffu : lt + (unsigned)hr * rowb;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(halo + hr * (PP_HC * 128) + 4096), 16, (int)off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- fragment addresses: pixel (halo row 4 wm + rr, halo column r + cs), chunk (2 ks + h) ^ (((r + cs) >> 1) & 7); rr is an immediate, ks an XOR of bits 5-6
+    int fa[3];
+#pragma unroll
+    for (int cs = 0; cs < 3; ++cs) fa[cs] = G * PP_HALO + ((4 * wm * PP_HC) + r + cs) * 128 + ((h ^ (((r + cs) >> 1) & 7)) << 4);
+
+    const bool part0 = n0 < a.n1;                        // block-uniform: the 64 channels lie in one output part (launcher)
+    const __amdgpu_buffer_rsrc_t rsy = part0 ? __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2bytes, 0x00020000);
+    const unsigned ldyb = (unsigned)(part0 ? a.ldy : a.ldy2) * 2u;
+    const unsigned ycol0 = (unsigned)(part0 ? n0 : n0 - a.n1) * 2u;
+
+    // InstanceNorm statistics on the matrix pipe: wave w4 owns channel group cg = w4 of the group's patches, both sums.  The two 16 x 16 tiles
+    // live for one patch only; their diagonal (channel l15: register l15 & 3 of the lanes with (l15 >> 2) == lq) is folded into two
+    // per-lane floats that persist over the group's patches of an image (eight VALU per patch instead of eight registers across the X segment)
+    float s1acc = 0.f, s2acc = 0.f;
+    int simg = q0 / ppi;
+    auto flush = [&](int img) {
+        const int l15 = lane & 15, lq = lane >> 4;
+        if ((l15 >> 2) == lq) {
+            double* sp = a.stats + (size_t)((2 * blockIdx.x + G) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + n0 + 16 * w4 + l15) * 2;
+            atomicAdd(sp, (double)s1acc);
+            atomicAdd(sp + 1, (double)s2acc);
+        }
+        s1acc = 0.f;
+        s2acc = 0.f;
+    };
+
+    // timing-only build (abl::stamp, tools/probes/pp_stamps.py): cycles between the boundaries below, summed over the group's patches, per wave
+    [[maybe_unused]] unsigned long long tph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (abl::stamp) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (k >= 0) tph[k] += t - tlast;
+            tlast = t;
+        }
+    };
+    f32x16_t acc[4];
+    // X segment, steps [t0, t1) of the walk pp_step (72 steps; the first 36 are halo rows 0 - 2): the fragment of (halo row rr, column shift cs,
+    // k step ks) feeds patch rows m = rr - kh, kh = 0 .. 2.  Fragments are read two steps ahead; the sched_barriers pin "issue the read, then
+    // this step's MFMAs" (header comment)
+    auto xsteps = [&](auto T0, auto T1, auto DEPTH, auto&& pre, auto&& post) {
+        constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value, depth = decltype(DEPTH)::value;       // fragments in flight: 2 or 3
+        auto frag = [&](int t) {
+            const PPStep st = pp_step(t < t1 ? t : t1 - 1);
+            int b = fa[st.cs];
+            asm volatile("" : "+v"(b));          // keeps hipcc from holding all twelve (cs, ks) addresses in registers across the segment (254 are in use)
+            return *(const f32x4*)(smem + ((b ^ (st.ks << 5)) + st.rr * (PP_HC * 128)));
+        };
+        f32x4 f0 = frag(t0), f1 = frag(t0 + 1), f2 = f1;
+        if constexpr (depth == 3) f2 = frag(t0 + 2);
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+            const f32x4 fn = frag(t + depth);
+            pre(t);
+            __builtin_amdgcn_sched_barrier(0);
+            const PPStep st = pp_step(t);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kh = st.rr - m;
+                if (kh >= 0 && kh <= 2) {
+                    const f32x16_t c0 = pp_first(m, t) ? f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : acc[m];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[kh * 3 + st.cs][st.ks]), __builtin_bit_cast(bf16x8, f0), c0, 0, 0, 0);
+                }
+            }
+            post(t);
+            __builtin_amdgcn_sched_barrier(0);
+            f0 = f1;
+            if constexpr (depth == 3) {
+                f1 = f2;
+                f2 = fn;
+            } else {
+                f1 = fn;
+            }
+        }
+    };
+    auto nohook = [](int) {};
+
+    // hipcc cannot tell an LDS access from the destination of an LDS-DMA in flight: in front of every ds_read / ds_write that follows the halo DMA in
+    // program order it waits vmcnt(0) -- for the whole halo to land (the round-5 stamps: 3 200 cycles in front of the epilogue's first staging
+    // write, 4 500 with the DMA issue, against 2 600 for half an X segment).  The Y segment's LDS accesses behind the DMA issue (staging writes,
+    // staging reads of the store pass) are therefore inline asm with waits placed by hand; values read that way are threaded through the
+    // waiting asm ("+v"), so that no use is scheduled in front of it.  The bias vector is read BEFORE the DMA issue, as ordinary loads.
+    const int stg_a = 2 * PP_HALO + G * PP_STG;           // LDS byte address of the group's staging image (smem starts at 0: the only LDS object)
+    // Y segment, first half: next halo, epilogue of patch q into the staging image
+    auto yhead = [&](const int q) {
+        f32x4 b4[4];
+        if constexpr (EPI) {
+            int lb = lane;
+            asm volatile("" : "+v"(lb));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b4[g] = *(const f32x4*)(sbias + 32 * wn + 8 * g + 4 * (lb >> 5));
+        }
+        if (q + 1 < q1 && !(prio & 4)) dma(q + 1);             // prio bit 2: timing-only ablation (no halo DMA after the first)
+        stamp(4);                                // [4] bias reads + halo DMA issue
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int er = ln & 31, eh = ln >> 5;
+        const int st_w = stg_a + (4 * wm * 32 + er) * 128 + (((4 * wn) ^ (er & 7)) << 4) + (eh << 3);          // + m * 4096, chunk g: ^ (g << 4)
+        if (prio & 8) return;                    // timing-only ablation: no epilogue
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2_t pk[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x2 lo = {acc[m][4 * g], acc[m][4 * g + 1]}, hi = {acc[m][4 * g + 2], acc[m][4 * g + 3]};
+                if constexpr (EPI) {             // bias, LeakyReLU with 0 <= slope <= 1 (launcher): max(u, u * slope).  Scalar instructions on purpose (this
+                    // file is built with -fno-slp-vectorize): beside the partner wave's MFMAs a v_pk_add_f32 / v_pk_mul_f32 costs four times a v_add_f32
+                    lo = f32x2{shm_lrelu_max(lo.x + b4[g][0], a.slope), shm_lrelu_max(lo.y + b4[g][1], a.slope)};
+                    hi = f32x2{shm_lrelu_max(hi.x + b4[g][2], a.slope), shm_lrelu_max(hi.y + b4[g][3], a.slope)};
+                }
+                pk[m] = u32x2_t{__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
+            }
+            const int aw = st_w ^ (g << 4);
+            // patch rows m, m + 1 are 4096 bytes = 8 x (64 x 8 bytes) apart
+            asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:0 offset1:8" ::"v"(aw), "v"(pk[0]), "v"(pk[1]) : "memory");
+            asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:16 offset1:24" ::"v"(aw), "v"(pk[2]), "v"(pk[3]) : "memory");
+        }
+    };
+    // Y segment, second half: whole-line stores of the group's patch
+    auto ytail = [&](const int q) {
+        if (prio & 16) return;                   // timing-only ablation: no store pass
+        const int img = q / ppi, prem = q - img * ppi;
+        const int y0 = (prem / ppr) * PP_PH, x0 = (prem % ppr) * PP_PW;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int p8 = ln >> 3, c = ln & 7;
+        // store instruction i of wave w4 covers patch pixels 64 w4 + 8 i + p8 = row 2 w4 + (i >> 2), column 8 (i & 3) + p8
+        const int st_r = stg_a + (64 * w4 + p8) * 128 + ((c ^ p8) << 4);                        // + i * 1024
+        const unsigned yo = (unsigned)((img * a.hi + y0 + 2 * w4) * a.wi + x0 + p8) * ldyb + ycol0 + (unsigned)c * 16u;
+        u32x4 v[8];
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                     "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(st_r)
+                     : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // reads return in order: instruction i needs all but the 7 - i youngest
+            if (i == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 4) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            if (i == 6) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v[6]), "+v"(v[7]));
+            if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[7]));
+            __builtin_amdgcn_raw_buffer_store_b128(v[i], rsy, yo + (unsigned)((i >> 2) * a.wi + 8 * (i & 3)) * ldyb, 0, 2);       // nt: read next by another kernel
+        }
+    };
+    // InstanceNorm sums of the patch whose staging image is complete and not yet overwritten: the group's PREVIOUS patch, inside the first half of
+    // an X segment (the Y wave has no free slot on the matrix pipe: with the X wave ahead in the arbitration its sixteen MFMAs took 2 400
+    // cycles; as a block in front of the X steps they cost the X wave 1 100).  Interleaved: the two transposed reads of fragment f at step 2 f,
+    // its two MFMAs (mfma(F, F): diagonal = sum y^2; mfma(F, ones) = sum y) behind the main MFMAs of step 2 f + 2, the diagonals folded into the
+    // per-lane sums at step 17.  X1 has room for it: patch row 3's accumulator is not live before step 36.
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    auto tr_base = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int pix = ln >> 2, tp = ln & 3;             // transposed read: lane 4 q + p of group g supplies pixel 4 g + q, 8-byte piece p of the channel group
+        return (const unsigned short*)(stg + pix * 128 + (((2 * w4 + (tp >> 1)) ^ (pix & 7)) << 4) + ((tp & 1) << 3));
+    };
+    auto tr_frag = [&](const unsigned short* tb, int f) {
+        const s16x4_t f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tb + f * 2048));            // pixels 32 f + 4 g + q
+        const s16x4_t f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tb + f * 2048 + 1024));     // + 16
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto fold = [&](const f32x4& S1, const f32x4& S2) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int i = ln & 3;            // = l15 & 3
+        s1acc += i == 0 ? S1[0] : i == 1 ? S1[1] : i == 2 ? S1[2] : S1[3];
+        s2acc += i == 0 ? S2[0] : i == 1 ? S2[1] : i == 2 ? S2[2] : S2[3];
+    };
+    auto next_image = [&](const int img) {
+        if (img != simg) {
+            flush(simg);
+            simg = img;
+        }
+    };
+    auto xstats_tail = [&](const int img) {      // the group's last patch, after the loop
+        next_image(img);
+        const unsigned short* tb = tr_base();
+        f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const bf16x8 F = tr_frag(tb, f);
+            S2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F, F, S2, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F, ones, S1, 0, 0, 0);
+        }
+        fold(S1, S2);
+    };
+
+    // ---- prologue: first halo of both groups; group 1 then runs one segment (two barriers) behind group 0
+    if (q0 < q1) dma(q0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), as a builtin: visible to hipcc's wait tracker (see the end-of-Y wait)
+    SHM_LDS_BARRIER();
+    if (G == 1) {
+        SHM_LDS_BARRIER();
+        SHM_LDS_BARRIER();
+    }
+    const bool want_stats = EPI && a.stats != nullptr;       // block-uniform
+    if constexpr (abl::stamp) {
+        tl0 = __builtin_amdgcn_s_memtime();
+        rl0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int i = 0; i < per; ++i) {
+        const int q = q0 + i;
+        const bool act = q < q1;                 // group-uniform
+        // ===== X segment (the other group is in its Y segment)
+        stamp(-1);
+        if (act) {
+            if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
+            bool st = false;
+            if constexpr (EPI) st = want_stats && i > 0;
+            if (st) {
+                if constexpr (EPI) {
+                    next_image((q - 1) / ppi);
+                    const unsigned short* tb = tr_base();
+                    bf16x8 Fa = ones, Fb = ones;             // fragment in use / fragment in flight
+                    f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = {0.f, 0.f, 0.f, 0.f};
+                    xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<2>{},
+                           [&](int t) {
+                               if (t <= 16 && (t & 1) == 0) {
+                                   Fa = Fb;
+                                   if (t < 16) Fb = tr_frag(tb, t >> 1);
+                               }
+                           },
+                           [&](int t) {
+                               if (t >= 2 && t <= 16 && (t & 1) == 0) {
+                                   S2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, Fa, S2, 0, 0, 0);
+                                   S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, ones, S1, 0, 0, 0);
+                               }
+                               if (t == 17) fold(S1, S2);
+                           });
+                }
+            } else {
+                xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<3>{}, nohook, nohook);
+            }
+        }
+        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
+        stamp(0);                                // [0] first half of the MFMA steps
+        SHM_LDS_BARRIER();
+        stamp(1);                                // [1] wait at the mid-X barrier (= the other group's staging barrier)
+        if (act) {
+            xsteps(PPInt<XSPLIT>{}, PPInt<72>{}, PPInt<3>{}, nohook, nohook);
+            if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
+        }
+        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        stamp(2);                                // [2] second half
+        SHM_LDS_BARRIER();                       // every wave of the group has read its last fragment: the halo image may be refilled
+        stamp(3);                                // [3] wait at the end-of-X barrier
+        // ===== Y segment (the other group is in its X segment).  One branch around the whole segment, barriers included (s_barrier counts arrivals,
+        // not program addresses): with yhead and ytail under separate `if (act)` hipcc's wait tracker sees a path "DMA issued, stores skipped",
+        // on which vmcnt(8) does not cover the DMA, and drains vmcnt(0) in front of the next LDS read
+        if (act) {
+            if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(1);
+            yhead(q);
+            stamp(9);                            // [9] epilogue + staging writes
+            SHM_LDS_BARRIER();                   // the staging image of patch q is complete
+            stamp(5);                            // [5] wait at the staging barrier
+            ytail(q);
+            stamp(6);                            // [6] staging reads + stores
+            // the next halo's items were issued in yhead; younger: this tail's eight stores.  The BUILTIN wait (vmcnt(8), nothing else): hipcc's wait
+            // tracker sees it and knows the halo DMA has landed -- behind an inline-asm wait it would drain the stores too (vmcnt(0)) in front of
+            // the next X segment's first fragment read
+            __builtin_amdgcn_s_waitcnt(0x0F78);
+            if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(0);
+            stamp(7);                            // [7] wait for the next halo
+            SHM_LDS_BARRIER();                   // the group's next halo has landed for all four waves
+            stamp(8);                            // [8] wait at the end-of-Y barrier
+        } else {
+            SHM_LDS_BARRIER();
+            SHM_LDS_BARRIER();
+        }
+    }
+    if (G == 0) {
+        SHM_LDS_BARRIER();
+        SHM_LDS_BARRIER();
+    }
+    if constexpr (EPI)
+        if (want_stats && q0 < q1) {
+            xstats_tail((q1 - 1) / ppi);
+            flush(simg);
+        }
+    if constexpr (abl::stamp)
+        if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0 && a.bias) {
+            unsigned* dump = (unsigned*)a.bias + 64;          // behind the 64 bias values (the probe passes a longer buffer)
+#pragma unroll
+            for (int k = 0; k < 11; ++k) dump[wave * 16 + k] = (unsigned)tph[k];
+            dump[wave * 16 + 11] = (unsigned)(q1 - q0);
+            const unsigned long long te = __builtin_amdgcn_s_memtime(), re = __builtin_amdgcn_s_memrealtime();
+            dump[wave * 16 + 12] = (unsigned)(tl0 - tk0);          // cycles before the loop
+            dump[wave * 16 + 13] = (unsigned)(te - tl0);           // cycles of the loop and the tail
+            dump[wave * 16 + 14] = (unsigned)(rl0 - rk0);          // the same in 10 ns ticks
+            dump[wave * 16 + 15] = (unsigned)(re - rl0);
+        }
+}
+
+int shm_pp_eligible(const TapGemmArgs& a) {
+    return a.K == 64 && a.x2 == nullptr && a.hi % PP_PH == 0 && a.wi % PP_PW == 0 && a.nout % 64 == 0 && (a.y2 == nullptr || a.n1 % 64 == 0) && a.ybytes != 0 &&
+           (a.y2 == nullptr || a.y2bytes != 0) && (size_t)a.hi * a.wi * a.ldx * 2 < (size_t)1 << 31 && a.slope >= 0.f && a.slope <= 1.f;
+}
+
+int shm_pp_launch(const TapGemmArgs& a, int batch, int ncu, hipStream_t st, const char* who) {
+    const int npatch = batch * (a.hi / PP_PH) * (a.wi / PP_PW), nyw = a.nout / 64;
+    int gx = ncu / nyw;                  // one eight-wave block per CU
+    if (gx < 1) gx = 1;
+    if (gx > (npatch + 1) / 2) gx = (npatch + 1) / 2;
+    const bool epi = a.slope != 1.f || a.stats != nullptr || a.bias != nullptr;
+    // wave priority: 0 none, 1 the X (MFMA) segment, 2 the Y segment; the X step behind which the staging barrier sits (SHM_PP_PRIO, SHM_PP_SPLIT,
+    // read once: A/B switches of the round-5 measurements)
+    static const int prio = [] {
+        const char* e = getenv("SHM_PP_PRIO");
+        return e ? atoi(e) : 0;
+    }();
+    static const int split = [] {
+        const char* e = getenv("SHM_PP_SPLIT");
+        return e ? atoi(e) : 36;
+    }();
+    hipError_t att = hipSuccess;
+#define PP_LAUNCH(EPI_, XS_)                                                                                                            \
+    do {                                                                                                                                \
+        static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_pp_bf16_kernel<EPI_, XS_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
+        att = at_;                                                                                                                      \
+        if (att == hipSuccess) hipLaunchKernelGGL((tapgemm_pp_bf16_kernel<EPI_, XS_>), dim3(gx, nyw, 1), dim3(512), PP_LDS, st, a, npatch, prio); \
+    } while (0)
+    if (epi) {
+        if (split == 48) PP_LAUNCH(true, 48);
+        else if (split == 56) PP_LAUNCH(true, 56);
+        else PP_LAUNCH(true, 36);
+    } else {
+        if (split == 48) PP_LAUNCH(false, 48);
+        else if (split == 56) PP_LAUNCH(false, 56);
+        else PP_LAUNCH(false, 36);
+    }
+#undef PP_LAUNCH
+    SHM_REQUIRE(att == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, PP_LDS, hipGetErrorString(att));
+    shm_set_last_kernel("tapgemm_pp_bf16_kernel<%s>", epi ? "true" : "false");
+    return SHM_OK;
+}

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void conv3x3s2_rgb_fwd_kernel(const RgbFwdArgs
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float u0 = shm_lrelu_max(acc[j][2 * h], a.slope), u1 = shm_lrelu_max(acc[j][2 * h + 1], a.slope);
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[h]) : "v"(u0), "v"(u1));
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    pk[h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{u0, u1}), bf16x2_));           // one v_cvt_pk_bf16_f32
                     const float v0 = __uint_as_float(pk[h] << 16), v1 = __uint_as_float(pk[h] & 0xffff0000u);       // the values as stored
                     s1[j][2 * h] += v0;
                     s2[j][2 * h] = __builtin_fmaf(v0, v0, s2[j][2 * h]);

@@ -55,7 +55,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.interleave", "SHM_ELEM_INTERLEAVE", 1, 0, 1},
     {"elem.stream_blocks", "SHM_ELEM_STREAM_BLOCKS", 32768, 256, 1 << 20},
     {"elem.apply_blocks", "SHM_ELEM_APPLY_BLOCKS", 4096, 256, 1 << 20},
-    {"tapgemm.wreg16", "SHM_TAPGEMM_WREG16", 1, 0, 1},
+    {"tapgemm.wreg16", "SHM_TAPGEMM_WREG16", 2, 0, 2},
     {"wgrad.bf16_wide", "SHM_WGRAD_BF16_WIDE", 0, 0, 4},
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
 };

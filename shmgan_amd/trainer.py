@@ -147,6 +147,17 @@ class ShmGANwithSSpecSeg:
             self._ws = torch.empty(max(n, 32 << 20), dtype=torch.float32, device=self.device)
         return self._ws
 
+    def release(self):
+        """Drop every device buffer this trainer holds (arena, split-K workspace, both models and their optimizer state) so that
+        another trainer can be built in the same process (bench.py's extra configurations); the object is unusable afterwards."""
+        if self._lane is not None:
+            self._lane.join()
+        torch.cuda.synchronize(self.device)
+        self.arena.t.clear()
+        self._ws = self._prefetched = self._loss_cache = None
+        self.G = self.D = self.SpecSeg = None
+        self.specular_candidate = None
+
     def _get_lane(self):
         import os
         if self._lane is None:

@@ -28,7 +28,7 @@ SYMBOL = {
     "dma256x128": "tapgemm_dma_kernel<{t}, {t}, 256, 128, 4, 2, 3, 16>",
     "dma128x128_bk32": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 2, 32>",
     "dma128x128_nst4": "tapgemm_dma_kernel<{t}, {t}, 128, 128, 2, 2, 4, 16>",
-    "wreg": "tapgemm_wreg16_bf16_kernel<{nch}>",                            # bf16: the eight-wave kernel with line-wide stores ("tapgemm.wreg16", default on)
+    "wreg": "tapgemm_wreg16_bf16_kernel<{nch}, {epi}>",                            # bf16: the eight-wave kernel with line-wide stores ("tapgemm.wreg16", default on)
     "wreg4": "tapgemm_wreg_kernel<{t}, {nch}>",                             # ... and the four-wave form with 32-column wave tiles
     "halo128_st": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 2>", "halo64_st": "tapgemm_halo_kernel<{t}, {t}, 64, 16, true, 2>",
     "phase4": "tapgemm_phase4_kernel<{t}, {t}>", "halo128_st_w4": "tapgemm_halo_kernel<{t}, {t}, 128, 16, true, 4>",
@@ -48,11 +48,17 @@ def _reset_tuning():
     _ops().set_tuning("reset", 0)
 
 
-def _sym(variant, dt, nch=2):
+def _sym(variant, dt, nch=2, epi=True, hw=None):
+    """epi: the launch has an activation or fused statistics (forward); False = the plain input-gradient form (round 5: tapgemm_wreg16_bf16_kernel<NCH, EPI>).
+    hw = (height, width) of the map: under "tapgemm.wreg16" = 2 (the default) a 64-input-channel bf16 layer on a map of whole 8 x 32-pixel
+    patches takes the ping-pong kernel (conv_pingpong.hip)."""
     if variant == "wreg" and dt == "f32":
         return f"tapgemm_wreg_f32_kernel<{int(2 * nch)}, 4, false>"          # 16-channel chunks, four N waves, one source
     nch = int(nch)
-    return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch)
+    if variant == "wreg" and SYMBOL["wreg"].startswith("tapgemm_wreg16") and nch == 2 and hw is not None and hw[0] % 8 == 0 and hw[1] % 32 == 0 \
+            and _ops().get_tuning("tapgemm.wreg16") == 2:
+        return f"tapgemm_pp_bf16_kernel<{'true' if epi else 'false'}>"
+    return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch, epi="true" if epi else "false")
 
 
 def _dev(a, dt):
@@ -103,7 +109,7 @@ def _fwd_case(variant, dt, n, h, c1, c2, cout, k, s, seed=0):
     ops.conv2d_in_fwd(_dev(xa, dt), None if xb is None else _dev(xb, dt), c1 if c2 else 0, c1, c2, _wk(w, cin, dt),
                       torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, h, h, cin, cout, k, s, 0.2, stats, 1e-6, scratch=scr)
     torch.cuda.synchronize()
-    assert ops.last_kernel() == _sym(variant, dt, cin / 32), ops.last_kernel()
+    assert ops.last_kernel() == _sym(variant, dt, cin / 32, hw=(h, h)), ops.last_kernel()
     got = host(y.float())
     assert rel_l2(got, ref) < TOL[dt], (variant, dt, rel_l2(got, ref))
     if (ho * ho) % 64 == 0:                   # the fused path (smaller maps take a separate statistics pass)
@@ -182,6 +188,46 @@ def test_wreg_forced_variant(dt, n, h, cin, cout):
     if dt == "f32" and cin == 32:
         cin = 16
     _fwd_case("wreg", dt, n, h, cin, 0, cout, 3, 1, seed=3)
+    if dt == "bf16":                          # "tapgemm.wreg16" = 1: tapgemm_wreg16_bf16_kernel on the shapes the ping-pong kernel takes by default
+        _ops().set_tuning("tapgemm.wreg16", 1)
+        _fwd_case("wreg", dt, n, h, cin, 0, cout, 3, 1, seed=3)
+
+
+# ---- the ping-pong kernel (conv_pingpong.hip; "tapgemm.wreg16" = 2, default): 64 input channels, maps of whole 8 x 32-pixel patches
+@pytest.mark.parametrize("n,hi,wi,cout,slope", [
+    (3, 16, 32, 64, 0.2),         # two patches per image, one above the other: every halo column of the map is padding
+    (5, 48, 64, 128, 0.2),        # 12 patches per image, two channel blocks, groups that cross image boundaries (statistics flush)
+    (2, 32, 96, 64, 0.0),         # interior patches with neighbours on every side, ReLU
+    (9, 16, 32, 192, 1.0),        # two patches per image, more groups than patches on a 256-CU grid, no activation (bias + statistics only)
+    (40, 64, 64, 64, 0.2),        # 640 patches on 512 groups: uneven ranges
+])
+def test_pingpong_forward_with_statistics(n, hi, wi, cout, slope):
+    ops = _ops()
+    rng = np.random.default_rng(200 + n)
+    cin = 64
+    x = rng.standard_normal((n, hi, wi, cin))
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    ref = conv_ref(_rnd(x, "bf16"), _rnd(w, "bf16"), 1) + b
+    ref = np.where(ref > 0, ref, slope * ref)
+    y = torch.full((n, hi, wi, cout), 9.0, device="cuda", dtype=BF)
+    stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+    ops.set_tuning("tapgemm.variant", "wreg")
+    for rep in range(2):                      # the second call finds the statistics scratch as the first one left it (zero on return)
+        ops.conv2d_in_fwd(_dev(x, "bf16"), None, 0, cin, 0, _wk(w, cin, "bf16"), torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, hi, wi, cin, cout, 3, 1,
+                          slope, stats, 1e-6, scratch=scr)
+        torch.cuda.synchronize()
+        assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<true>", ops.last_kernel()
+        got = host(y.float())
+        assert rel_l2(got, ref) < TOL["bf16"], rel_l2(got, ref)
+        if (hi * wi) % 64 == 0:
+            _check_stats(stats, got, n, cout, "bf16")
+        y.fill_(9.0)
+    # the same product without bias, activation or statistics is the EPI = false instantiation
+    ops.conv2d_fwd(_dev(x, "bf16"), None, 0, cin, 0, _wk(w, cin, "bf16"), None, y, cout, n, hi, wi, cin, cout, 3, 1, 1.0)
+    assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<false>", ops.last_kernel()
+    assert rel_l2(host(y.float()), conv_ref(_rnd(x, "bf16"), _rnd(w, "bf16"), 1)) < TOL["bf16"]
 
 
 # ---- "tapgemm.wreg16" = 0: the four-wave bf16 form with 32-column wave tiles (the default is the eight-wave form, test_wreg_forced_variant)
@@ -197,7 +243,7 @@ def test_wreg_four_wave_bf16(n, h, cin, cout):
         SYMBOL["wreg"] = sym
 
 
-@pytest.mark.parametrize("dt,wreg16", [("f32", 1), ("bf16", 1), ("bf16", 0)])
+@pytest.mark.parametrize("dt,wreg16", [("f32", 1), ("bf16", 2), ("bf16", 1), ("bf16", 0)])
 def test_wreg_kernels_keep_a_nan_a_nan(dt, wreg16):
     """Round-3 advisor finding: the two-instruction LeakyReLU of the weights-in-registers kernels (common.h: shm_lrelu_max) was
     v_med3(u, u * slope, FLT_MAX), which turns a NaN MFMA result into FLT_MAX -- a diverged activation became a finite number
@@ -217,7 +263,7 @@ def test_wreg_kernels_keep_a_nan_a_nan(dt, wreg16):
     ops.set_tuning("tapgemm.variant", "wreg")
     ops.conv2d_in_fwd(_dev(x, dt), None, 0, cin, 0, _wk(w, cin, dt), torch.from_numpy(b).cuda(), y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
     torch.cuda.synchronize()
-    assert ops.last_kernel().startswith("tapgemm_wreg"), ops.last_kernel()
+    assert ops.last_kernel().startswith("tapgemm_pp" if wreg16 == 2 else "tapgemm_wreg"), ops.last_kernel()
     got = host(y.float())
     bad = np.isnan(got)
     want = np.zeros_like(bad)
@@ -317,11 +363,13 @@ def test_dma_forced_variant_other_shapes(variant, dt, n, h, c1, c2, cout, k, s):
 
 # ---- input gradient (flipped taps / four stride-2 phases, split destination) under forced variants
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "wreg"])
+@pytest.mark.parametrize("variant", HALO + ["dma128x128", "dma64x128", "dma128x64", "dma64x64", "dma256x64", "dma256x128", "wreg", "wreg_pp"])
 def test_dgrad_s1_forced_variant(variant, dt):
     ops = _ops()
     rng = np.random.default_rng(7)
     n, h, c1, c2, cout = 2, 16, 64, 64, 64              # dx split into (upsampled, skip) parts: n1 = 64
+    if variant == "wreg_pp":                             # a 32 x 32 map: the bf16 launch takes the ping-pong kernel
+        variant, n, h = "wreg", 3, 32
     cin = c1 + c2
     w = rng.standard_normal((3, 3, cin, cout)) * 0.1
     dy = rng.standard_normal((n, h, h, cout))
@@ -333,7 +381,7 @@ def test_dgrad_s1_forced_variant(variant, dt):
     d2 = torch.full((n, h, h, c2), 7.0, device="cuda", dtype=adt)
     ops.set_tuning("tapgemm.variant", variant)
     ops.conv2d_dgrad(_dev(dy, dt), cout, _dev(w, dt), d1, d2, c1, c1, c2, n, h, h, cin, cout, 3, 1)
-    assert ops.last_kernel() == _sym(variant, dt)
+    assert ops.last_kernel() == _sym(variant, dt, epi=False, hw=(h, h))
     if variant == "wreg" and dt == "bf16":    # the same product with the gradient signal leaving in fp32 (SHM_BF16_GF32)
         f1 = torch.full((n, h, h, c1), 7.0, device="cuda")
         f2 = torch.full((n, h, h, c2), 7.0, device="cuda")

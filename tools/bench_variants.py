@@ -28,6 +28,17 @@ shapes = shapes or [(40, 256, 64, 64), (8, 256, 64, 64), (40, 128, 128, 128)]
 variants = variants or ["auto", "wreg", "halo64", "halo128", "dma128x64", "dma128x128", "dma64x128", "dma256x64"]
 ROUNDS, REPS = 5, 4
 
+
+def force(v):
+    """a variant name, or "knob:value" = automatic dispatch with tapgemm.<knob> set (e.g. wreg16:1 / wreg16:2: the two bf16 weights-in-registers kernels)"""
+    ops.set_tuning("reset", 0)
+    if ":" in v:
+        k, val = v.split(":")
+        ops.set_tuning("tapgemm." + k, int(val))
+    else:
+        ops.set_tuning("tapgemm.variant", v)
+
+
 for dtn in dts:
     dt = torch.bfloat16 if dtn == "bf16" else torch.float32
     es = 2 if dtn == "bf16" else 4
@@ -50,7 +61,7 @@ for dtn in dts:
         for cname, fn in calls.items():
             ok, times, syms = [], {}, {}
             for v in variants:
-                ops.set_tuning("tapgemm.variant", v)
+                force(v)
                 try:
                     fn()
                     torch.cuda.synchronize()
@@ -61,7 +72,7 @@ for dtn in dts:
                     pass
             for _ in range(ROUNDS):
                 for v in ok:
-                    ops.set_tuning("tapgemm.variant", v)
+                    force(v)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(REPS):
