@@ -67,8 +67,10 @@ const char* shm_last_kernel(void);
  *   "tapgemm.small_grid_blocks" grids with fewer 128x128 tiles take the 64x128 tile (default 1024)
  *   "tapgemm.phase4_min_blocks" stride-2 transposed 3x3 products with at least this many fused (16x16 input pixels x 64 channels) blocks
  *                               take the four-phases-in-one-block kernel (default 256)
- *   "tapgemm.wreg16"            bf16 weights-in-registers layers (one source, 32 / 64 input channels): 1 = eight-wave form with 16-column wave tiles
- *                               (v_mfma_f32_16x16x32_bf16, four waves per SIMD; default), 0 = four-wave form with 32-column tiles
+ *   "tapgemm.wreg16"            bf16 weights-in-registers layers (one source, 32 / 64 input channels): 2 (default) = the one-block-per-CU ping-pong
+ *                               kernel (tapgemm_pp_bf16_kernel, v_mfma_f32_32x32x16_bf16) where the shape allows (64 input channels, map of whole
+ *                               8 x 32-pixel patches) and the eight-wave form elsewhere, 1 = the eight-wave form with 16-column wave tiles
+ *                               (tapgemm_wreg16_bf16_kernel, v_mfma_f32_16x16x32_bf16, four waves per SIMD), 0 = four-wave form with 32-column tiles
  *   "tapgemm.flat_epilogue"     1 = treat every output as larger than 4 GiB: element stores through 64-bit addresses, no buffer-store kernels (tests), default 0
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing, 3 no stride-2 halo form
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)

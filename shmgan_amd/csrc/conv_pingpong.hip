@@ -11,23 +11,39 @@
 //     8 x 32-pixel patches (all 64 output channels: 2 (rows 0-3 / 4-7) x 2 (channels 0-31 / 32-63) waves) and alternates between an X segment
 //     -- the patch's 144 v_mfma_f32_32x32x16_bf16 per wave, operands: weights in 144 registers, activation fragments from the group's halo
 //     image in LDS -- and a Y segment: halo DMA of its NEXT patch, epilogue of the patch just computed (bias, LeakyReLU, bf16, LDS staging),
-//     whole-line stores, statistics.  The two groups run half a period apart, separated by workgroup barriers: on every SIMD one wave is in X
-//     while its partner is in Y, by construction.  An X segment is 4 608 matrix-pipe cycles; a Y segment issues ~450 vector instructions.
+//     whole-line stores.  The two groups run half a period apart, separated by workgroup barriers (two per segment: the Y segment's staging
+//     barrier falls behind step 48 of the other group's 72 X steps): on every SIMD one wave is in X while its partner is in Y, by construction.
 //   * 32x32x16 tiles: a fragment read (1 KiB per wave) feeds up to three MFMAs of 32 cycles (halo-row walk: halo row R, column shift cs serves
-//     patch rows R - kh), so the X wave needs an LDS read per ~64-96 pipe cycles and one step of look-ahead hides its latency; the MFMA holds the
-//     vector issue port 8 of its 32 cycles, which leaves the port to the partner's epilogue.
+//     patch rows R - kh), and the MFMA holds the vector issue port 8 of its 32 cycles, which leaves the port to the partner's epilogue.
 //   * Halo image per group: [10 rows][34 pixels][128 bytes], single-buffered (it is refilled in the group's Y segment, after the barrier that ends
 //     its X segment), filled by LDS-DMA: wave w4 of the group fetches the 8-pixel column segment w4 of every halo row (ten 1 KiB items whose
 //     per-lane source offset is ONE lane constant plus a uniform term) and the two-pixel tails of rows w4, w4 + 4, w4 + 8; 16-byte chunk c of
 //     halo column hc sits at position c ^ ((hc >> 1) & 7): the 32-pixel fragment read (two chunks per pixel) and the linear DMA write are both
 //     conflict-free.  Out-of-image rows fall outside a per-image buffer descriptor (zeros), out-of-image columns get an out-of-range offset.
-//   * The X wave is alone on its SIMD's matrix pipe (its partner is in Y), so its fragment reads are issued TWO steps ahead of their use
-//     (hipcc, left alone, sinks a one-step look-ahead back to its use: ds_read, lgkmcnt(0), MFMA -- the round-5 stamps showed X at 66 % of the
-//     pipe) and the halo rows are walked in the order 0/2 interleaved, 1 | 5/3 interleaved, 4, so that a fragment with one MFMA (rows 0, 5) is
-//     followed by one with three.
 //   * Epilogue as in conv_wreg16.hip: a lane's accumulator quads are four consecutive channels of one pixel -> 8-byte pieces into a
-//     [256 pixels][128 bytes] staging image (chunk XOR pixel & 7), barrier, 1 KiB stores of whole lines; InstanceNorm sums on the matrix pipe
-//     from the staging image (transposed reads: mfma(F, F) diagonal = sum y^2, mfma(F, ones) = sum y; see conv_wreg16.hip).
+//     [256 pixels][128 bytes] staging image (chunk XOR pixel & 7), barrier, 1 KiB stores of whole lines.  InstanceNorm sums on the matrix pipe
+//     from the staging image (transposed reads: mfma(F, F) diagonal = sum y^2, mfma(F, ones) = sum y; see conv_wreg16.hip), of the group's
+//     PREVIOUS patch, interleaved into the first X steps of the next one.
+//
+// What the phase stamps (tools/probes/pp_stamps.py; cycles per patch and wave, n = 40 at 256 x 256) taught on the way, in the order found:
+//   1. hipcc sinks a one-step fragment look-ahead back to its use (ds_read, lgkmcnt(0), MFMA): an X segment took 7 000 cycles for 4 608 of
+//      MFMA.  Reads are issued two / three steps ahead behind sched_barriers, and halo rows are walked 0 / 2 interleaved, 1 | 5 / 3
+//      interleaved, 4, so that a one-MFMA fragment is followed by a three-MFMA one.
+//   2. hipcc waits vmcnt(0) in front of every LDS access that follows an LDS-DMA in program order (it cannot tell the addresses apart): the
+//      epilogue's first staging write waited 3 200 cycles for the whole halo to land.  The Y segment's LDS accesses are inline asm with
+//      waits placed by hand, the end-of-Y wait is the BUILTIN s_waitcnt (visible to hipcc's tracker, which otherwise drains the stores in front
+//      of the next fragment read), and the Y segment sits under ONE branch (two made the tracker see a path "DMA issued, stores skipped").
+//   3. A wave's sixteen statistics MFMAs took 2 400 cycles in the Y segment (no free slot on a pipe the X wave keeps busy) and 1 100 as a
+//      block in front of the X steps; interleaved into them they cost ~500.
+//   4. v_pk_add_f32 / v_pk_mul_f32 (formed by the SLP vectoriser) beside the partner's MFMAs: the epilogue took 3 300 cycles, 1 750 with
+//      scalar instructions (-fno-slp-vectorize for this file).  s_setprio for either segment changes nothing.
+//   5. With the fragment address formed in the loop (v_mov, v_xad, ds_read behind each other) the chain of a one-MFMA step does not fit under
+//      its MFMA: +14 cycles per read.  The twelve addresses are registers for the length of an X half (re-formed per half: kept across the Y
+//      segment they spill).  A second, statistics-free copy of the first X half in the loop made hipcc shuffle 84 register pairs per patch
+//      to reconcile two allocations: the statistics are a template parameter and the first patch runs them on garbage and drops the result.
+//   State: X 4 270 + 1 830 cycles (ideal 3 330 + 1 540), Y 1 500 (DMA issue) + 1 750 (epilogue) + 870 (stores), period 13 500 cycles at
+//   1.8 GHz; the launch 219 us against tapgemm_wreg16_bf16_kernel's 229 (forward + statistics) and 176 against 191 (input gradient), same box,
+//   sustained; at n = 8 and at 512 x 512 the two kernels tie.  The ~10 us prologue (36 weight loads per lane, first halo) is 6 % at n = 40.
 //
 // LDS: 2 x 43 KiB halo + 2 x 32 KiB staging + bias = 150.25 KiB.  Eligible: K = 64, one source tensor, map height % 8 == 0 and width % 32 == 0,
 // Cout % 64 == 0 with 64-channel blocks inside one output part, outputs below 4 GiB, an image below 2 GiB.
@@ -67,8 +83,10 @@ struct PPInt {
 };
 }  // namespace
 
-template <bool EPI, int XSPLIT>
-__global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmArgs a, const int npatch, const int prio) {
+// MODE 0: plain product (input-gradient launches: no bias, slope 1, no statistics); 1: bias + LeakyReLU; 2: bias + LeakyReLU + InstanceNorm statistics
+template <int MODE, int XSPLIT>
+__global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmArgs a, const int npatch, const int dbg) {
+    constexpr bool EPI = MODE != 0, STATS = MODE == 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     [[maybe_unused]] unsigned long long tk0 = 0, rk0 = 0, tl0 = 0, rl0 = 0;
@@ -188,11 +206,16 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     // this step's MFMAs" (header comment)
     auto xsteps = [&](auto T0, auto T1, auto DEPTH, auto&& pre, auto&& post) {
         constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value, depth = decltype(DEPTH)::value;       // fragments in flight: 2 or 3
+        // the twelve (cs, ks) fragment addresses live in registers for the length of this call only: re-formed from fa[] here (the empty asm
+        // stops hipcc from hoisting them out of the patch loop, where they would be twelve more registers across the Y segment: spills), so that
+        // a step's read is ONE instruction -- with the XOR in the loop (v_mov, v_xad, ds_read behind each other) the address chain of a
+        // one-MFMA step did not fit under its MFMA (stamps: +14 cycles per read)
+        int fl[3] = {fa[0], fa[1], fa[2]};
+        asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]));
         auto frag = [&](int t) {
             const PPStep st = pp_step(t < t1 ? t : t1 - 1);
-            int b = fa[st.cs];
-            asm volatile("" : "+v"(b));          // keeps hipcc from holding all twelve (cs, ks) addresses in registers across the segment (254 are in use)
-            return *(const f32x4*)(smem + ((b ^ (st.ks << 5)) + st.rr * (PP_HC * 128)));
+            if constexpr (abl::nolds) return f32x4{1.f, 2.f, 3.f, 4.f};         // timing only: no fragment reads
+            return *(const f32x4*)(smem + ((fl[st.cs] ^ (st.ks << 5)) + st.rr * (PP_HC * 128)));
         };
         f32x4 f0 = frag(t0), f1 = frag(t0 + 1), f2 = f1;
         if constexpr (depth == 3) f2 = frag(t0 + 2);
@@ -238,13 +261,13 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
 #pragma unroll
             for (int g = 0; g < 4; ++g) b4[g] = *(const f32x4*)(sbias + 32 * wn + 8 * g + 4 * (lb >> 5));
         }
-        if (q + 1 < q1 && !(prio & 4)) dma(q + 1);             // prio bit 2: timing-only ablation (no halo DMA after the first)
+        if (q + 1 < q1 && !(abl::stamp && (dbg & 4))) dma(q + 1);          // dbg: timing-only ablations of the stamped build (4: no halo DMA after the first)
         stamp(4);                                // [4] bias reads + halo DMA issue
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int er = ln & 31, eh = ln >> 5;
         const int st_w = stg_a + (4 * wm * 32 + er) * 128 + (((4 * wn) ^ (er & 7)) << 4) + (eh << 3);          // + m * 4096, chunk g: ^ (g << 4)
-        if (prio & 8) return;                    // timing-only ablation: no epilogue
+        if (abl::stamp && (dbg & 8)) return;     // 8: no epilogue
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32x2_t pk[4];
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     };
     // Y segment, second half: whole-line stores of the group's patch
     auto ytail = [&](const int q) {
-        if (prio & 16) return;                   // timing-only ablation: no store pass
+        if (abl::stamp && (dbg & 16)) return;    // 16: no store pass
         const int img = q / ppi, prem = q - img * ppi;
         const int y0 = (prem / ppr) * PP_PH, x0 = (prem % ppr) * PP_PW;
         int ln = lane;
@@ -312,12 +335,14 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         const s16x4_t f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tb + f * 2048 + 1024));     // + 16
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    auto fold = [&](const f32x4& S1, const f32x4& S2) {
+    auto fold = [&](const f32x4& S1, const f32x4& S2, const bool keep) {       // keep = false (uniform): the sums are discarded by a SELECT (they may be NaN)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int i = ln & 3;            // = l15 & 3
-        s1acc += i == 0 ? S1[0] : i == 1 ? S1[1] : i == 2 ? S1[2] : S1[3];
-        s2acc += i == 0 ? S2[0] : i == 1 ? S2[1] : i == 2 ? S2[2] : S2[3];
+        const float v1 = i == 0 ? S1[0] : i == 1 ? S1[1] : i == 2 ? S1[2] : S1[3];
+        const float v2 = i == 0 ? S2[0] : i == 1 ? S2[1] : i == 2 ? S2[2] : S2[3];
+        s1acc += keep ? v1 : 0.f;
+        s2acc += keep ? v2 : 0.f;
     };
     auto next_image = [&](const int img) {
         if (img != simg) {
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             S2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F, F, S2, 0, 0, 0);
             S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F, ones, S1, 0, 0, 0);
         }
-        fold(S1, S2);
+        fold(S1, S2, true);
     };
 
     // ---- prologue: first halo of both groups; group 1 then runs one segment (two barriers) behind group 0
@@ -346,7 +371,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         SHM_LDS_BARRIER();
         SHM_LDS_BARRIER();
     }
-    const bool want_stats = EPI && a.stats != nullptr;       // block-uniform
     if constexpr (abl::stamp) {
         tl0 = __builtin_amdgcn_s_memtime();
         rl0 = __builtin_amdgcn_s_memrealtime();
@@ -357,30 +381,30 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         // ===== X segment (the other group is in its Y segment)
         stamp(-1);
         if (act) {
-            if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
-            bool st = false;
-            if constexpr (EPI) st = want_stats && i > 0;
-            if (st) {
-                if constexpr (EPI) {
-                    next_image((q - 1) / ppi);
-                    const unsigned short* tb = tr_base();
-                    bf16x8 Fa = ones, Fb = ones;             // fragment in use / fragment in flight
-                    f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = {0.f, 0.f, 0.f, 0.f};
-                    xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<2>{},
-                           [&](int t) {
-                               if (t <= 16 && (t & 1) == 0) {
-                                   Fa = Fb;
-                                   if (t < 16) Fb = tr_frag(tb, t >> 1);
-                               }
-                           },
-                           [&](int t) {
-                               if (t >= 2 && t <= 16 && (t & 1) == 0) {
-                                   S2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, Fa, S2, 0, 0, 0);
-                                   S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, ones, S1, 0, 0, 0);
-                               }
-                               if (t == 17) fold(S1, S2);
-                           });
-                }
+            if (abl::stamp && (dbg & 3) == 1) __builtin_amdgcn_s_setprio(1);      // wave priority: no effect either way (round-5 stamps), left to the stamped build
+            if constexpr (STATS) {
+                // ONE form of the first half per instantiation (with a second, statistics-free copy of the 36 steps in the loop hipcc shuffled 84
+                // register pairs per patch to reconcile the two allocations): the first patch of a group runs the statistics instructions on
+                // whatever the staging image holds and drops the result
+                const bool keep = i > 0;
+                if (keep) next_image((q - 1) / ppi);
+                const unsigned short* tb = tr_base();
+                bf16x8 Fa = ones, Fb = ones;             // fragment in use / fragment in flight
+                f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = {0.f, 0.f, 0.f, 0.f};
+                xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<2>{},
+                       [&](int t) {
+                           if (t <= 16 && (t & 1) == 0) {
+                               Fa = Fb;
+                               if (t < 16) Fb = tr_frag(tb, t >> 1);
+                           }
+                       },
+                       [&](int t) {
+                           if (t >= 2 && t <= 16 && (t & 1) == 0) {
+                               S2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, Fa, S2, 0, 0, 0);
+                               S1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fa, ones, S1, 0, 0, 0);
+                           }
+                           if (t == 17) fold(S1, S2, keep);
+                       });
             } else {
                 xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<3>{}, nohook, nohook);
             }
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         stamp(1);                                // [1] wait at the mid-X barrier (= the other group's staging barrier)
         if (act) {
             xsteps(PPInt<XSPLIT>{}, PPInt<72>{}, PPInt<3>{}, nohook, nohook);
-            if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
+            if (abl::stamp && (dbg & 3) == 1) __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
         stamp(2);                                // [2] second half
@@ -401,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         // not program addresses): with yhead and ytail under separate `if (act)` hipcc's wait tracker sees a path "DMA issued, stores skipped",
         // on which vmcnt(8) does not cover the DMA, and drains vmcnt(0) in front of the next LDS read
         if (act) {
-            if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(1);
+            if (abl::stamp && (dbg & 3) == 2) __builtin_amdgcn_s_setprio(1);
             yhead(q);
             stamp(9);                            // [9] epilogue + staging writes
             SHM_LDS_BARRIER();                   // the staging image of patch q is complete
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             // tracker sees it and knows the halo DMA has landed -- behind an inline-asm wait it would drain the stores too (vmcnt(0)) in front of
             // the next X segment's first fragment read
             __builtin_amdgcn_s_waitcnt(0x0F78);
-            if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(0);
+            if (abl::stamp && (dbg & 3) == 2) __builtin_amdgcn_s_setprio(0);
             stamp(7);                            // [7] wait for the next halo
             SHM_LDS_BARRIER();                   // the group's next halo has landed for all four waves
             stamp(8);                            // [8] wait at the end-of-Y barrier
@@ -425,8 +449,8 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         SHM_LDS_BARRIER();
         SHM_LDS_BARRIER();
     }
-    if constexpr (EPI)
-        if (want_stats && q0 < q1) {
+    if constexpr (STATS)
+        if (q0 < q1) {
             xstats_tail((q1 - 1) / ppi);
             flush(simg);
         }
@@ -455,15 +479,11 @@ int shm_pp_launch(const TapGemmArgs& a, int batch, int ncu, hipStream_t st, cons
     if (gx < 1) gx = 1;
     if (gx > (npatch + 1) / 2) gx = (npatch + 1) / 2;
     const bool epi = a.slope != 1.f || a.stats != nullptr || a.bias != nullptr;
-    // wave priority: 0 none, 1 the X (MFMA) segment, 2 the Y segment; the X step behind which the staging barrier sits (SHM_PP_PRIO, SHM_PP_SPLIT,
-    // read once: A/B switches of the round-5 measurements)
+    // SHM_PP_DBG: switches of the stamped timing build only (tools/probes/pp_stamps.py): bits 0-1 wave priority (1: X segment, 2: Y segment), 4 no halo
+    // DMA, 8 no epilogue, 16 no store pass.  The product build ignores the value.
     static const int prio = [] {
-        const char* e = getenv("SHM_PP_PRIO");
+        const char* e = getenv("SHM_PP_DBG");
         return e ? atoi(e) : 0;
-    }();
-    static const int split = [] {
-        const char* e = getenv("SHM_PP_SPLIT");
-        return e ? atoi(e) : 36;
     }();
     hipError_t att = hipSuccess;
 #define PP_LAUNCH(EPI_, XS_)                                                                                                            \
@@ -472,17 +492,12 @@ int shm_pp_launch(const TapGemmArgs& a, int batch, int ncu, hipStream_t st, cons
         att = at_;                                                                                                                      \
         if (att == hipSuccess) hipLaunchKernelGGL((tapgemm_pp_bf16_kernel<EPI_, XS_>), dim3(gx, nyw, 1), dim3(512), PP_LDS, st, a, npatch, prio); \
     } while (0)
-    if (epi) {
-        if (split == 48) PP_LAUNCH(true, 48);
-        else if (split == 56) PP_LAUNCH(true, 56);
-        else PP_LAUNCH(true, 36);
-    } else {
-        if (split == 48) PP_LAUNCH(false, 48);
-        else if (split == 56) PP_LAUNCH(false, 56);
-        else PP_LAUNCH(false, 36);
-    }
+    const int mode = !epi ? 0 : a.stats ? 2 : 1;
+    if (mode == 2) PP_LAUNCH(2, 48);
+    else if (mode == 1) PP_LAUNCH(1, 48);
+    else PP_LAUNCH(0, 48);
 #undef PP_LAUNCH
     SHM_REQUIRE(att == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, PP_LDS, hipGetErrorString(att));
-    shm_set_last_kernel("tapgemm_pp_bf16_kernel<%s>", epi ? "true" : "false");
+    shm_set_last_kernel("tapgemm_pp_bf16_kernel<%d>", mode);
     return SHM_OK;
 }

@@ -57,7 +57,7 @@ def _sym(variant, dt, nch=2, epi=True, hw=None):
     nch = int(nch)
     if variant == "wreg" and SYMBOL["wreg"].startswith("tapgemm_wreg16") and nch == 2 and hw is not None and hw[0] % 8 == 0 and hw[1] % 32 == 0 \
             and _ops().get_tuning("tapgemm.wreg16") == 2:
-        return f"tapgemm_pp_bf16_kernel<{'true' if epi else 'false'}>"
+        return f"tapgemm_pp_bf16_kernel<{2 if epi else 0}>"          # MODE 2: bias + LeakyReLU + statistics; 0: the plain product
     return SYMBOL[variant].format(t="float" if dt == "f32" else "__bf16", nch=nch, epi="true" if epi else "false")
 
 
@@ -218,15 +218,19 @@ def test_pingpong_forward_with_statistics(n, hi, wi, cout, slope):
         ops.conv2d_in_fwd(_dev(x, "bf16"), None, 0, cin, 0, _wk(w, cin, "bf16"), torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, hi, wi, cin, cout, 3, 1,
                           slope, stats, 1e-6, scratch=scr)
         torch.cuda.synchronize()
-        assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<true>", ops.last_kernel()
+        assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<2>", ops.last_kernel()
         got = host(y.float())
         assert rel_l2(got, ref) < TOL["bf16"], rel_l2(got, ref)
         if (hi * wi) % 64 == 0:
             _check_stats(stats, got, n, cout, "bf16")
         y.fill_(9.0)
-    # the same product without bias, activation or statistics is the EPI = false instantiation
+    # bias + activation without statistics: MODE 1
+    ops.conv2d_fwd(_dev(x, "bf16"), None, 0, cin, 0, _wk(w, cin, "bf16"), torch.from_numpy(b.astype(np.float32)).cuda(), y, cout, n, hi, wi, cin, cout, 3, 1, slope)
+    assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<1>", ops.last_kernel()
+    assert rel_l2(host(y.float()), ref) < TOL["bf16"]
+    # the same product without bias, activation or statistics: MODE 0
     ops.conv2d_fwd(_dev(x, "bf16"), None, 0, cin, 0, _wk(w, cin, "bf16"), None, y, cout, n, hi, wi, cin, cout, 3, 1, 1.0)
-    assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<false>", ops.last_kernel()
+    assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<0>", ops.last_kernel()
     assert rel_l2(host(y.float()), conv_ref(_rnd(x, "bf16"), _rnd(w, "bf16"), 1)) < TOL["bf16"]
 
 

@@ -1,6 +1,7 @@
 """Phase stamps of tapgemm_pp_bf16_kernel (timing-only build of conv_pingpong.hip with -DSHM_ABL_STAMP, loaded through SHM_LIB_PATH): cycles per
 patch and wave between the segment boundaries of the ping-pong loop, for one block in the middle of the grid.  The stamped build dumps behind the
-64 bias values (this script passes a longer bias buffer).
+64 bias values (this script passes a longer bias buffer).  SHM_PP_DBG = bits of timing-only switches of that build: 1 / 2 wave priority for the
+X / Y segment, 4 no halo DMA after the first, 8 no epilogue, 16 no store pass (28 = the X segment beside an idle partner); --abl=NOLDS: no fragment reads.
 
     python tools/probes/pp_stamps.py [n,h,cin,cout]      (builds the stamped library into build_ab/ first if it is missing)"""
 import os
@@ -9,15 +10,16 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
-so = ROOT / "build_ab" / "libshm_pp_stamp.so"
+abl = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--abl=")]          # e.g. --abl=NOLDS: also -DSHM_ABL_NOLDS
+so = ROOT / "build_ab" / ("libshm_pp_stamp" + "".join("_" + x.lower() for x in abl) + ".so")
 if "SHM_LIB_PATH" not in os.environ:
     from shmgan_amd import _lib
     if not so.exists() or so.stat().st_mtime < (_lib.CSRC / "conv_pingpong.hip").stat().st_mtime:
         so.parent.mkdir(exist_ok=True)
         _lib.build()
-        obj = so.parent / "conv_pingpong_stamp.o"
+        obj = so.parent / (so.stem + ".o")
         flags = [f for f in _lib.HIPCC_FLAGS if f != "-shared"]
-        subprocess.run(["/opt/rocm/bin/hipcc", *flags, *_lib.EXTRA_FLAGS.get("conv_pingpong.hip", []), "-DSHM_ABL_STAMP", "-c", str(_lib.CSRC / "conv_pingpong.hip"), "-o", str(obj)], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", *flags, *_lib.EXTRA_FLAGS.get("conv_pingpong.hip", []), "-DSHM_ABL_STAMP", *["-DSHM_ABL_" + x for x in abl], "-c", str(_lib.CSRC / "conv_pingpong.hip"), "-o", str(obj)], check=True)
         objs = [str(obj) if s == "conv_pingpong.hip" else str(_lib.CSRC / "_obj" / (Path(s).stem + ".o")) for s in _lib.SOURCES]
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", str(so)], check=True)
     if "--build-only" in sys.argv:
@@ -39,10 +41,23 @@ y = torch.empty((n, h, h, cout), device="cuda", dtype=dt)
 stats = torch.empty(n * cout * 2, dtype=torch.float64, device="cuda")
 scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
 ops.set_tuning("tapgemm.variant", "wreg")
+sustained = "--sustained" in sys.argv          # 40 launches back to back (the chip at the clock it holds under this load), stamps of the last one
 for _ in range(5):
     b.zero_()
     ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, b, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
     torch.cuda.synchronize()
+if sustained:
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(20):
+        ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, b, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    e0.record()
+    for _ in range(19):
+        ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, b, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    b.zero_()
+    ops.conv2d_in_fwd(x, None, 0, cin, 0, wk, b, y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"sustained: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call (conv + finalize), stamps of the last launch:")
 print(ops.last_kernel())
 d = b[64:].view(torch.int32).cpu().numpy().reshape(8, 16)
 names = ["X half 1", "mid-X bar", "X half 2", "end-X bar", "DMA issue", "epilogue", "stg bar", "stores", "stats", "halo wait", "end-Y bar"]
