@@ -80,8 +80,27 @@ class Arena:
             self.t[key] = t
         return t
 
+    def get_slack(self, name, shape, dtype, slack):
+        """A tensor of `shape` at the front of a zero-filled flat allocation with `slack` more elements behind it: the compact 3-channel
+        images (one 16-byte chunk per pixel) are also read by the generic conv kernels under a forced variant, which fetch a whole
+        K-channel operand row per pixel -- the last pixels' rows then end inside the slack instead of past the allocation (kernels that
+        address through buffer descriptors are bounded anyway; the flat-address ones are not: round-4 advisor finding)."""
+        key = (name, tuple(shape), dtype, int(slack))
+        t = self.t.get(key)
+        if t is None:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            flat = torch.zeros(n + int(slack), dtype=dtype, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+            t = flat[:n].view(tuple(shape))
+            self.t[key] = t
+            self.t[key + ("storage",)] = flat
+        return t
+
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in self.t.values())
+        # a get_slack tensor is a view of its "storage" entry: count the storage
+        return sum(t.numel() * t.element_size() for k, t in self.t.items() if not (len(k) == 4 and isinstance(k[3], int)))
 
 
 class WgradLane:
@@ -1046,7 +1065,9 @@ class Discriminator(_ModelBase):
                 return dz
             if i > 0 or need_dx:
                 ldx = rec["ldx"]
-                dprev = A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
+                # i == 0: the image gradient in the compact pitch (3 channels in a 4- / 8-element pixel).  The input-gradient kernels write the
+                # real channels only; the pad slot is zero because the buffer is allocated zero-filled, once (advisor finding, round 4)
+                dprev = A.get_slack(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt, 0) if i == 0 else A.get(f"d/bwd/dx{i}/{n}", (n, h, h, ldx), self.gdt)
                 gs = None
                 if i > 0 and self.gsum:          # dprev is the gradient at block i-1's InstanceNorm output: its sums come with it
                     gred = A.get(f"d/bwd/gred{i - 1}/{n}", (ops.GSUM_SLOTS * n * cin * 2,), torch.float64)
@@ -1090,7 +1111,7 @@ class Discriminator(_ModelBase):
     def __call__(self, x, training=False, noise=None, keep_mask=None):
         """Keras-style call on [N,S,S,3] (reference: self.D(x, training=...))."""
         n = x.shape[0]
-        xd = self.arena.get(f"dcall/x16/{n}", (n, self.S, self.S, self.in_pitch), self.adt)
+        xd = self.arena.get_slack(f"dcall/x16/{n}", (n, self.S, self.S, self.in_pitch), self.adt, self.pad)
         ops.pack_rgb16(x.contiguous(), noise if training else None, xd, n * self.S * self.S)
         rows = [(0, n, 0)] if (training and keep_mask is not None) else []
         return self.forward(xd, keep_mask, rows)

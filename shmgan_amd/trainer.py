@@ -347,7 +347,7 @@ class ShmGANwithSSpecSeg:
         gen_Y = G.forward(gen_in, "g1", attn=attn_g)
 
         # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
-        xd = A.get("d/x16", (12 * B, S, S, D.in_pitch), adt)          # one 16-byte chunk per pixel (Discriminator.in_pitch)
+        xd = A.get_slack("d/x16", (12 * B, S, S, D.in_pitch), adt, D.pad)          # one 16-byte chunk per pixel (Discriminator.in_pitch) + a K-row of slack
         gen_rgb = A.get("g1/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, noise[:B], gen_rgb, xd[0:B], B, B, npix)                  # SHM.py:544-559
 
@@ -561,25 +561,35 @@ class ShmGANwithSSpecSeg:
         a full disk); the chosen path (or None) is broadcast, every rank loads exactly that file, and the ranks then agree on a
         success flag -- a rank that could not load what rank 0 chose ends the job (non-zero exit) instead of training on other
         weights, Adam state and draw streams than its peers.  Anything else (EACCES, EIO, a checkpoint of another model
-        configuration or attention mode) is not a damaged file and propagates."""
+        configuration or attention mode) is not a damaged file: rank 0 broadcasts the reason and EVERY rank raises it (round-4 advisor
+        finding: rank 0 used to raise in front of the broadcast and leave its peers waiting in it)."""
         import zipfile
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if self.G is None:
             self.build()
-        chosen, payload = None, None
+        chosen, payload, fatal = None, None, None
         if self._rank() == 0:
-            for path in reversed(self._checkpoints()):
-                try:
-                    payload = self._read_npz(path)
-                    chosen = path
-                    break
-                except (zipfile.BadZipFile, EOFError) as e:
-                    print(f"checkpoint {path} is unreadable ({type(e).__name__}: {e}); trying the previous one")
+            try:
+                for path in reversed(self._checkpoints()):
+                    try:
+                        payload = self._read_npz(path)
+                        chosen = path
+                        break
+                    except (zipfile.BadZipFile, EOFError, ValueError) as e:
+                        # ValueError: np.load / json on an intact zip member with a damaged .npy header or state string -- a damaged file like
+                        # the other two.  _read_npz's own checks (names, shapes, attention mode) raise KeyError, which is not swallowed here
+                        print(f"checkpoint {path} is unreadable ({type(e).__name__}: {e}); trying the previous one")
+            except Exception as e:                      # not a damaged file: every rank must hear about it before rank 0 raises
+                fatal = e                                # (the others would sit in the broadcast until the collective times out)
         if multi:
-            box = [chosen]
+            box = [chosen, None if fatal is None else repr(fatal)]
             dist.broadcast_object_list(box, src=0)
-            chosen = box[0]
+            chosen, why = box
+            if why is not None:
+                raise RuntimeError(f"rank {self._rank()}: rank 0 could not choose a checkpoint: {why}") from fatal
+        elif fatal is not None:
+            raise fatal
         ok, err = 1, None
         if chosen is not None:
             try:

@@ -140,11 +140,18 @@ def test_built_library_has_no_store_data_hazard():
     ok2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_lshl_add_u64 v[16:17], v[16:17], 0, 16\n\tv_mov_b32_e32 v1, v2\n\tv_mov_b32_e32 v20, v2\n"
     bad2 = "0000 <k>:\n\tglobal_store_dwordx4 v[16:17], v[20:23], off\n\tv_mov_b32_e32 v1, v2\n\tv_pk_add_f32 v[22:23], v[2:3], v[4:5]\n"
     assert len(chk.scan(bad)) == 1 and len(chk.scan(bad2)) == 1 and not chk.scan(ok1) and not chk.scan(ok2)
-    # ... and its second rule: no VALU read of an MFMA's VGPR result within four wait states (another MFMA may chain on it)
+    # ... and its second rule: no VALU read of an MFMA's VGPR result within passes + 2 wait states of it, per MFMA shape (another MFMA may
+    # chain on it and counts as its own passes; a VALU write to the register supersedes the result; an unconditional branch ends the window)
     bad3 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\tv_mov_b32_e32 v7, v8\n\tv_max_f32_e32 v9, v1, v2\n"
-    ok3 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\ts_nop 4\n\tv_max_f32_e32 v9, v1, v2\n"
+    bad4 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\ts_nop 4\n\tv_max_f32_e32 v9, v1, v2\n"          # 8 passes want 10
+    bad5 = "0000 <k>:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n\ts_nop 3\n\tv_cvt_pk_bf16_f32 v9, v0, v1\n"   # 4 passes want 6
+    ok3 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\ts_nop 7\n\ts_nop 1\n\tv_max_f32_e32 v9, v1, v2\n"
     ok4 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\tv_mfma_f32_16x16x4_f32 v[0:3], v6, v7, v[0:3]\n\tv_mfma_f32_16x16x4_f32 a[0:3], v6, v7, a[0:3]\n"
-    assert len(chk.scan(bad3)) == 1 and not chk.scan(ok3) and not chk.scan(ok4)
+    ok5 = "0000 <k>:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n\ts_nop 5\n\tv_cvt_pk_bf16_f32 v9, v0, v1\n"
+    ok6 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\tv_mov_b32_e32 v1, 0\n\tv_max_f32_e32 v9, v1, v1\n"                 # v1 rewritten
+    ok7 = "0000 <k>:\n\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]\n\ts_branch 12\n\tv_max_f32_e32 v9, v1, v2\n"                       # not fall-through
+    assert len(chk.scan(bad3)) == 1 and len(chk.scan(bad4)) == 1 and len(chk.scan(bad5)) == 1
+    assert not chk.scan(ok3) and not chk.scan(ok4) and not chk.scan(ok5) and not chk.scan(ok6) and not chk.scan(ok7)
     assert chk.main(["check_isa_hazards.py", str(_lib.LIB_PATH)]) == 0
 
 

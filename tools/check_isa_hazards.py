@@ -10,8 +10,8 @@ The MI355X does not: round 4's conv3x3s2_rgb_fwd_kernel had `buffer_store_dwordx
 v_max_f32 into v17 (the next tile's LeakyReLU), and ~4e-4 of that register's values were stored as the next tile's -- lanes 12-15 of a row only,
 only at sizes that fill the chip, differently from run to run.  With the tile offset in the instruction's immediate field the compiler spaces
 the write out itself.  The scan applies the rule to every wide store, whatever its soffset.
-The scan also applies the neighbouring rule inline asm escapes the same way: no VALU read of an MFMA's VGPR result within four wait states (the
-shortest MFMA wants five; hipcc pads its own instructions).
+The scan also applies the neighbouring rule inline asm escapes the same way: no VALU read of an MFMA's VGPR result within passes + 2 wait states of
+it (per MFMA shape; hipcc pads its own instructions -- since round 5 no inline asm reads an accumulator, the conversions are compiler-visible).
 (Linear scan of the disassembly: a store at the very end of a loop body against a write at its top is not seen.)
 
     python tools/check_isa_hazards.py [path/to/libshmgan_hip.so]      exit 0 = clean, 1 = findings (printed with kernel and lines)
@@ -60,13 +60,23 @@ def vregs(tok):
     return set(range(int(m.group(2)), int(m.group(3)) + 1))
 
 
+# wait states between an MFMA and a VALU read of its VGPR result: passes + 2 (a pass = 4 cycles of the matrix pipe), per instruction
+MFMA_PASSES = {"v_mfma_f32_32x32x2_f32": 16, "v_mfma_f32_16x16x4_f32": 8, "v_mfma_f32_32x32x16_bf16": 8, "v_mfma_f32_16x16x32_bf16": 4,
+               "v_mfma_f32_32x32x16_f16": 8, "v_mfma_f32_16x16x32_f16": 4}
+MFMA_DEFAULT_PASSES = 4
+
+
+def mfma_wait_states(ins):
+    return MFMA_PASSES.get(ins.replace("_e64", ""), MFMA_DEFAULT_PASSES) + 2
+
+
 def nop_states(ins, ops):
     if ins == "s_nop":
         return int(ops[0], 0) + 1
+    if ins.startswith("v_mfma") or ins.startswith("v_smfmac"):
+        # an MFMA behind another one issues when the matrix pipe takes it: it holds the wave for about its passes
+        return MFMA_PASSES.get(ins.replace("_e64", ""), MFMA_DEFAULT_PASSES)
     return 1
-
-
-MFMA_WAIT_STATES = 4              # a lower bound: the shortest (2-pass) MFMA wants 5 wait states before a VALU reads its VGPR result
 
 
 def all_vregs(ops):
@@ -110,13 +120,20 @@ def scan(text):
             for regs, left, where in mfma:
                 if src & regs:
                     findings.append((kernel, where, body))
+        # a VALU write to a register an MFMA result sits in supersedes that result for later readers; code behind an unconditional
+        # branch is not reached by falling through
+        if ins.startswith("v_") and not ins.startswith("v_cmp") and ops and not (ins.startswith("v_mfma") or ins.startswith("v_smfmac")):
+            w = vregs(ops[0])
+            mfma = [(r - w, left, wh) for r, left, wh in mfma if r - w]
+        if ins in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pending, mfma = [], []
         states = nop_states(ins, ops)
         pending = [(r, left - states, w) for r, left, w in pending if left - states > 0]
         mfma = [(r, left - states, w) for r, left, w in mfma if left - states > 0]
         if (ins.startswith("v_mfma") or ins.startswith("v_smfmac")) and ops:
             dst = vregs(ops[0])       # empty for AGPR destinations
             if dst:
-                mfma.append((dst, MFMA_WAIT_STATES, body))
+                mfma.append((dst, mfma_wait_states(ins), body))
         wide = ins.endswith("dwordx3") or ins.endswith("dwordx4")
         if wide and "store" in ins:
             # buffer_store: vdata, vaddr, srsrc, soffset; global / flat / scratch: vaddr, vdata, saddr
