@@ -53,8 +53,9 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: all ranks share GPU 0")
     ap.add_argument("--grad-dtype", type=str, default=None, choices=["float32", "bfloat16"],
                     help="bf16 mode only: element type of the gradient-signal tensors (float32 = SHM_BF16_GF32)")
-    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
-                    help="f32 = BASELINE configs[1] (default, the headline line); bf16 = configs[3]/[4] (bf16 MFMA path)")
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f32x3"],
+                    help="f32 = BASELINE configs[1] (default, the headline line: exact-fp32 MFMA); bf16 = configs[3]/[4] (bf16 MFMA path); f32x3 = fp32 "
+                         "tensors with the 3x3 unit-stride weight gradients as six bf16 MFMA products of exact three-plane splits (opt-in, wgrad.f32_split)")
     args = ap.parse_args()
 
     # Before torch is imported or any torch.cuda function runs (device_count() may already bring HSA up, and HSA reads this at
@@ -96,11 +97,13 @@ def main():
 
     from shmgan_amd import ShmGANwithSSpecSeg, ops
 
+    if args.dtype == "f32x3":
+        ops.set_tuning("wgrad.f32_split", 1)
     S, F, B = args.image_size, args.filter_size, args.batch
     model = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, device=dev,
-                               compute_dtype="bfloat16" if args.dtype == "bf16" else "float32",
+                               compute_dtype="bfloat16" if args.dtype == "bf16" else "float32",          # f32x3: fp32 tensors
                                grad_dtype=args.grad_dtype).build()
-    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS        # (f32x3: fp32-equivalent FLOPs against the f32 pipe's peak)
 
     # synthetic inputs, resident in HBM before the timed region
     rng = np.random.default_rng(1234 + rank)
@@ -193,7 +196,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, "
-                                   + ("fp32" if args.dtype == "f32" else "bf16 operands / fp32 accumulate")
+                                   + {"f32": "fp32", "bf16": "bf16 operands / fp32 accumulate",
+                                      "f32x3": "fp32 tensors, 3x3 unit-stride weight gradients from six bf16 MFMA products of three-plane splits"}[args.dtype]
                                    + (" (BASELINE configs[1])" if (S, B, F, args.dtype) == (256, 8, 64, "f32") else "")
                                    + (" (BASELINE configs[3])" if (S, B, F, args.dtype) == (512, 4, 64, "bf16") else "")
                                    + (" (BASELINE configs[4], per GPU)" if (S, B, F, args.dtype) == (256, 32, 64, "bf16") else ""),
@@ -221,7 +225,7 @@ def main():
             # HBM-side bytes are PMC counters: they need rocprofv3 --pmc passes of this same command, which cannot run inside the
             # timed process -- the figure is read from the committed distillate of those passes (tools/profile_round.sh ->
             # tools/pmc_traffic.py, profiles/README.md); `traffic_source` names the file
-            tags = (["r04_f32", "r03_f32", "r02_f32"] if args.dtype == "f32" else
+            tags = (["r05_f32", "r04_f32", "r03_f32", "r02_f32"] if args.dtype != "bf16" else
                     (["r04_s512_b4_bf16", "r03_s512_b4_bf16", "r02_s512_b4_bf16"] if (S, B) == (512, 4) else ["r04_bf16", "r03_bf16", "r02_bf16"]))
             tpath = next((ROOT / "profiles" / f"{t}_traffic_pmc.json" for t in tags if (ROOT / "profiles" / f"{t}_traffic_pmc.json").exists()),
                          ROOT / "profiles" / "none")
@@ -272,6 +276,25 @@ def main():
                              tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12) for k, v in ps.items()]
                 rows.sort(key=lambda r: -r["ms_per_step"])
                 Path(args.per_shape).write_text(json.dumps(rows, indent=1))
+        if world == 1 and args.dtype == "f32" and not args.no_extra_configs:
+            # the opt-in fp32-from-bf16-planes weight gradient (csrc/conv_wgrad_x3.hip) on the same model, same process:
+            # the headline above stays the exact-fp32 MFMA step
+            ops.set_tuning("wgrad.f32_split", 1)
+            for i in range(2):
+                model.train_step(*inputs, draws=draws_for(1000 + i), next_batch=inputs)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                model.train_step(*inputs, draws=draws_for(1002 + i), next_batch=inputs)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t2
+            ops.set_tuning("wgrad.f32_split", 0)
+            out["extra"] = {"f32x3": {"ms_per_step": round(dt3 / args.steps * 1e3, 3), "value": round(B * args.steps / dt3, 3), "unit": "images/sec",
+                                      "steps": args.steps, "warmup": 2,
+                                      "arithmetic": "3xbf16 planes (exact truncation split of every fp32 operand), 6 products with i + j <= 2, fp32 accumulate; "
+                                                    "3x3 unit-stride weight gradients only (wgrad_halo_x3_kernel), everything else exact-fp32 MFMA",
+                                      "losses_finite": bool(all(np.isfinite(v) for k, v in model.losses().items() if k != "ssim"))}}
+            note(f"f32x3 (opt-in): {dt3 / args.steps * 1e3:.2f} ms/step")
         if not args.no_kernel_timer and world == 1:      # a single-GPU property; at N > 1 the other ranks would wait behind it
             out["north_star_block"] = north_star_block(torch, ops, dev)
         if world == 1 and not args.no_extra_configs and (S, B, F, args.dtype) == (256, 8, 64, "f32"):

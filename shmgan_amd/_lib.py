@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SHM_LIB_PATH"]) if os.environ.get("SHM_LIB_PATH") else _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
-SOURCES = ["conv_igemm.hip", "conv_wreg16.hip", "conv_pingpong.hip", "conv_wgrad.hip", "conv_rgb.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wreg16.hip", "conv_pingpong.hip", "conv_wgrad.hip", "conv_wgrad_x3.hip", "conv_rgb.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
 F32, BF16 = 0, 1                 # SHM_F32 / SHM_BF16 of include/shmgan_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-local-typedef"]
@@ -119,7 +119,7 @@ def build(force=False, verbose=False, jobs=None):
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
-    shared = [CSRC / "common.h", CSRC / "ablate.h", CSRC / "tapgemm.h", HEADER]
+    shared = [CSRC / "common.h", CSRC / "ablate.h", CSRC / "tapgemm.h", CSRC / "wgrad.h", HEADER]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
     # what the objects were built WITH: compiler, flags and source list (a change of HIPCC_FLAGS must not relink stale objects)

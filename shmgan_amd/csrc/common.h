@@ -43,6 +43,7 @@ enum ShmTune {
     SHM_TUNE_ELEM_APPLY_BLOCKS,       // block target of the InstanceNorm-backward apply pass
     SHM_TUNE_TAPGEMM_WREG16,          // bf16 weights-in-registers layers: 2 = ping-pong kernel where eligible (conv_pingpong.hip), 1 = the eight-wave form with 16-column wave tiles (v_mfma_f32_16x16x32_bf16), 0 = the four-wave form
     SHM_TUNE_WGRAD_BF16_WIDE,         // bf16 weight gradient, eight-wave 64 x 128 block: 0 = automatic (stride 2 only), 1 never, 2 stride 2, 3 unit stride, 4 both
+    SHM_TUNE_WGRAD_F32_SPLIT,         // fp32 3x3 unit-stride weight gradient: 1 = six bf16 MFMA products of exact three-plane splits (conv_wgrad_x3.hip), 0 = exact-fp32 MFMA (default)
     SHM_TUNE_TAPGEMM_FLAT_EPILOGUE,   // 1 = treat the outputs as larger than 4 GiB (tests: the 64-bit-address epilogues and the kernels that do not need buffer stores)
     SHM_TUNE_COUNT
 };

@@ -13,33 +13,9 @@
 // are fetched through L1/L2.  Wave w owns the 32x32 sub-tile (w>>1, w&1) of every tap
 // (9 accumulators).  Partial slabs go to a workspace and are summed in a fixed order by
 // wgrad_reduce_kernel (deterministic, no float atomics).
-#include "common.h"
-#include "ablate.h"
-
-// XCD-aware block order (speed only): the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, each with its
-// own L2, so the blocks that share an operand tile -- same pixels, different (ci, co) tile -- land on eight different L2s and
-// every tile is fetched from HBM up to eight times (wgrad_halo_bf16_kernel: L2 hit rate 0.33, 3.3 TB/s HBM-side at 38 % MFMA
-// utilisation).  Remapped, XCD j works through the contiguous range [j*total/8, (j+1)*total/8) of the x-fastest block order,
-// i.e. through whole pixel splits: both operand tiles of a split are fetched once per XCD and reused from its L2.  Bijective
-// for any grid (guide, "XCD swizzle must be bijective").  Whatever the real placement, results are unchanged.
-struct Blk3 {
-    int x, y, z;
-};
-__device__ __forceinline__ Blk3 xcd_block_order() {
-    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
-    const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-    const unsigned q = total >> 3, r = total & 7u, xcd = lin & 7u, idx = lin >> 3;
-    const unsigned nw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    Blk3 b;
-    b.x = (int)(nw % nx);
-    b.y = (int)((nw / nx) % ny);
-    b.z = (int)(nw / (nx * ny));
-    return b;
-}
+#include "wgrad.h"
 
 #include <stdlib.h>
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradArgs {            // x, x2, dy: float (wgrad_kernel) or bf16 (wgrad_bf16_kernel) tensors
     const void* x;
@@ -259,19 +235,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // 64-byte halves swapped, which makes the four rows x two channel blocks a 32-lane half reads hit 32
 // distinct 8-byte bank pairs.  Stage = 16 pixels; same work split, split-K slabs and (register
 // staged, two-stages-ahead) pipeline as wgrad_kernel.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* base) {
-    // pixels [0,4) and [4,8) of this lane's k group: two transposed reads 4 rows (512 B) apart
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 4 * 64));
-    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 template <int NT, bool STRADDLE>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
     constexpr int BKP = 16;
@@ -454,26 +417,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
 // needs ~5x fewer address instructions per MFMA.  Three stages, DMA two stages ahead, counted
 // s_waitcnt vmcnt, raw s_barrier.  Work split: block = (64 ci, 64 co, slice of patches); wave w
 // owns the 32x32 sub-tile (w>>1, w&1) of all nine taps; partial slabs as in wgrad_kernel.
-struct WgradHaloArgs {
-    const void* x;
-    const void* x2;
-    int c1, ldx, ldx2;
-    const void* dy;
-    int lddy;
-    float* part;
-    int h, w, cin_ld, cin, cout;
-    int npatch, patches_per_split;
-    unsigned xbytes, x2bytes, dybytes;
-    // "norm" (shm_conv2d_wgrad_norm): source `ntpart` (0 = x, 1 = x2) is the UN-normalised activation a of an InstanceNorm block with
-    // table nt = float [batch][4][ntc] (mean, inv, beta, ring).  SHM_NORM_EXACT (kernels <1>): shm_in_norm on its halo pixels in LDS, see
-    // tapgemm_halo_kernel.  SHM_NORM_SCALED (kernels <2>): sum x_hat * dz = inv * sum a_ext * dz + (beta - mean * inv) * sum dz with
-    // a_ext = a inside the image and `ring` outside -- the kernels write `ring` over the out-of-image halo entries of border patches and
-    // scale the rows of their slab by inv (a block's patches lie in ONE sample: the launcher cuts the splits that way); the second
-    // term is shm_conv2d_wgrad_norm_finish's.
-    const float* nt;
-    int ntpart, ntc;
-};
-
 // A 16-byte global load the COMPILER does not see as a vector-memory operation (inline asm, drained on the spot).  The table
 // registers of the NM kernels are re-read when a block moves on to the next image, i.e. under a branch: as plain loads hipcc has
 // to assume them outstanding at every later use and puts s_waitcnt vmcnt(0) in front of each normalisation -- which also waits
@@ -1832,6 +1775,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.nt = g_wnorm.nt;
         hgs.ntpart = g_wnorm.part;
         hgs.ntc = g_wnorm.c;
+        if (!want_nm && shm_tune(SHM_TUNE_WGRAD_F32_SPLIT) == 1) {        // "wgrad.f32_split": conv_wgrad_x3.hip
+            const int rc = shm_wgrad_x3_launch(hgs, cin, cout, nsh, st);
+            if (rc != SHM_OK) return rc;
+        } else {
         if (want_nm && g_wnorm.mode)
             hipLaunchKernelGGL(wgrad_halo_kernel<2>, gridh, dim3(256), 0, st, hgs);
         else if (want_nm)
@@ -1839,6 +1786,7 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         else
             hipLaunchKernelGGL(wgrad_halo_kernel<0>, gridh, dim3(256), 0, st, hgs);
         shm_set_last_kernel(want_nm ? (g_wnorm.mode ? "wgrad_halo_kernel<2>" : "wgrad_halo_kernel<1>") : "wgrad_halo_kernel");
+        }
         }
     } else {
     dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), ns);

@@ -1,0 +1,221 @@
+// fp32 weight gradient of the 3x3 unit-stride layers as SIX bf16 MFMA products ("wgrad.f32_split" = 1; bench.py --dtype f32x3; opt-in, round 5).
+//
+//   dW[tap][ci][co] = sum_p X[src(p, tap)][ci] * dY[p][co]          (ShmGANwithSSpecSeg.py:859-872: the gradients both optimizers apply)
+//
+// The exact-fp32 path (wgrad_halo_kernel) runs on v_mfma_f32_32x32x2_f32 at 0.90 of a 157 TFLOP/s pipe; the bf16 pipe is sixteen times as
+// fast.  Every fp32 operand splits EXACTLY into three bf16 planes by truncation -- x0 = x & 0xffff0000, r = x - x0 (exact), x1 = r & 0xffff0000,
+// x2 = r - x1 (eight significant bits left: a bf16 value as it stands) -- and the product of two fp32 numbers is the sum of the nine plane
+// products, of which the six with i + j <= 2 carry everything above 2^-24 of it.  bf16 x bf16 is exact in the MFMA's fp32 accumulators, so
+// the six-product sum rounds like an fp32 dot product (rel-L2 against float64 on a 512 x 576 x 128 product: 1.2e-7, the f32 MFMA's own 3.1e-7;
+// LABNOTES 10.8): six MFMAs of 32 cycles instead of eight of 64.
+//
+// Structure = wgrad_halo_bf16_kernel<2> (block: 64 ci x 64 co x 9 taps over a slice of 2 x 16-pixel patches, wave w the 32 x 32 sub-tile
+// (w >> 1, w & 1) of every tap, operands by ds_read_b64_tr_b16 from [pixel][64 channels] rows with the half-swap swizzle, deterministic
+// split-K slabs) with the operand planes made IN the kernel: a stage's 4 x 18 x-halo pixels and 2 x 16 dY pixels come from HBM as fp32 into
+// registers (two 16-byte loads per lane and item, out-of-image = out-of-range offset = zeros), are split (4 VALU per value + 1.5 to pack) and
+// written as three x planes and three dY planes of the bf16 kernel's LDS image (42 KiB per stage, ONE LDS stage: the next stage's loads are in
+// flight in registers during this stage's 108 MFMAs per wave; two blocks per CU cover each other's split / write phase).  Splitting in the
+// kernel costs ~150 vector instructions per lane and stage beside 3 456 matrix-pipe cycles; as a pass of its own it would write and
+// re-read 6 bytes per element of every activation and gradient tensor (~20 ms per step).  Per (K step of 16 pixels, tap): one x fragment per
+// plane meets the K step's three dY fragments: x0 three MFMAs, x1 two, x2 one.
+#include "wgrad.h"
+
+namespace {
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> the three dwords (plane 0, 1, 2) holding the bf16 planes of a in the low half and of b in the high half
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                                   // hi16(b) : hi16(a)
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);          // exact
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);      // exact, <= 8 significant bits
+    p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+}  // namespace
+
+template <int R>
+__global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloArgs a) {
+    constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
+    constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows
+    constexpr int XP = NHR * 64, DP = NPX * 64;         // bf16 elements per x plane / dY plane
+    constexpr int NXI = NHR / 8, NDI = NPX / 8;         // items of 8 rows x 64 channels: 10 + 4
+    constexpr int NIT = NXI + NDI, NJ = (NIT + 3) / 4;  // items per wave: waves below NIT % 4 (or all) take NJ, the others NJ - 1
+    extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];       // [x plane 0..2][dY plane 0..2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int mi = wave >> 1, ni = wave & 1;
+    const Blk3 blk = xcd_block_order();
+    const int ci0 = blk.x * 64, co0 = blk.y * 64;
+    const int pid0 = blk.z * a.patches_per_split;
+    const int pid1 = min(a.npatch, pid0 + a.patches_per_split);
+    const int nstages = pid1 - pid0;
+
+    // item lane mapping (as the bf16 kernel's DMA): lane -> (row l >> 3 of the item, 16-byte bf16 chunk l & 7 = eight channels); LDS chunk j of
+    // row r holds source chunk j ^ (4 * bit1(r)); items are 8 rows, so bit1(r) = bit1(l >> 3)
+    const int drow = lane >> 3;
+    const int sch = (lane & 7) ^ (((drow >> 1) & 1) << 2);
+    const bool second = ci0 >= a.c1;
+    const int ldX = second ? a.ldx2 : a.ldx;
+    const int cX = ci0 + sch * 8;
+    const bool xvalid = cX < a.cin_ld;
+    const int ccX = second ? cX - a.c1 : cX;
+    const int coD = co0 + sch * 8;
+    const bool dvalid = coD < a.cout;
+    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+
+    int n, pr, pc;
+    {
+        const int ppc = a.h / R, ppi = ppc * (a.w / PW);           // patches numbered down the columns of an image, see wgrad_halo_kernel
+        const int p = pid0 < a.npatch ? pid0 : 0;
+        n = p / ppi;
+        const int r = p - n * ppi;
+        pc = (r / ppc) * PW;
+        pr = (r % ppc) * R;
+    }
+    // per-lane constant byte offset + patch origin, edge bits (five per item, one register), as in wgrad_halo_bf16_kernel -- fp32 elements here
+    unsigned off0[NJ], bm = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int item = wave + 4 * j;
+        unsigned bits;
+        if (item < NXI) {
+            const int hp = 8 * item + drow;
+            const int r_ = hp / HP, c_ = hp - r_ * HP;
+            off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 4u;
+            bits = !(xvalid && c_ < PW + 2) ? 16u : (r_ == 0 ? 1u : 0u) | (r_ == R + 1 ? 2u : 0u) | (c_ == 0 ? 4u : 0u) | (c_ == PW + 1 ? 8u : 0u);
+        } else {
+            const int q = 8 * (item - NXI) + drow;
+            off0[j] = (unsigned)(((q >> 4) * a.w + (q & 15)) * a.lddy + coD) * 4u;
+            bits = (dvalid && item < NIT) ? 0u : 16u;
+        }
+        bm |= bits << (5 * j);
+    }
+    // stage registers: eight fp32 channels per item and lane
+    f32x4 sr[NJ][2];
+    auto load = [&]() {
+        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
+        const unsigned edges = 16u | (pr == 0 ? 1u : 0u) | (pr + R == a.h ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc + PW == a.w ? 8u : 0u);
+        const unsigned xb = (unsigned)(org * ldX) * 4u, db = (unsigned)(((n * a.h + pr) * a.w + pc) * a.lddy) * 4u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int item = wave + 4 * j;
+            if (j < NJ - 1 || item < NIT) {
+                const bool isx = item < NXI;                   // wave-uniform
+                const unsigned off = (bm & (edges << (5 * j))) ? 0xffffffffu : off0[j] + (isx ? xb : db);
+                sr[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(isx ? rsx : rsd, off, 0, 0));
+                sr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(isx ? rsx : rsd, off == 0xffffffffu ? off : off + 16u, 0, 0));
+            }
+        }
+        pr += R;
+        if (pr == a.h) {
+            pr = 0;
+            pc += PW;
+            if (pc == a.w) {
+                pc = 0;
+                ++n;
+            }
+        }
+    };
+    // split the stage registers and write the six plane images
+    auto spill = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int item = wave + 4 * j;
+            if (j < NJ - 1 || item < NIT) {
+                u32x4 p0, p1, p2;
+                const float v[8] = {sr[j][0][0], sr[j][0][1], sr[j][0][2], sr[j][0][3], sr[j][1][0], sr[j][1][1], sr[j][1][2], sr[j][1][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned q0, q1, q2;
+                    split_pair(v[2 * e], v[2 * e + 1], q0, q1, q2);
+                    p0[e] = q0;
+                    p1[e] = q1;
+                    p2[e] = q2;
+                }
+                const bool isx = item < NXI;                   // wave-uniform
+                unsigned short* dst = smem + (isx ? item * 512 : 3 * XP + (item - NXI) * 512) + lane * 8;
+                const int ps = isx ? XP : DP;
+                *(u32x4*)(dst) = p0;
+                *(u32x4*)(dst + ps) = p1;
+                *(u32x4*)(dst + 2 * ps) = p2;
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read addresses (elements), as in wgrad_halo_bf16_kernel: the lane supplies row 8 hh + (i >> 2) [+ 4 for the second read] and
+    // channels [32 tile + 16 (g & 1) + 4 (i & 3), + 4); tap and K step enter as immediates, kw shifts the row and with it bit 1 of the row index
+    const int fq = 8 * hh + ((lane & 15) >> 2);
+    const int fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int fa[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int row = fq + kw;
+        fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5));
+    }
+    const int fb = 3 * XP + fq * 64 + ((ni * 32 + fcol) ^ (((fq >> 1) & 1) << 5));
+    auto compute = [&]() {
+#pragma unroll
+        for (int qr = 0; qr < R; ++qr) {
+            bf16x8 d[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[p] = tr_frag(smem + p * DP + fb + qr * PW * 64);
+            // the x fragments of halo row qr + kh are shared by (qr, kh) and (qr + 1, kh - 1): hipcc would keep them all in registers (12 rows x
+            // 3 planes x 4 registers beside 144 accumulators: 57 spills); an opaque copy of the addresses per K step makes them reads again
+            int fx[3] = {fa[0], fa[1], fa[2]};
+            asm volatile("" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                bf16x8 x[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) x[p] = tr_frag(smem + p * XP + fx[t % 3] + (qr + t / 3) * HP * 64);
+                // the small products first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], d[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], d[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], d[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], d[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], d[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], d[0], acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        load();
+        for (int s = 0; s < nstages; ++s) {
+            SHM_LDS_BARRIER();                   // every wave has read the last fragment of the previous stage
+            spill();                             // (hipcc waits for the stage registers' loads here)
+            if (s + 1 < nstages) load();         // the next stage's loads fly during this stage's MFMAs
+            SHM_LDS_BARRIER();                   // the six plane images are complete
+            compute();
+        }
+    }
+
+    float* out = a.part + (size_t)blk.z * 9 * a.cin * a.cout;
+    const int con = co0 + ni * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (ci < a.cin && con < a.cout) out[((size_t)t * a.cin + ci) * a.cout + con] = acc[t][r];
+        }
+    }
+}
+
+int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, hipStream_t st) {
+    constexpr unsigned kLds = (3u * (4 * 20) + 3u * (2 * 16)) * 128u;      // 42 KiB: two blocks per CU
+    hipLaunchKernelGGL((wgrad_halo_x3_kernel<2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsplit), dim3(256), kLds, st, hgs);
+    shm_set_last_kernel("wgrad_halo_x3_kernel<2>");
+    return SHM_OK;
+}

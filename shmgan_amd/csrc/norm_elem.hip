@@ -57,6 +57,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.apply_blocks", "SHM_ELEM_APPLY_BLOCKS", 4096, 256, 1 << 20},
     {"tapgemm.wreg16", "SHM_TAPGEMM_WREG16", 2, 0, 2},
     {"wgrad.bf16_wide", "SHM_WGRAD_BF16_WIDE", 0, 0, 4},
+    {"wgrad.f32_split", "SHM_WGRAD_F32_SPLIT", 0, 0, 1},
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];

@@ -293,8 +293,9 @@ def test_golden_fixture_on_device(name):
     _check_grad_fixture(m, gold)
 
 
+@pytest.mark.parametrize("f32_split", [0, 1])          # 1: "wgrad.f32_split", the fp32 weight gradients from six bf16 MFMA products -- same bounds
 @pytest.mark.parametrize("name", ["step_S256_F64_B1.npz", "step_S256_F64_B8.npz"])
-def test_golden_fixture_full_size(name):
+def test_golden_fixture_full_size(name, f32_split):
     """BASELINE configs[1] at full size (S=256, F=64; B=8 is the bench batch) against the committed float64-oracle
     fixture: every named loss, gen_Y (subsampled values + per-sample moments), SSIM, the SpecSeg mask, and per-tensor
     gradient norms and projections of all 53 weight tensors.  This is the only place the fp32 kernels' full-size
@@ -304,11 +305,22 @@ def test_golden_fixture_full_size(name):
     from pathlib import Path
     gold = np.load(Path(__file__).resolve().parent / "golden" / name)
     S, F, B, step, sub = [int(v) for v in gold["meta"]]
+    from shmgan_amd import ops
     m, _ = _mk(S, F, B)
     m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
     m.before_backward, pinned = _pin_kinks(m, gold)
-    m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
-    torch.cuda.synchronize()
+    try:
+        ops.set_tuning("wgrad.f32_split", f32_split)
+        timer = ops.KernelTimer() if f32_split else None
+        ops.TIMER = timer
+        m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.TIMER = None
+        ops.set_tuning("reset", 0)
+    if f32_split:                                        # the knob did take the step's 3x3 unit-stride weight gradients
+        names = list(timer.summary())
+        assert any(k.startswith("wgrad_halo_x3_kernel") for k in names) and not any(k == "wgrad_halo_kernel" for k in names), names
     got = m.losses()
     for k in got:
         if k != "ssim":
