@@ -61,6 +61,24 @@ int shm_tune(int id);
         __builtin_amdgcn_s_barrier();                           \
     } while (0)
 
+// LDS-DMA the compiler does not see (round 5).  hipcc cannot tell an LDS access from the destination of an LDS-DMA in flight when the access has
+// no memory operand it can reason about -- ds_read_b64_tr_b16 through its builtin, any inline-asm access -- and waits vmcnt(0) in front of
+// it: in the bf16 weight-gradient kernels that is the first transposed read of every stage, i.e. the stage pipeline ("DMA two stages ahead,
+// counted s_waitcnt vmcnt") drained to the DMA issued a moment before (MFMA busy 0.34).  Issued as inline asm the DMA is invisible to that
+// pass and the kernels' own counted waits are the only ones.  rs: the four descriptor words (shm_rsrc_words); lds_addr: wave-uniform LDS
+// byte address of the 1 KiB destination (lane l lands at + 16 l); voff: per-lane byte offset into the buffer, out of range = zeros.
+typedef unsigned shm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ shm_u32x4 shm_rsrc_words(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return shm_u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void shm_dma16(const shm_u32x4 rs, const unsigned lds_addr, const unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ unsigned shm_lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 #define SHM_TG_COUNT 17           // SHM_TG_* of include/shmgan_hip.h
 
 // 4-channel vector access in either element type; arithmetic is always fp32.

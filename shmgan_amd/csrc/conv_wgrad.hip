@@ -919,9 +919,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
     const int ccX = second ? cX - a.c1 : cX;
     const int coD = co0 + sch * 8;
     const bool dvalid = coD < a.cout;
-    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
-                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    // descriptors as words: the DMA is issued as inline asm (common.h, shm_dma16)
+    const shm_u32x4 rsx = second ? shm_rsrc_words(a.x2, a.x2bytes) : shm_rsrc_words(a.x, a.xbytes);
+    const shm_u32x4 rsd = shm_rsrc_words(a.dy, a.dybytes);
     // items 0..9: halo rows [8i, 8i+8); items 10..13: dY rows.  Wave w takes items w, w+4, w+8, w+12.
     [[maybe_unused]] int hr[NXJ], hc[NXJ];                 // (NM: norm_x)
 #pragma unroll
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradHalo
             if (j < NJ - 1 || item < NIT) {
                 const bool isx = item < NXI;                   // wave-uniform
                 const unsigned off = (bm & (edges << (5 * j))) ? 0xffffffffu : off0[j] + (isx ? xb : db);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
+                shm_dma16(isx ? rsx : rsd, shm_lds_addr(sx + item * 512), off);
             }
         }
         pr += R;
@@ -1221,9 +1221,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
     const int cX = ci0 + sch * 8;
     const bool xvalid = cX < a.cin_ld;
     const int ccX = second ? cX - a.c1 : cX;
-    const __amdgpu_buffer_rsrc_t rsx = second ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000)
-                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    // descriptors as words: the DMA is issued as inline asm (common.h, shm_dma16)
+    const shm_u32x4 rsx = second ? shm_rsrc_words(a.x2, a.x2bytes) : shm_rsrc_words(a.x, a.xbytes);
+    const shm_u32x4 rsd = shm_rsrc_words(a.dy, a.dybytes);
 
     int n, pr, pc;                                      // patch origin in OUTPUT pixels
     {
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo8_bf16_kernel(const WgradHal
             if (j < NJ - 1 || item < NIT) {
                 const bool isx = item < NXI;                   // wave-uniform
                 const unsigned off = (bm & (edges << (5 * j))) ? 0xffffffffu : off0[j] + (isx ? xb : db);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx ? rsx : rsd, (lds_ptr)(sx + item * 512), 16, (int)off, 0, 0, 0);
+                shm_dma16(isx ? rsx : rsd, shm_lds_addr(sx + item * 512), off);
             }
         }
         pr += R;
