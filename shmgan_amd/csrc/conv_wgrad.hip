@@ -1776,7 +1776,17 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.ntpart = g_wnorm.part;
         hgs.ntc = g_wnorm.c;
         if (!want_nm && shm_tune(SHM_TUNE_WGRAD_F32_SPLIT) == 1) {        // "wgrad.f32_split": conv_wgrad_x3.hip
-            const int rc = shm_wgrad_x3_launch(hgs, cin, cout, nsh, st);
+            // stages of four pixel rows where the map allows ("wgrad.bf16_rows" = 2 keeps two): the patches and the split are re-cut for them
+            const int rows = (hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2) ? 4 : 2;
+            if (rows == 4) {
+                hgs.npatch = batch * (hi / 4) * (wi / 16);
+                int n4 = ns < hgs.npatch ? ns : hgs.npatch;
+                hgs.patches_per_split = shm_cdiv(hgs.npatch, n4);
+                n4 = shm_cdiv(hgs.npatch, hgs.patches_per_split);
+                nsh = n4;             // (never more slabs than the two-row cut: the workspace check above holds)
+                ns = n4;
+            }
+            const int rc = shm_wgrad_x3_launch(hgs, cin, cout, nsh, rows, st);
             if (rc != SHM_OK) return rc;
         } else {
         if (want_nm && g_wnorm.mode)

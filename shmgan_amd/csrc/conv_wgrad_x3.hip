@@ -213,9 +213,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
     }
 }
 
-int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, hipStream_t st) {
-    constexpr unsigned kLds = (3u * (4 * 20) + 3u * (2 * 16)) * 128u;      // 42 KiB: two blocks per CU
-    hipLaunchKernelGGL((wgrad_halo_x3_kernel<2>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsplit), dim3(256), kLds, st, hgs);
-    shm_set_last_kernel("wgrad_halo_x3_kernel<2>");
+int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st) {
+    const dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsplit);
+    if (rows == 4) {
+        constexpr unsigned kLds = (3u * (6 * 20) + 3u * (4 * 16)) * 128u;      // 69 KiB: two blocks per CU
+        static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s", hipGetErrorString(attr));
+        hipLaunchKernelGGL((wgrad_halo_x3_kernel<4>), grid, dim3(256), kLds, st, hgs);
+    } else {
+        constexpr unsigned kLds = (3u * (4 * 20) + 3u * (2 * 16)) * 128u;      // 42 KiB
+        hipLaunchKernelGGL((wgrad_halo_x3_kernel<2>), grid, dim3(256), kLds, st, hgs);
+    }
+    shm_set_last_kernel("wgrad_halo_x3_kernel<%d>", rows == 4 ? 4 : 2);
     return SHM_OK;
 }

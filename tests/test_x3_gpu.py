@@ -29,9 +29,15 @@ def _ws(nbytes):
     return torch.empty(max(nbytes // 4 + 1, 1024), device="cuda")
 
 
-def _run(x, x2, dy, cin, cout, n, h, w, split, accumulate=0, dw=None):
+def _x3_name(h, rows=0):
+    """stages of four pixel rows where the map height allows, unless "wgrad.bf16_rows" = 2"""
+    return f"wgrad_halo_x3_kernel<{4 if (h % 4 == 0 and rows != 2) else 2}>"
+
+
+def _run(x, x2, dy, cin, cout, n, h, w, split, accumulate=0, dw=None, rows=0):
     ops = _ops()
     ops.set_tuning("wgrad.f32_split", split)
+    ops.set_tuning("wgrad.bf16_rows", rows)
     c1 = x.shape[-1]
     if dw is None:
         dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
@@ -56,8 +62,11 @@ def test_x3_wgrad_matches_the_oracle_and_the_exact_kernel(n, h, w, cin, cout):
     xr, dr = x.astype(np.float32).astype(np.float64), dy.astype(np.float32).astype(np.float64)
     ref, = torch.autograd.grad(st.conv2d_same(nchw(xr), wt, 1), wt, nchw(dr))
     got, k = _run(dev(x), None, dev(dy), cin, cout, n, h, w, 1)
-    assert k == "wgrad_halo_x3_kernel<2>", k
+    assert k == _x3_name(h), k
     e3 = rel_l2(host(got), ref.numpy())
+    if h % 4 == 0:                            # ... and the two-row stages on the same shape
+        got2, k2 = _run(dev(x), None, dev(dy), cin, cout, n, h, w, 1, rows=2)
+        assert k2 == "wgrad_halo_x3_kernel<2>" and rel_l2(host(got2), ref.numpy()) < TOL
     exact, k0 = _run(dev(x), None, dev(dy), cin, cout, n, h, w, 0)
     assert k0 == "wgrad_halo_kernel", k0
     e1 = rel_l2(host(exact), ref.numpy())
@@ -82,7 +91,7 @@ def test_x3_wgrad_concat_source():
     dw = torch.empty((3, 3, c1 + c2, cout), device="cuda")
     ws = _ws(ops.conv2d_wgrad_workspace(n, h, h, c1 + c2, cout, 3))
     ops.conv2d_wgrad(dev(xa), dev(xb), c1, c1, c2, dev(dy), cout, dw, n, h, h, c1 + c2, c1 + c2, cout, 3, 1, 0, ws)
-    assert ops.last_kernel() == "wgrad_halo_x3_kernel<2>"
+    assert ops.last_kernel() == _x3_name(h)
     assert rel_l2(host(dw), ref.numpy()) < TOL
 
 
@@ -99,7 +108,7 @@ def test_x3_wgrad_is_exact_on_small_integers_and_keeps_specials():
     wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
     ref, = torch.autograd.grad(st.conv2d_same(nchw(x), wt, 1), wt, nchw(dy))
     got, k = _run(dev(x), None, dev(dy), cin, cout, n, h, h, 1)
-    assert k == "wgrad_halo_x3_kernel<2>"
+    assert k == _x3_name(h)
     g = host(got)
     same = g == ref.numpy()
     print(f"integer operands: {same.mean():.4f} of the elements bit-exact, max |sum| 2^{np.log2(np.abs(ref.numpy()).max()):.1f}")
