@@ -247,6 +247,49 @@ def test_wreg_four_wave_bf16(n, h, cin, cout):
         SYMBOL["wreg"] = sym
 
 
+def test_pingpong_repeat_launches_are_bitwise_identical():
+    """The ping-pong kernel orders its LDS traffic by hand (inline-asm LDS accesses beside an LDS-DMA in flight, counted waits, four barriers per
+    period): at the north star's size, which fills the chip, thirty launches of the forward block and of its input gradient must give the same
+    bits -- outputs and fused statistics -- and agree with the eight-wave kernel ("tapgemm.wreg16" = 1) to bf16 rounding of a different fp32
+    summation order.  (The race detector of round 2, tools/probes/conv_repeat_probe.py, as a test.)"""
+    ops = _ops()
+    n, h, c = 40, 256, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((n, h, h, c), device="cuda", generator=g).to(BF)
+    w = torch.randn((3, 3, c, c), device="cuda", generator=g) * 0.05
+    wk = torch.zeros(9 * c * c, device="cuda", dtype=BF)
+    ops.transpose_taps(w, wk, 9, c, c, c)
+    b = torch.randn(c, device="cuda", generator=g)
+    y = torch.empty((n, h, h, c), device="cuda", dtype=BF)
+    dx = torch.empty((n, h, h, c), device="cuda", dtype=BF)
+    stats = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    scr = torch.zeros(ops.STATS_SLOTS * n * c * 2, dtype=torch.float64, device="cuda")
+    ops.set_tuning("tapgemm.variant", "wreg")
+    first = None
+    for rep in range(30):
+        y.fill_(3.0)
+        dx.fill_(3.0)
+        ops.conv2d_in_fwd(x, None, 0, c, 0, wk, b, y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+        assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<2>"
+        ops.conv2d_dgrad(y, c, w.to(BF), dx, None, c, c, 0, n, h, h, c, c, 3, 1)
+        assert ops.last_kernel() == "tapgemm_pp_bf16_kernel<0>"
+        torch.cuda.synchronize()
+        cur = (y.clone(), stats.clone(), dx.clone())
+        if first is None:
+            first = cur
+        else:
+            # the statistics go through f64 atomics into a few slots: their order is not fixed, the sums agree to the last bits of a double
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[2], first[2]), rep
+            assert (cur[1] - first[1]).abs().max() <= 1e-12 * first[1].abs().max(), rep
+    ops.set_tuning("tapgemm.wreg16", 1)
+    ops.conv2d_in_fwd(x, None, 0, c, 0, wk, b, y, c, n, h, h, c, c, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+    assert ops.last_kernel() == "tapgemm_wreg16_bf16_kernel<2, true>"
+    torch.cuda.synchronize()
+    d = (y.float() - first[0].float()).abs()
+    assert float((d > 0).float().mean()) < 0.02 and float(d.max()) <= 0.0625 * float(first[0].float().abs().max())      # a bf16 ulp here and there
+    assert (stats - first[1]).abs().max() <= 1e-3 * first[1].abs().max()
+
+
 @pytest.mark.parametrize("dt,wreg16", [("f32", 1), ("bf16", 2), ("bf16", 1), ("bf16", 0)])
 def test_wreg_kernels_keep_a_nan_a_nan(dt, wreg16):
     """Round-3 advisor finding: the two-instruction LeakyReLU of the weights-in-registers kernels (common.h: shm_lrelu_max) was

@@ -8,7 +8,7 @@ tag=$1; shift
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
-args="--serialize --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer $*"
+args="--serialize --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-configs $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" $args > "$out/stats.log" 2>&1
 echo "[$tag] stats pass done"
@@ -29,7 +29,7 @@ python3 - "$tag" "$*" <<'PY'
 import json, os, sys
 tag, args = sys.argv[1], sys.argv[2]
 meta = {"tree": os.environ.get("SHM_TREE_SHA", "unknown"), "csrc_sha16": os.environ["SHM_CSRC_SHA"],
-        "command": "bench.py --serialize --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer " + args,
+        "command": "bench.py --serialize --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-configs " + args,
         "passes": ["--kernel-trace --stats", "--pmc FETCH_SIZE", "--pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
                    "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"]}
 for kind in ("traffic_pmc", "sq_pmc"):

@@ -7,7 +7,7 @@ root=$(pwd)
 out=$root/gpurun_out/trace_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out/t" -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer $* > "$out/log.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out/t" -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-extra-configs $* > "$out/log.txt" 2>&1
 cd "$root"
 f=$(find "$out/t" -name '*kernel_trace.csv' | head -1)
 export SHM_CSRC_SHA=$(cat shmgan_amd/csrc/*.hip shmgan_amd/csrc/*.h | sha256sum | cut -c1-16)
