@@ -455,9 +455,22 @@ def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps):
     mfma_us = timed(mfma) * (flops / (per_wave * waves * 16384.0))          # scaled to the block's exact FLOPs (rounding of per_wave)
     sv = stamps.view(-1, 2).double()
     clock = float((sv[:, 0] / sv[:, 1].clamp(min=1)).median()) * 0.1            # cycles per 10 ns tick -> GHz
+    # the same FLOPs in the ping-pong kernel's shape and geometry: v_mfma_f32_32x32x16_bf16, one eight-wave block per CU (two waves per SIMD)
+    L.ceil_mfma32_bf16.restype = C.c_int
+    L.ceil_mfma32_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    waves32 = ncu * 8
+    per_wave32 = int(flops / 32768 / waves32) // 8 * 8
+
+    def mfma32():
+        if L.ceil_mfma32_bf16(ops_.data_ptr(), sink.data_ptr(), stamps.data_ptr(), ncu, per_wave32, st) < 0:
+            raise RuntimeError("ceiling probe: MFMA (32x32x16) launch failed")
+    mfma32_us = timed(mfma32) * (flops / (per_wave32 * waves32 * 32768.0))
+    sv32 = stamps.view(-1, 2)[:waves32].double()
+    clock32 = float((sv32[:, 0] / sv32[:, 1].clamp(min=1)).median()) * 0.1
     copy_us = timed(copy)
     ceil_us = max(mfma_us, copy_us)
     return {"ceiling": {"mfma_us": round(mfma_us, 2), "mfma_tflops": round(flops / mfma_us / 1e6, 1), "mfma_clock_ghz": round(clock, 3),
+                        "mfma_32x32x16_us": round(mfma32_us, 2), "mfma_32x32x16_clock_ghz": round(clock32, 3),
                         "copy_us": round(copy_us, 2), "copy_GBps": round(2 * tensor_bytes / copy_us / 1e3, 1),
                         "what": "bare 16x16x32 bf16 MFMA loop with the block's FLOPs (random operands in registers, 4 waves per SIMD) / 16-byte "
                                 "streaming copy of the block's activation bytes; same process, after the product kernel"},

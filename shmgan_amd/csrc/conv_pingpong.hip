@@ -9,12 +9,14 @@
 //
 //   * ONE eight-wave block per CU (two waves per SIMD, 256 registers each), split into two GROUPS of four waves.  A group owns a stream of
 //     8 x 32-pixel patches (all 64 output channels: 2 (rows 0-3 / 4-7) x 2 (channels 0-31 / 32-63) waves) and alternates between an X segment
-//     -- the patch's 144 v_mfma_f32_32x32x16_bf16 per wave, operands: weights in 144 registers, activation fragments from the group's halo
-//     image in LDS -- and a Y segment: halo DMA of its NEXT patch, epilogue of the patch just computed (bias, LeakyReLU, bf16, LDS staging),
+//     -- the patch's 288 v_mfma_f32_16x16x32_bf16 per wave (2 channel tiles x 2 pixel tiles x 4 rows of 16 x 16 outputs), operands: weights in 144
+//     registers, activation fragments from the group's halo image in LDS -- and a Y segment: halo DMA of its NEXT patch, epilogue of the patch just computed (bias, LeakyReLU, bf16, LDS staging),
 //     whole-line stores.  The two groups run half a period apart, separated by workgroup barriers (two per segment: the Y segment's staging
 //     barrier falls behind step 48 of the other group's 72 X steps): on every SIMD one wave is in X while its partner is in Y, by construction.
-//   * 32x32x16 tiles: a fragment read (1 KiB per wave) feeds up to three MFMAs of 32 cycles (halo-row walk: halo row R, column shift cs serves
-//     patch rows R - kh), and the MFMA holds the vector issue port 8 of its 32 cycles, which leaves the port to the partner's epilogue.
+//   * A fragment read (1 KiB per wave: 16 pixels x 32 channels) feeds up to six MFMAs of 16 cycles (two channel tiles x the halo-row walk: halo row
+//     R, column shift cs serves patch rows R - kh).  The first version ran v_mfma_f32_32x32x16_bf16 (half the instructions, same registers); the
+//     launch is clock-bound and the chip holds a lower clock on that shape (bare loops, same FLOPs, sustained: 121 us at 1.33 GHz against 109 us
+//     at 1.67 GHz), item 6 below.
 //   * Halo image per group: [10 rows][34 pixels][128 bytes], single-buffered (it is refilled in the group's Y segment, after the barrier that ends
 //     its X segment), filled by LDS-DMA: wave w4 of the group fetches the 8-pixel column segment w4 of every halo row (ten 1 KiB items whose
 //     per-lane source offset is ONE lane constant plus a uniform term) and the two-pixel tails of rows w4, w4 + 4, w4 + 8; 16-byte chunk c of
@@ -41,9 +43,12 @@
 //      its MFMA: +14 cycles per read.  The twelve addresses are registers for the length of an X half (re-formed per half: kept across the Y
 //      segment they spill).  A second, statistics-free copy of the first X half in the loop made hipcc shuffle 84 register pairs per patch
 //      to reconcile two allocations: the statistics are a template parameter and the first patch runs them on garbage and drops the result.
-//   State: X 4 270 + 1 830 cycles (ideal 3 330 + 1 540), Y 1 500 (DMA issue) + 1 750 (epilogue) + 870 (stores), period 13 500 cycles at
-//   1.8 GHz; the launch 219 us against tapgemm_wreg16_bf16_kernel's 229 (forward + statistics) and 176 against 191 (input gradient), same box,
-//   sustained; at n = 8 and at 512 x 512 the two kernels tie.  The ~10 us prologue (36 weight loads per lane, first halo) is 6 % at n = 40.
+//   6. v_mfma_f32_32x32x16_bf16 -> 16x16x32: 13 570 -> 14 050 cycles per patch pair (the Y wave gets fewer issue slots: epilogue 1 800 -> 2 170), the
+//      sustained in-kernel clock 1.40-1.46 -> 1.56 GHz: forward + statistics 217-223 -> 214-218 us, input gradient 180 -> 171-176 us, n = 8 -3..-5 %.
+//   State: X 4 540 + 1 910 cycles (ideal 3 330 + 1 540), Y 1 360 (DMA issue) + 2 170 (epilogue) + 950 (stores), period 14 050 cycles at
+//   1.56 GHz sustained; the launch 214-218 us against tapgemm_wreg16_bf16_kernel's 229-235 (forward + statistics) and 171-176 against 186-190
+//   (input gradient), same box, sustained; n = 8: 52.5 against 52.7-57.9 / 39.7 against 41.6-42.0.  The ~12 us prologue (36 weight loads per
+//   lane, first halo) is 6 % at n = 40.
 //
 // LDS: 2 x 43 KiB halo + 2 x 32 KiB staging + bias = 150.25 KiB.  Eligible: K = 64, one source tensor, map height % 8 == 0 and width % 32 == 0,
 // Cout % 64 == 0 with 64-channel blocks inside one output part, outputs below 4 GiB, an image below 2 GiB.
@@ -59,28 +64,39 @@ constexpr int PP_STG = PP_PH * PP_PW * 128;                            // 32 KiB
 constexpr unsigned PP_LDS = 2u * PP_HALO + 2u * PP_STG + 256u;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-// the X segment's walk over (halo row rr, column shift cs, k step ks): rows 0 / 2 interleaved, row 1 | rows 5 / 3 interleaved, row 4
+// the X segment's walk over (halo row rr, column shift cs, 32-channel step k32, 16-pixel tile pt): rows 0 / 2 interleaved, row 1 | rows 5 / 3
+// interleaved, row 4; within a row (cs, k32, pt) with pt fastest
 struct PPStep {
-    int rr, cs, ks;
+    int rr, cs, k32, pt;
 };
 constexpr PPStep pp_step(int t) {
     const int half = t / 36, u = t % 36;
     const int idx = u < 24 ? u >> 1 : u - 24;
     const int rr = half == 0 ? (u < 24 ? ((u & 1) ? 2 : 0) : 1) : (u < 24 ? ((u & 1) ? 3 : 5) : 4);
-    return PPStep{rr, idx >> 2, idx & 3};
+    return PPStep{rr, idx >> 2, (idx >> 1) & 1, idx & 1};
 }
-// is step t the first one that accumulates into patch row m (its MFMA then takes C = 0)?
-constexpr bool pp_touches(int m, int t) { return pp_step(t).rr - m >= 0 && pp_step(t).rr - m <= 2; }
-constexpr bool pp_first(int m, int t) {
-    if (!pp_touches(m, t)) return false;
+// is step t the first one that accumulates into the tiles of (patch row m, pixel tile pt) (their MFMAs then take C = 0)?
+constexpr bool pp_touches(int m, int pt, int t) { return pp_step(t).pt == pt && pp_step(t).rr - m >= 0 && pp_step(t).rr - m <= 2; }
+constexpr bool pp_first(int m, int pt, int t) {
+    if (!pp_touches(m, pt, t)) return false;
     for (int u = 0; u < t; ++u)
-        if (pp_touches(m, u)) return false;
+        if (pp_touches(m, pt, u)) return false;
     return true;
 }
 template <int V>
 struct PPInt {
     static constexpr int value = V;
 };
+// compile-time loop: f(PPInt<T0>{}), ..., f(PPInt<T1 - 1>{}).  The X steps index register arrays (accumulators, weights) by functions of the step
+// number: with an unrolled run-time loop hipcc did not always fold them (the 16x16x32 form went to scratch with waterfall loops), here every
+// index is a constant expression by construction
+template <int T0, int T1, class F>
+__device__ __forceinline__ void pp_static_for(F&& f) {
+    if constexpr (T0 < T1) {
+        f(PPInt<T0>{});
+        pp_static_for<T0 + 1, T1>(f);
+    }
+}
 }  // namespace
 
 // MODE 0: plain product (input-gradient launches: no bias, slope 1, no statistics); 1: bias + LeakyReLU; 2: bias + LeakyReLU + InstanceNorm statistics
@@ -98,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
-    const int r = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.y * 64;
     char* const halo = smem + G * PP_HALO;
     char* const stg = smem + 2 * PP_HALO + G * PP_STG;
@@ -111,17 +127,22 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     const int q0 = min(npatch, (2 * bx + G) * per), q1 = min(npatch, q0 + per);
     const int ppr = a.wi / PP_PW, ppi = (a.hi / PP_PH) * ppr;
 
-    // ---- weights -> registers: A operand of v_mfma_f32_32x32x16_bf16, lane (r, h) holds row n0 + 32 wn + r, k = 16 ks + 8 h ... + 7
+    // ---- weights -> registers: A operand of v_mfma_f32_16x16x32_bf16, lane (l15, lq) holds row n0 + 32 wn + 16 ct + l15, k = 32 k32 + 8 lq ... + 7.
+    // (Round 5: the first version of this kernel ran v_mfma_f32_32x32x16_bf16 -- same registers, half the instructions.  The launch is clock-bound
+    // (LABNOTES 11.3) and the chip holds a lower clock on that shape: the bare loops of bench.py's ceiling probe, same FLOPs, sustained: 121 us at
+    // 1.33 GHz against 109 us at 1.67 GHz for 16x16x32.)
     const bool flip = P.dh[0] > 0;                       // input-gradient launch: taps arrive as (1 - kh, 1 - kw)
-    f32x4 bw[9][4];
+    f32x4 bw[9][2][2];                                   // [tap][k32][channel tile]
     {
         const bf16_t* wp = (const bf16_t*)a.w;
-        const int ncol = n0 + 32 * wn + r;
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int wsl = flip ? P.widx[8 - u] : P.widx[u];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bw[u][ks] = *(const f32x4*)(wp + ((size_t)wsl * a.nout + ncol) * a.K + ks * 16 + h * 8);
+            for (int k32 = 0; k32 < 2; ++k32)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    bw[u][k32][ct] = *(const f32x4*)(wp + ((size_t)wsl * a.nout + n0 + 32 * wn + 16 * ct + l15) * a.K + k32 * 32 + lq * 8);
         }
     }
     if (tid < 64) sbias[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
@@ -164,10 +185,11 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         }
     };
 
-    // ---- fragment addresses: pixel (halo row 4 wm + rr, halo column r + cs), chunk (2 ks + h) ^ (((r + cs) >> 1) & 7); rr is an immediate, ks an XOR of bits 5-6
+    // ---- fragment addresses (B operand: lane (l15, lq) holds pixel 16 pt + l15 + cs of halo row 4 wm + rr, channels 32 k32 + 8 lq ... + 7 = chunk
+    // 4 k32 + lq): position chunk ^ (((l15 + cs) >> 1) & 7) -- the tile's 16 pt leaves the swizzle alone; rr and pt are immediates, k32 an XOR of bit 6
     int fa[3];
 #pragma unroll
-    for (int cs = 0; cs < 3; ++cs) fa[cs] = G * PP_HALO + ((4 * wm * PP_HC) + r + cs) * 128 + ((h ^ (((r + cs) >> 1) & 7)) << 4);
+    for (int cs = 0; cs < 3; ++cs) fa[cs] = G * PP_HALO + ((4 * wm * PP_HC) + l15 + cs) * 128 + ((lq ^ (((l15 + cs) >> 1) & 7)) << 4);
 
     const bool part0 = n0 < a.n1;                        // block-uniform: the 64 channels lie in one output part (launcher)
     const __amdgpu_buffer_rsrc_t rsy = part0 ? __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000)
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             tlast = t;
         }
     };
-    f32x16_t acc[4];
+    f32x4 acc[4][2][2];                                  // [patch row m][pixel tile pt][channel tile ct]: four channels (4 lq + i) of pixel l15
     // X segment, steps [t0, t1) of the walk pp_step (72 steps; the first 36 are halo rows 0 - 2): the fragment of (halo row rr, column shift cs,
     // k step ks) feeds patch rows m = rr - kh, kh = 0 .. 2.  Fragments are read two steps ahead; the sched_barriers pin "issue the read, then
     // this step's MFMAs" (header comment)
@@ -212,27 +234,30 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         // one-MFMA step did not fit under its MFMA (stamps: +14 cycles per read)
         int fl[3] = {fa[0], fa[1], fa[2]};
         asm volatile("" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]));
-        auto frag = [&](int t) {
+        auto frag = [&](const int t) {               // t is a constant at every call site (always inlined)
             const PPStep st = pp_step(t < t1 ? t : t1 - 1);
             if constexpr (abl::nolds) return f32x4{1.f, 2.f, 3.f, 4.f};         // timing only: no fragment reads
-            return *(const f32x4*)(smem + ((fl[st.cs] ^ (st.ks << 5)) + st.rr * (PP_HC * 128)));
+            return *(const f32x4*)(smem + ((fl[st.cs] ^ (st.k32 << 6)) + st.rr * (PP_HC * 128) + st.pt * 2048));
         };
         f32x4 f0 = frag(t0), f1 = frag(t0 + 1), f2 = f1;
         if constexpr (depth == 3) f2 = frag(t0 + 2);
-#pragma unroll
-        for (int t = t0; t < t1; ++t) {
+        pp_static_for<t0, t1>([&](auto TT) {
+            constexpr int t = decltype(TT)::value;
+            constexpr PPStep st = pp_step(t);
             const f32x4 fn = frag(t + depth);
             pre(t);
             __builtin_amdgcn_sched_barrier(0);
-            const PPStep st = pp_step(t);
+            pp_static_for<0, 4>([&](auto MM) {
+                constexpr int m = decltype(MM)::value, kh = st.rr - m;
+                if constexpr (kh >= 0 && kh <= 2) {
+                    constexpr bool first = pp_first(m, st.pt, t);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int kh = st.rr - m;
-                if (kh >= 0 && kh <= 2) {
-                    const f32x16_t c0 = pp_first(m, t) ? f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : acc[m];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[kh * 3 + st.cs][st.ks]), __builtin_bit_cast(bf16x8, f0), c0, 0, 0, 0);
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const f32x4 c0 = first ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m][st.pt][ct];
+                        acc[m][st.pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[kh * 3 + st.cs][st.k32][ct]), __builtin_bit_cast(bf16x8, f0), c0, 0, 0, 0);
+                    }
                 }
-            }
+            });
             post(t);
             __builtin_amdgcn_sched_barrier(0);
             f0 = f1;
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             } else {
                 f1 = fn;
             }
-        }
+        });
     };
     auto nohook = [](int) {};
 
@@ -254,38 +279,41 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     const int stg_a = 2 * PP_HALO + G * PP_STG;           // LDS byte address of the group's staging image (smem starts at 0: the only LDS object)
     // Y segment, first half: next halo, epilogue of patch q into the staging image
     auto yhead = [&](const int q) {
-        f32x4 b4[4];
+        f32x4 b4[2];                                     // the lane's four channels 4 lq + i of each channel tile
         if constexpr (EPI) {
             int lb = lane;
             asm volatile("" : "+v"(lb));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b4[g] = *(const f32x4*)(sbias + 32 * wn + 8 * g + 4 * (lb >> 5));
+            for (int ct = 0; ct < 2; ++ct) b4[ct] = *(const f32x4*)(sbias + 32 * wn + 16 * ct + 4 * (lb >> 4));
         }
         if (q + 1 < q1 && !(abl::stamp && (dbg & 4))) dma(q + 1);          // dbg: timing-only ablations of the stamped build (4: no halo DMA after the first)
         stamp(4);                                // [4] bias reads + halo DMA issue
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int er = ln & 31, eh = ln >> 5;
-        const int st_w = stg_a + (4 * wm * 32 + er) * 128 + (((4 * wn) ^ (er & 7)) << 4) + (eh << 3);          // + m * 4096, chunk g: ^ (g << 4)
+        const int e15 = ln & 15, eq = ln >> 4;
+        // staging: pixel p = (4 wm + m) * 32 + 16 pt + e15, 16-byte chunk 4 wn + 2 ct + (eq >> 1) of its 128-byte row XOR p & 7 (= e15 & 7), half eq & 1
+        const int st_w = stg_a + (4 * wm * 32 + e15) * 128 + (((4 * wn + (eq >> 1)) ^ (e15 & 7)) << 4) + ((eq & 1) << 3);      // + m * 4096 + pt * 2048, ct: ^ (2 << 4)
         if (abl::stamp && (dbg & 8)) return;     // 8: no epilogue
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x2_t pk[4];
+        for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                f32x2 lo = {acc[m][4 * g], acc[m][4 * g + 1]}, hi = {acc[m][4 * g + 2], acc[m][4 * g + 3]};
-                if constexpr (EPI) {             // bias, LeakyReLU with 0 <= slope <= 1 (launcher): max(u, u * slope).  Scalar instructions on purpose (this
-                    // file is built with -fno-slp-vectorize): beside the partner wave's MFMAs a v_pk_add_f32 / v_pk_mul_f32 costs four times a v_add_f32
-                    lo = f32x2{shm_lrelu_max(lo.x + b4[g][0], a.slope), shm_lrelu_max(lo.y + b4[g][1], a.slope)};
-                    hi = f32x2{shm_lrelu_max(hi.x + b4[g][2], a.slope), shm_lrelu_max(hi.y + b4[g][3], a.slope)};
+            for (int ct = 0; ct < 2; ++ct) {
+                u32x2_t pk[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x2 lo = {acc[m][pt][ct][0], acc[m][pt][ct][1]}, hi = {acc[m][pt][ct][2], acc[m][pt][ct][3]};
+                    if constexpr (EPI) {         // bias, LeakyReLU with 0 <= slope <= 1 (launcher): max(u, u * slope).  Scalar instructions on purpose (this
+                        // file is built with -fno-slp-vectorize): beside the partner wave's MFMAs a v_pk_add_f32 / v_pk_mul_f32 costs four times a v_add_f32
+                        lo = f32x2{shm_lrelu_max(lo.x + b4[ct][0], a.slope), shm_lrelu_max(lo.y + b4[ct][1], a.slope)};
+                        hi = f32x2{shm_lrelu_max(hi.x + b4[ct][2], a.slope), shm_lrelu_max(hi.y + b4[ct][3], a.slope)};
+                    }
+                    pk[m] = u32x2_t{__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
                 }
-                pk[m] = u32x2_t{__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
+                const int aw = (st_w ^ (ct << 5)) + pt * 2048;
+                // patch rows m, m + 1 are 4096 bytes = 8 x (64 x 8 bytes) apart
+                asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:0 offset1:8" ::"v"(aw), "v"(pk[0]), "v"(pk[1]) : "memory");
+                asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:16 offset1:24" ::"v"(aw), "v"(pk[2]), "v"(pk[3]) : "memory");
             }
-            const int aw = st_w ^ (g << 4);
-            // patch rows m, m + 1 are 4096 bytes = 8 x (64 x 8 bytes) apart
-            asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:0 offset1:8" ::"v"(aw), "v"(pk[0]), "v"(pk[1]) : "memory");
-            asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:16 offset1:24" ::"v"(aw), "v"(pk[2]), "v"(pk[3]) : "memory");
-        }
     };
     // Y segment, second half: whole-line stores of the group's patch
     auto ytail = [&](const int q) {
@@ -409,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
                 xsteps(PPInt<0>{}, PPInt<XSPLIT>{}, PPInt<3>{}, nohook, nohook);
             }
         }
-        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
+        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]));
         stamp(0);                                // [0] first half of the MFMA steps
         SHM_LDS_BARRIER();
         stamp(1);                                // [1] wait at the mid-X barrier (= the other group's staging barrier)
@@ -417,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             xsteps(PPInt<XSPLIT>{}, PPInt<72>{}, PPInt<3>{}, nohook, nohook);
             if (abl::stamp && (dbg & 3) == 1) __builtin_amdgcn_s_setprio(0);
         }
-        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        if constexpr (abl::stamp) asm volatile("" ::"v"(acc[0][1][1]), "v"(acc[1][1][1]), "v"(acc[2][1][1]), "v"(acc[3][1][1]));
         stamp(2);                                // [2] second half
         SHM_LDS_BARRIER();                       // every wave of the group has read its last fragment: the halo image may be refilled
         stamp(3);                                // [3] wait at the end-of-X barrier

@@ -47,6 +47,39 @@ __global__ __launch_bounds__(512, 4) void ceil_mfma_kernel(const u32x4* __restri
     }
 }
 
+// the same FLOPs as v_mfma_f32_32x32x16_bf16 (the ping-pong kernel's shape): four accumulator tiles of 16 registers, half as many instructions
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512, 2) void ceil_mfma32_kernel(const u32x4* __restrict__ ops, float* __restrict__ out, unsigned long long* __restrict__ stamps,
+                                                            int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[2], b[2];
+    a[0] = __builtin_bit_cast(bf16x8, ops[lane]);
+    a[1] = __builtin_bit_cast(bf16x8, ops[64 + lane]);
+    b[0] = __builtin_bit_cast(bf16x8, ops[128 + lane]);
+    b[1] = __builtin_bit_cast(bf16x8, ops[192 + lane]);
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {           // 8 MFMAs per iteration
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[(m + j) & 1], acc[m], 0, 0, 0);
+    }
+    asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if (lane == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
 __global__ __launch_bounds__(256) void ceil_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += 4 * stride) {
@@ -65,6 +98,12 @@ extern "C" {
 int ceil_mfma_bf16(const void* ops, float* out, unsigned long long* stamps, int blocks, int mfmas_per_wave, void* stream) {
     const int iters = mfmas_per_wave / 8;
     hipLaunchKernelGGL(ceil_mfma_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const u32x4*)ops, out, stamps, iters);
+    return hipGetLastError() == hipSuccess ? iters * 8 : -1;
+}
+// the 32x32x16 form: mfmas_per_wave counts 32x32x16 instructions (32 768 FLOP each); two waves per SIMD at `blocks` = CUs
+int ceil_mfma32_bf16(const void* ops, float* out, unsigned long long* stamps, int blocks, int mfmas_per_wave, void* stream) {
+    const int iters = mfmas_per_wave / 8;
+    hipLaunchKernelGGL(ceil_mfma32_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const u32x4*)ops, out, stamps, iters);
     return hipGetLastError() == hipSuccess ? iters * 8 : -1;
 }
 int ceil_copy(const void* src, void* dst, size_t bytes, int blocks, void* stream) {
