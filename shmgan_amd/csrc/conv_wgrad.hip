@@ -1775,9 +1775,10 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.nt = g_wnorm.nt;
         hgs.ntpart = g_wnorm.part;
         hgs.ntc = g_wnorm.c;
-        if (!want_nm && shm_tune(SHM_TUNE_WGRAD_F32_SPLIT) == 1) {        // "wgrad.f32_split": conv_wgrad_x3.hip
+        if ((!want_nm || g_wnorm.mode == 0) && shm_tune(SHM_TUNE_WGRAD_F32_SPLIT) == 1) {        // "wgrad.f32_split": conv_wgrad_x3.hip (plain and SHM_NORM_EXACT sources)
             // stages of four pixel rows where the map allows ("wgrad.bf16_rows" = 2 keeps two): the patches and the split are re-cut for them
-            const int rows = (hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2) ? 4 : 2;
+            // (the normalising form keeps two rows: with four its 24 table values spill)
+            const int rows = (hi % 4 == 0 && shm_tune(SHM_TUNE_WGRAD_BF16_ROWS) != 2 && !want_nm) ? 4 : 2;
             if (rows == 4) {
                 hgs.npatch = batch * (hi / 4) * (wi / 16);
                 int n4 = ns < hgs.npatch ? ns : hgs.npatch;

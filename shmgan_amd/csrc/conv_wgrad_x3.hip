@@ -34,14 +34,17 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 }
 }  // namespace
 
-template <int R>
+// NM: the x source a.ntpart is the UN-normalised activation of an InstanceNorm block (SHM_NORM_EXACT, as wgrad_halo_kernel<1>): shm_in_norm on the in-image
+// pixels of the stage registers before the split; the block's 64 (mean, inv, beta) triples of the current sample sit in LDS behind the plane images
+template <int R, bool NM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloArgs a) {
     constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
     constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows
     constexpr int XP = NHR * 64, DP = NPX * 64;         // bf16 elements per x plane / dY plane
     constexpr int NXI = NHR / 8, NDI = NPX / 8;         // items of 8 rows x 64 channels: 10 + 4
     constexpr int NIT = NXI + NDI, NJ = (NIT + 3) / 4;  // items per wave: waves below NIT % 4 (or all) take NJ, the others NJ - 1
-    extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];       // [x plane 0..2][dY plane 0..2]
+    extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];       // [x plane 0..2][dY plane 0..2][NM: mean, inv, beta x 64]
+    [[maybe_unused]] float* const tab = (float*)(smem + 3 * XP + 3 * DP);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +100,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
     }
     // stage registers: eight fp32 channels per item and lane
     f32x4 sr[NJ][2];
+    [[maybe_unused]] int sn = 0, spr = 0, spc = 0;             // (NM) sample and origin of the patch the stage registers hold
     auto load = [&]() {
+        if constexpr (NM) {
+            sn = n;
+            spr = pr;
+            spc = pc;
+        }
         const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
         const unsigned edges = 16u | (pr == 0 ? 1u : 0u) | (pr + R == a.h ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc + PW == a.w ? 8u : 0u);
         const unsigned xb = (unsigned)(org * ldX) * 4u, db = (unsigned)(((n * a.h + pr) * a.w + pc) * a.lddy) * 4u;
@@ -122,13 +131,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
         }
     };
     // split the stage registers and write the six plane images
+    const bool nm_on = NM && a.nt != nullptr && (int)second == a.ntpart;        // block-uniform
+    [[maybe_unused]] int nimg = -1;
     auto spill = [&]() {
+        [[maybe_unused]] float nmean[8], ninv[8], nbeta[8];
+        if constexpr (NM)
+            if (nm_on) {
+                int lc = lane;
+                asm volatile("" : "+v"(lc));             // re-read per stage (24 registers across the MFMA loop would spill)
+                const int c8 = ((lc & 7) ^ ((((lc >> 3) >> 1) & 1) << 2)) * 8;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f32x4 m4 = *(const f32x4*)(tab + c8 + 4 * hf), i4 = *(const f32x4*)(tab + 64 + c8 + 4 * hf), b4 = *(const f32x4*)(tab + 128 + c8 + 4 * hf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nmean[4 * hf + e] = m4[e];
+                        ninv[4 * hf + e] = i4[e];
+                        nbeta[4 * hf + e] = b4[e];
+                    }
+                }
+            }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int item = wave + 4 * j;
             if (j < NJ - 1 || item < NIT) {
                 u32x4 p0, p1, p2;
-                const float v[8] = {sr[j][0][0], sr[j][0][1], sr[j][0][2], sr[j][0][3], sr[j][1][0], sr[j][1][1], sr[j][1][2], sr[j][1][3]};
+                float v[8] = {sr[j][0][0], sr[j][0][1], sr[j][0][2], sr[j][0][3], sr[j][1][0], sr[j][1][1], sr[j][1][2], sr[j][1][3]};
+                if constexpr (NM)
+                    if (nm_on && item < NXI) {
+                        const int hp = 8 * item + drow;
+                        const int r_ = hp / HP, c_ = hp - r_ * HP;
+                        const int iy = spr - 1 + r_, ix = spc - 1 + c_;
+                        if (xvalid && c_ < PW + 2 && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w) {       // padding stays zero
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = shm_in_norm(v[e], nmean[e], ninv[e], nbeta[e]);
+                        }
+                    }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned q0, q1, q2;
@@ -194,6 +232,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
         load();
         for (int s = 0; s < nstages; ++s) {
             SHM_LDS_BARRIER();                   // every wave has read the last fragment of the previous stage
+            if constexpr (NM)
+                if (nm_on && sn != nimg) {       // block-uniform: the stage in registers belongs to another sample than the table in LDS
+                    nimg = sn;
+                    if (tid < 192) {
+                        const int pl = tid >> 6, ch = ci0 - (second ? a.c1 : 0) + (tid & 63);
+                        tab[tid] = ch < a.ntc ? a.nt[((size_t)sn * SHM_NT_PLANES + pl) * a.ntc + ch] : 0.f;
+                    }
+                    SHM_LDS_BARRIER();
+                }
             spill();                             // (hipcc waits for the stage registers' loads here)
             if (s + 1 < nstages) load();         // the next stage's loads fly during this stage's MFMAs
             SHM_LDS_BARRIER();                   // the six plane images are complete
@@ -215,15 +262,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
 
 int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st) {
     const dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsplit);
+    const bool nm = hgs.nt != nullptr;               // SHM_NORM_EXACT source
     if (rows == 4) {
-        constexpr unsigned kLds = (3u * (6 * 20) + 3u * (4 * 16)) * 128u;      // 69 KiB: two blocks per CU
+        constexpr unsigned kLds = (3u * (6 * 20) + 3u * (4 * 16)) * 128u + 768u;      // 69 KiB: two blocks per CU
+        SHM_REQUIRE(!nm, SHM_E_SHAPE, "shm_conv2d_wgrad: the normalising x3 form runs stages of two rows");
         static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 69 KiB of LDS: %s", hipGetErrorString(attr));
         hipLaunchKernelGGL((wgrad_halo_x3_kernel<4>), grid, dim3(256), kLds, st, hgs);
     } else {
-        constexpr unsigned kLds = (3u * (4 * 20) + 3u * (2 * 16)) * 128u;      // 42 KiB
-        hipLaunchKernelGGL((wgrad_halo_x3_kernel<2>), grid, dim3(256), kLds, st, hgs);
+        constexpr unsigned kLds = (3u * (4 * 20) + 3u * (2 * 16)) * 128u + 768u;      // 42 KiB
+        if (nm) hipLaunchKernelGGL((wgrad_halo_x3_kernel<2, true>), grid, dim3(256), kLds, st, hgs);
+        else hipLaunchKernelGGL((wgrad_halo_x3_kernel<2>), grid, dim3(256), kLds, st, hgs);
     }
-    shm_set_last_kernel("wgrad_halo_x3_kernel<%d>", rows == 4 ? 4 : 2);
+    shm_set_last_kernel(nm ? "wgrad_halo_x3_kernel<%d, true>" : "wgrad_halo_x3_kernel<%d>", rows == 4 ? 4 : 2);
     return SHM_OK;
 }

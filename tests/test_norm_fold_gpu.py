@@ -168,7 +168,7 @@ def _wgrad(x, x2, c1, dy, n, h, cin, cout, **kw):
     return dw, ops.last_kernel()
 
 
-@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2)])
+@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2), ("f32x3", 2)])       # f32x3: "wgrad.f32_split" (csrc/conv_wgrad_x3.hip)
 @pytest.mark.parametrize("n,h,cin,cout,blocks", [
     (3, 16, 64, 64, 0),
     (2, 32, 128, 64, 0),
@@ -178,6 +178,10 @@ def _wgrad(x, x2, c1, dy, n, h, cin, cout, **kw):
 def test_wgrad_fold_is_bit_identical(dt, rows, n, h, cin, cout, blocks):
     ops = _ops()
     rng = np.random.default_rng(13)
+    x3 = dt == "f32x3"
+    if x3:
+        dt = "f32"
+        ops.set_tuning("wgrad.f32_split", 1)
     a, stats, beta, nt, ahat = _block(rng, n, h, cin, dt)
     dy = _t(rng.standard_normal((n, h, h, cout)), dt)
     if rows:
@@ -186,7 +190,10 @@ def test_wgrad_fold_is_bit_identical(dt, rows, n, h, cin, cout, blocks):
         ops.set_tuning("wgrad.blocks", blocks)
     dw0, k0 = _wgrad(ahat, None, 0, dy, n, h, cin, cout)
     dw1, k1 = _wgrad(a, None, 0, dy, n, h, cin, cout, nt_x=nt)
-    assert k1 != k0 and k1.rstrip(">").endswith("1"), (k0, k1)
+    if x3:
+        assert (k0, k1) == ("wgrad_halo_x3_kernel<2>", "wgrad_halo_x3_kernel<2, true>"), (k0, k1)
+    else:
+        assert k1 != k0 and k1.rstrip(">").endswith("1"), (k0, k1)
     assert torch.equal(dw0, dw1), (k1, float((dw0 - dw1).abs().max()))
 
 
@@ -313,7 +320,7 @@ def test_concat_scaled_mode(variant, n, h, cu, cs, cout, dt):
     assert ok, (k1, err)
 
 
-@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2)])
+@pytest.mark.parametrize("dt,rows", [("f32", 0), ("bf16", 4), ("bf16", 2), ("f32x3", 2)])       # f32x3: "wgrad.f32_split" (csrc/conv_wgrad_x3.hip)
 @pytest.mark.parametrize("n,h,cin,cout,c1", [(3, 16, 64, 64, 0), (2, 32, 128, 64, 0), (5, 16, 64, 128, 0), (2, 48, 64, 64, 0), (2, 32, 192, 64, 64)])
 def test_wgrad_scaled_mode(dt, rows, n, h, cin, cout, c1):
     """sum x_hat * dz = inv * sum a_ext * dz (kernel: `ring` outside the image, slab rows times inv, splits on sample boundaries)
