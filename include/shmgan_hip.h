@@ -75,7 +75,7 @@ const char* shm_last_kernel(void);
  *   "wgrad.variant"             0 automatic, 1 generic kernels only, 2 halo kernels without thin-input packing, 3 no stride-2 halo form
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)
  *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4
- *   "wgrad.f32_split"           fp32 3x3 unit-stride weight gradient (the halo kernel's shapes, no fused normalisation): 1 = six v_mfma_f32_32x32x16_bf16
+ *   "wgrad.f32_split"           fp32 3x3 unit-stride weight gradient (the halo kernel's shapes, plain and SHM_NORM_EXACT sources): 1 = six v_mfma_f32_32x32x16_bf16
  *                               products of the exact three-plane bf16 splits of x and dY with fp32 accumulation (wgrad_halo_x3_kernel; rounds like an
  *                               fp32 dot product, rel-L2 ~1e-7), 0 (default) = exact-fp32 MFMA.  Opt-in: bench.py --dtype f32x3
  *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
