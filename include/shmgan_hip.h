@@ -78,6 +78,7 @@ const char* shm_last_kernel(void);
  *   "wgrad.f32_split"           fp32 3x3 unit-stride weight gradient (the halo kernel's shapes, plain and SHM_NORM_EXACT sources): 1 = six v_mfma_f32_32x32x16_bf16
  *                               products of the exact three-plane bf16 splits of x and dY with fp32 accumulation (wgrad_halo_x3_kernel; rounds like an
  *                               fp32 dot product, rel-L2 ~1e-7), 0 (default) = exact-fp32 MFMA.  Opt-in: bench.py --dtype f32x3
+ *   "elem.fused_bwd"            bf16 shm_in_bwd: 1 (default) = the one-pass form where shm_in_bwd_fused_scratch was given and the shape fits, 0 = two passes
  *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
  *                               3 at unit stride only, 4 both
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
@@ -245,6 +246,16 @@ size_t shm_conv2d_wgrad_norm_workspace(int batch, int hi, int wi, int cin, int c
 int shm_conv2d_wgrad_norm_finish(float* dw, const float* nt, const double* dzsum, int batch, int c, int part_lo, int cin, int cout,
                                  int ksize, void* stream);
 int shm_in_bwd_keep_dz_sums(double* dst);
+/* One-pass bf16 form of shm_in_bwd (round 5, in_bwd_fused8_kernel: a block keeps its slice of g1 / g2 / a in registers between the reduce and
+ * the apply phase, the blocks of a sample meet at a per-sample barrier; 3 tensor passes over HBM instead of 5).  The NEXT shm_in_bwd call of this
+ * thread may use `scratch` = f64 [n_doubles], n_doubles >= SHM_IN_BWD_FUSED_DOUBLES(batch, h * w, c), zero on entry and zero again on return
+ * (outside the per-block partial rows at its front, which every launch rewrites in full and which may hold anything).
+ * One-shot (NULL disarms).  Taken for dtype SHM_BF16, c % 8 == 0, c <= 512, 256 % (c / 8) == 0, h * w a multiple of the 16384 / c pixel
+ * slice and at most 256 slices per sample, tuning "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics:
+ * the sums are added in block order (bitwise reproducible). */
+#define SHM_IN_BWD_FUSED_DOUBLES(batch, hw, c) \
+    (((size_t)(batch) * ((size_t)(hw) * (size_t)(c) / 16384) * 3 * (size_t)(c) + 1) / 2 + (size_t)(batch) * (size_t)(c) + (size_t)(batch) * 288 + 1)
+int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles);
 /* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers
  * normalise a on the fly, only the pool's consumer needs a tensor.  Same bits as shm_in_apply_pool's `pooled`. */
 int shm_in_pool(const void* a, int lda, const double* stats, const float* beta, void* pooled, int ldp, int batch, int h, int w,

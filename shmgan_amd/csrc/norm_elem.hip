@@ -59,6 +59,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"wgrad.bf16_wide", "SHM_WGRAD_BF16_WIDE", 0, 0, 4},
     {"wgrad.f32_split", "SHM_WGRAD_F32_SPLIT", 0, 0, 1},
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
+    {"elem.fused_bwd", "SHM_ELEM_FUSED_BWD", 1, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -823,6 +824,271 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
     if (k.dbias) block_reduce_atomic<1>(v, pm, (RAW ? k.dstage : k.red + (size_t)k.nbatch * k.c * 2) + (size_t)n * k.c, k.c, true);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// bf16 InstanceNorm backward in ONE pass over HBM (round 5).  The two-pass form reads g and a twice (reduce, apply): the
+// second read of a 34-335 MB tensor pair comes from HBM again (l2_hit 0.02-0.26 in profiles/r05_bf16_traffic_pmc.json).  Here a block
+// KEEPS its slice of g and a (and of the pooled gradient g2) in registers between the two phases: 8 pixels x 8 channels x 2-3 tensors per
+// thread as raw bf16 (64-96 VGPRs), and the blocks of one SAMPLE meet at a per-sample barrier between the phases:
+//   phase 1: partial sums (sum g, sum g * xhat) of the slice -> LDS combine -> the block's own row of a partials table (plain coherent stores:
+//            no float atomics anywhere -- the first version's 192 f64 atomics per block, 2 M per launch, WERE the launch: 1.36 ms against 0.38)
+//   barrier: arrival counter of the sample; the LAST ARRIVER adds the rows in block order (bitwise reproducible), publishes the two means of every
+//            channel and raises the release flags (details at the code).  The blocks of a sample are consecutive block ids (blockIdx.y = sample)
+//            and at most 256 of them (the launcher falls back to two passes otherwise): a whole sample is resident long before the chip is
+//            full (>= 512 blocks fit), blocks are dispatched in id order, so the earliest incomplete sample always completes.  A block that
+//            would spin for more than ~1 s raises the scratch's timeout word and goes on (wrong numbers, never a hang).
+//   phase 2: every block applies from its registers with the published means, stores dz and writes its row of bias-gradient partials; the last
+//            block to leave adds those rows in block order into the per-sample staging and clears the sample's counters, flags and means
+//            (scratch: zero on entry, zero on return -- the partial rows are rewritten in full by every launch and need no clearing).
+// HBM traffic: g + a read once, dz written once = 3 tensor passes instead of 5.  Phase stamps (tools/probes/in_bwd_fused_stamps.py, n = 40 at
+// 256 x 256 x 64, median per block): slices loaded 3.1 us, rows written 2.4, arrival to release 13.8 (of which ~5 waiting for the sample's last
+// block), phase 2 stores 1.2, departure 2.3: 23 us per block with 768 resident.  Starting the samples of the first resident generation a fraction
+// of a period apart changed nothing (the launch is bound by that latency chain times the residency, not by a memory phase all blocks share).
+constexpr int SHM_FUSED_FLAGS = 16, SHM_FUSED_SYNC_WORDS = 32 * (SHM_FUSED_FLAGS + 2);
+// scratch (float64 units): partials f32 [batch][bpi][3 c] (sum g, sum g * xhat interleaved, then sum dz) | means f32 [batch][c][2] | sync u32
+// [batch][SYNC_WORDS] | timeout word.  bpi = blocks per sample = h * w * c / 16384.
+static size_t fused_row_doubles(int batch, size_t bpi, int c) { return ((size_t)batch * bpi * 3 * c + 1) / 2; }        // fp32 rows
+static size_t fused_scratch_doubles(int batch, int hw, int c) {
+    const size_t bpi = (size_t)hw * c / 16384;
+    return fused_row_doubles(batch, bpi, c) + (size_t)batch * c + (size_t)batch * (SHM_FUSED_SYNC_WORDS / 2) + 1;
+}
+__device__ __forceinline__ f32x8 unpack8(const shm_u32x4 u) {
+    f32x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r[2 * i] = __uint_as_float(u[i] << 16);
+        r[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+    return r;
+}
+// coherent (device-scope, L2-bypassing) accesses without fences: see the barrier below
+template <typename V>
+__device__ __forceinline__ V coh_load(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V>
+__device__ __forceinline__ void coh_store(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool G2>
+__global__ __launch_bounds__(256, G2 ? 2 : 3) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
+                                                                         unsigned* __restrict__ fsync, unsigned* __restrict__ ferr) {
+    constexpr int U = 8;
+    __shared__ double red[256 * 8];
+    __shared__ float sm12[1024];
+    __shared__ int s_last;
+    const int lanes_c = k.c >> 3, PP = 256 / lanes_c;                  // the launcher guarantees 256 % lanes_c == 0: every thread is active
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
+    const int n = k.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, hw = k.h * k.w;
+    const int pbase = blockIdx.x * (U * PP) + pp;                      // pixel of slot u: pbase + u * PP (hw % (U * PP) == 0)
+    const int bpi = gridDim.x, c3 = 3 * k.c;
+    float* const prow0 = fpart + (size_t)n * bpi * c3;                 // the sample's rows; row b = [c][2] sums, then [c] bias-gradient partials
+    float* const prow = prow0 + (size_t)blockIdx.x * c3;               // (fp32: a row holds sums over one slice, and the means are fp32 in the end)
+
+#ifdef SHM_FUSED_STAMP
+    unsigned long long* const stamp = (unsigned long long*)(ferr + 2) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+#define FSTAMP(i) do { if (threadIdx.x == 0) stamp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+    FSTAMP(0);
+    shm_u32x4 gq[U], aq[U];
+    [[maybe_unused]] shm_u32x4 hq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = pbase + u * PP;
+        const size_t off = (size_t)n * hw + p;
+        gq[u] = *(const shm_u32x4*)((const bf16_t*)k.g1 + off * k.ldg1 + cl * 8);
+        aq[u] = *(const shm_u32x4*)((const bf16_t*)k.a + off * k.lda + cl * 8);
+        if constexpr (G2) {
+            const int y = p / k.w, x = p - y * k.w;
+            const size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
+            hq[u] = *(const shm_u32x4*)((const bf16_t*)k.g2 + q * k.ldg2 + cl * 8);
+        }
+    }
+    float mean[8], inv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2];
+        inv[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2 + 1];
+    }
+    auto gval = [&](int u) {
+        f32x8 g = unpack8(gq[u]);
+        if constexpr (G2) {
+            const f32x8 h = unpack8(hq[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += 0.25f * h[e];
+        }
+        return g;
+    };
+    // Combine NV x 8 per-thread values over the PP pixel slots and store them: value j of channel ch lands at dst[ch * stride + j].  Every thread
+    // parks its values in LDS (fp32, [j][pp][c]), thread t < NV * c adds the PP terms of one output (consecutive threads read consecutive words).
+    // (The first version -- eight threads adding 32 LDS doubles each, twice -- took 21 of a block's 46 us; xor-shuffles spilled 116 registers.)
+    float* const redf = (float*)red;
+    auto park = [&](const float (&v)[8], int j) {
+        *(f32x4*)&redf[j * 2048 + threadIdx.x * 8] = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)&redf[j * 2048 + threadIdx.x * 8 + 4] = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    auto finish = [&](int nv, float* dst, int stride) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < k.c * nv; t += 256) {
+            const int j = t / k.c, ch = t - j * k.c;
+            float sum = 0.f;
+            for (int q = 0; q < PP; ++q) sum += redf[j * 2048 + q * k.c + ch];
+            coh_store(&dst[ch * stride + j], sum);
+        }
+    };
+    // Sums of `npairs` consecutive float PAIRS of every row of the sample, in a fixed order (bitwise reproducible): thread (rg, q) adds pair q of
+    // rows rg, rg + RG, ... (sixteen 8-byte coherent loads in flight), the RG partial sums meet in LDS; on return thread v < 2 * npairs calls
+    // total(v).  (One thread per value walking all 256 rows, eight loads at a time, made the barrier 45 us long.)
+    auto rowsum = [&](const float* base, int npairs) {
+        const int P = npairs < 256 ? npairs : 256, RG = 256 / P, rg = threadIdx.x / P;
+        __syncthreads();
+        for (int q = threadIdx.x % P; q < npairs; q += P) {
+            double s0 = 0.0, s1 = 0.0;
+            const unsigned long long* col = (const unsigned long long*)base + q;
+            const size_t rs = (size_t)c3 / 2;                                // row stride in pairs (c3 is even)
+            int b = rg;
+            for (; b + 15 * RG < bpi; b += 16 * RG) {
+                unsigned long long t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = coh_load(col + (size_t)(b + j * RG) * rs);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    s0 += (double)__uint_as_float((unsigned)t[j]);
+                    s1 += (double)__uint_as_float((unsigned)(t[j] >> 32));
+                }
+            }
+            for (; b < bpi; b += RG) {
+                const unsigned long long t = coh_load(col + (size_t)b * rs);
+                s0 += (double)__uint_as_float((unsigned)t);
+                s1 += (double)__uint_as_float((unsigned)(t >> 32));
+            }
+            red[(rg * npairs + q) * 2] = s0;
+            red[(rg * npairs + q) * 2 + 1] = s1;
+        }
+        __syncthreads();
+        return RG;
+    };
+    auto total = [&](int v, int npairs, int RG) {
+        double s = 0.0;
+        for (int r = 0; r < RG; ++r) s += red[(r * npairs + (v >> 1)) * 2 + (v & 1)];
+        return s;
+    };
+    // ---- phase 1
+    {
+        float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef SHM_FUSED_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FSTAMP(1);
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x8 g = gval(u), x = unpack8(aq[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (x[e] - mean[e]) * inv[e];
+                sg[e] += g[e];
+                sx[e] += g[e] * xh;
+            }
+        }
+        __syncthreads();
+        park(sg, 0);
+        park(sx, 1);
+        finish(2, prow, 2);
+    }
+    // ---- the sample's barrier.  No agent-scope FENCES: on a multi-XCD chip a release fence is buffer_wbl2 (write the XCD's dirty L2 lines back)
+    // and every acquire -- one per poll -- a buffer_inv of the L2 (0.65 ms per launch with ~1000 resident blocks).  Everything the blocks exchange
+    // moves through device-scope relaxed atomics (loads, stores, the two counters), which are performed at the device's coherence point: a block
+    // waits for the acknowledgement of its stores (vmcnt) and then counts its arrival.  And no crowd on one address: 256 blocks polling the arrival
+    // counter queue their reads in front of the arrivals themselves (measured: 41 us per sample).  The LAST ARRIVER (it alone knows every row is
+    // in) publishes the means and raises SHM_FUSED_FLAGS copies of the release flag, each in its own 128-byte line; block b polls copy b % 16.
+    unsigned* const sy = fsync + (size_t)n * SHM_FUSED_SYNC_WORDS;        // [0] arrivals, [32] departures, [64 + 32 j] flag copy j
+    float* const res = fres + (size_t)n * k.c * 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FSTAMP(2);
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+    __syncthreads();
+    FSTAMP(3);
+    if (s_last) {
+        const int RG = rowsum(prow0, k.c);
+        for (int v = threadIdx.x; v < 2 * k.c; v += 256) {
+            const float r = (float)(total(v, k.c, RG) / hw);
+            sm12[v] = r;
+            coh_store(res + v, r);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the means are written before a flag goes up
+        __syncthreads();
+        if (threadIdx.x < SHM_FUSED_FLAGS) coh_store(sy + 64 + 32 * threadIdx.x, 1u);
+    } else {
+        if (threadIdx.x == 0) {
+            const unsigned* const flag = sy + 64 + 32 * (blockIdx.x % SHM_FUSED_FLAGS);
+            int spins = 0;
+            while (coh_load(flag) == 0u) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 20)) {
+                    __hip_atomic_fetch_or(ferr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < k.c * 2; i += 256) sm12[i] = coh_load(res + i);
+    }
+    __syncthreads();
+    FSTAMP(4);
+    // ---- phase 2 (the raw slices pass through an opaque copy: otherwise hipcc keeps phase 1's UNPACKED values alive across the barrier and spills)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        asm volatile("" : "+v"(gq[u]), "+v"(aq[u]));
+        if constexpr (G2) asm volatile("" : "+v"(hq[u]));
+    }
+    int pb2 = pbase;                  // (opaque as well: the store addresses are formed here, not carried from the loads at the top)
+    asm volatile("" : "+v"(pb2));
+    float m1[8], m2[8], sd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m1[e] = sm12[(cl * 8 + e) * 2];
+        m2[e] = sm12[(cl * 8 + e) * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const f32x8 g = gval(u), x = unpack8(aq[u]);
+        typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (x[e] - mean[e]) * inv[e];
+            const float da = inv[e] * (g[e] - m1[e] - xh * m2[e]);
+            const float d = x[e] > 0.f ? da : da * k.slope;
+            sd[e] += d;
+            o[e] = (bf16_t)d;
+        }
+        *(bf16x8_t*)((bf16_t*)k.dz + ((size_t)n * hw + pb2 + u * PP) * k.lddz + cl * 8) = o;
+    }
+    FSTAMP(5);
+    if (k.dbias) {
+        __syncthreads();
+        park(sd, 0);
+        finish(1, prow + 2 * k.c, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's row is written before its departure is counted
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+    __syncthreads();
+    FSTAMP(6);
+    if (s_last) {                     // every block of the sample is through: the bias-gradient staging of the sample, then a clean scratch
+        if (k.dbias) {
+            const int RG = rowsum(prow0 + 2 * k.c, k.c / 2);
+            for (int ch = threadIdx.x; ch < k.c; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + ch] = total(ch, k.c / 2, RG);
+        }
+        for (int i = threadIdx.x; i < k.c * 2; i += 256) coh_store(res + i, 0.f);
+        if (threadIdx.x < SHM_FUSED_FLAGS + 2) coh_store(sy + 32 * threadIdx.x, 0u);
+    }
+#ifdef SHM_FUSED_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FSTAMP(7);
+#endif
+#undef FSTAMP
+}
+
 // shm_in_bwd_apply's last launch: fold the staged bias gradient (dbias[ch] += sum over samples) and clear the gsum slot copies the
 // apply pass consumed -- "zero on entry, zero on return" for every f64 scratch, no memset in front of a launch.
 // keep != null: the per-sample sums are also copied out ([nslot = batch][c]: shm_in_bwd_keep_dz_sums)
@@ -937,6 +1203,16 @@ extern "C" int shm_in_bwd_keep_dz_sums(double* dst) {
     g_keep_dzsum = dst;
     return SHM_OK;
 }
+// shm_in_bwd_fused_scratch: scratch of the one-pass bf16 form (in_bwd_fused8_kernel) for the next shm_in_bwd call of this thread: n_doubles >=
+// SHM_IN_BWD_FUSED_DOUBLES(batch, h * w, c) float64 (fused_scratch_doubles above), zero on entry, zero on return.  One-shot; without it (or on shapes the one-pass form does
+// not take) shm_in_bwd runs its two passes.
+static thread_local double* g_fused_scratch = nullptr;
+static thread_local size_t g_fused_doubles = 0;
+extern "C" int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles) {
+    g_fused_scratch = scratch;
+    g_fused_doubles = scratch ? n_doubles : 0;
+    return SHM_OK;
+}
 
 static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2, int ldg2, const float* r1_dz, const float* r1_w, const void* a, int lda,
                        const double* stats, double* red, void* dz, int lddz, double* dbias, int batch, int h, int w, int c, float slope, int dtype,
@@ -944,6 +1220,10 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     const bool r1 = r1_dz != nullptr;
     double* const keep = g_keep_dzsum;
     g_keep_dzsum = nullptr;
+    double* const fscr = g_fused_scratch;
+    const size_t fscr_n = g_fused_doubles;
+    g_fused_scratch = nullptr;
+    g_fused_doubles = 0;
     SHM_REQUIRE(!keep || dbias, SHM_E_SHAPE, "%s: the per-sample dz sums are staged only with a bias gradient", who);
     SHM_CHECK_C(c, who);
     SHM_REQUIRE((r1 || ldg1 % 4 == 0) && lda % 4 == 0 && lddz % 4 == 0 && (!g2 || ldg2 % 4 == 0), SHM_E_SHAPE, "%s: bad pitch", who);
@@ -962,6 +1242,29 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
                        (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
+    // The one-pass form (in_bwd_fused8_kernel, "elem.fused_bwd"): bf16 tensors, whole slices of 8 x (2048 / c) pixels, at most 256 blocks per sample
+    {
+        const int lanes8 = c / 8, pp8 = lanes8 > 0 && 256 % lanes8 == 0 ? 256 / lanes8 : 0;
+        const int slice = 8 * pp8;
+        if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && c % 8 == 0 && c <= 512 && pp8 > 0 && ldg1 % 8 == 0 && lda % 8 == 0 &&
+            lddz % 8 == 0 && (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= 256 && batch <= 65535 &&
+            fscr_n >= fused_scratch_doubles(batch, hw, c)) {
+            float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));
+            unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);
+            unsigned* const ferr = fsync + (size_t)batch * SHM_FUSED_SYNC_WORDS;
+            const dim3 gridf(hw / slice, batch);
+            if (g2) hipLaunchKernelGGL((in_bwd_fused8_kernel<true>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
+            else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
+            shm_set_last_kernel(g2 ? "in_bwd_fused8_kernel<true>" : "in_bwd_fused8_kernel<false>");
+            const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
+            SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);
+            if (dbias) {       // (the two sum planes in front of the staging were not used: nothing to clear)
+                hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, (double*)nullptr, keep);
+                SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
+            }
+            return SHM_OK;
+        }
+    }
     // Sample chunks ("elem.chunk_mb", round 3): the apply pass re-reads what the reduce pass read.  On tensors larger than the 256 MiB
     // Infinity Cache that second read comes from HBM again (the back-to-front / front-to-back walk only saves the turning point);
     // run as reduce(chunk), apply(chunk) over chunks whose g + a fit the cache, the second read stays on die.  0 = one chunk.
@@ -1009,6 +1312,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         else
             SHM_DISPATCH_G(dtype, who, hipLaunchKernelGGL((in_bwd_apply_kernel<T, TG, false>), grid, dim3(256), 0, st, k));
     }
+    shm_set_last_kernel(wide8 ? "in_bwd_reduce8_kernel + in_bwd_apply_kernel" : "in_bwd_reduce_kernel + in_bwd_apply_kernel");
     const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
     SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(apply)", red, red_bytes, st);
     if (dbias) {

@@ -73,7 +73,7 @@ class Arena:
             # return" by contract, so they start out zeroed
             alloc = torch.zeros if dtype == torch.float64 else torch.empty
             t = alloc(tuple(shape), dtype=dtype, device=self.device)
-            if dtype == torch.float64:
+            if dtype == torch.float64 and torch.device(self.device).type == "cuda":
                 # the zero fill runs on whichever stream is current (a part of a two-stream forward allocates on the second
                 # stream) while slices of the buffer are about to be used on another one: wait for it once, at allocation
                 torch.cuda.current_stream(self.device).synchronize()
@@ -98,9 +98,25 @@ class Arena:
             self.t[key + ("storage",)] = flat
         return t
 
+    def fused_timeouts(self):
+        """Names of the one-pass InstanceNorm-backward scratches (_fused_scratch) whose timeout word is set: a sample barrier of
+        in_bwd_fused8_kernel gave up waiting (the launch then went on with wrong means instead of hanging).  One device-to-host copy."""
+        items = [(k[0], t) for k, t in self.t.items() if isinstance(k[0], str) and k[0].startswith("bwd/fused/")]
+        if not items:
+            return []
+        words = torch.stack([t[-1] for _, t in items]).cpu().tolist()
+        return [name for (name, _), w in zip(items, words) if w != 0.0]
+
     def nbytes(self):
         # a get_slack tensor is a view of its "storage" entry: count the storage
         return sum(t.numel() * t.element_size() for k, t in self.t.items() if not (len(k) == 4 and isinstance(k[3], int)))
+
+
+def _fused_scratch(arena, adt, n, hw, c):
+    """Scratch of the one-pass bfloat16 InstanceNorm backward (ops.in_bwd(fused=)): zero-filled float64, left zero by every call."""
+    if adt != torch.bfloat16:
+        return None
+    return arena.get(f"bwd/fused/{n}x{hw}x{c}", (ops.in_bwd_fused_doubles(n, hw, c),), torch.float64)
 
 
 class WgradLane:
@@ -689,7 +705,7 @@ class Generator(_ModelBase):
             else:
                 red = A.get(f"bwd/red/{n * cout}", (n * cout * 3,), torch.float64)
                 ops.in_bwd(g1, cout, g2, cout, rec["a"], cout, rec["stats"], red, dz, cout, self._acc_slice(2 * li + 1), n,
-                           h, w, cout, LRELU)
+                           h, w, cout, LRELU, fused=_fused_scratch(A, self.adt, n, h * w, cout))
         finally:
             # the request is one-shot, thread-local state of the library, consumed by the call above; if Python raised before reaching
             # it (an arena allocation, a bad argument) it must not stay armed for an unrelated InstanceNorm backward (advisor, round 3)
@@ -1055,7 +1071,8 @@ class Discriminator(_ModelBase):
                                  cout, LRELU)
             else:
                 red = A.get(f"d/bwd/red{i}/{n}", (n * cout * 3,), torch.float64)
-                ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU)
+                ops.in_bwd(dcur, cout, None, 0, rec["a"], cout, rec["stats"], red, dz, cout, None, n, ho, ho, cout, LRELU,
+                           fused=_fused_scratch(A, self.adt, n, ho * ho, cout))
             gred = None
             if params:
                 ws = self.ws_provider(ops.conv2d_wgrad_workspace(n, ho, ho, cin, cout, 3))

@@ -361,12 +361,27 @@ def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
         lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()), "shm_in_apply"))
 
 
-def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope):
+def in_bwd_fused_doubles(batch, hw, c):
+    """SHM_IN_BWD_FUSED_DOUBLES: float64 elements of the one-pass form's scratch (per-block partial rows, means, counters and flags)."""
+    return (batch * (hw * c // 16384) * 3 * c + 1) // 2 + batch * c + batch * 288 + 1
+
+
+def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, fused=None):
+    """fused: float64 scratch of in_bwd_fused_doubles(batch, h * w, c) elements (zero on entry, zero on return): the call may run the one-pass
+    bf16 form (shm_in_bwd_fused_scratch); the library falls back to reduce + apply on shapes that form does not take."""
     e = batch * h * w * c                          # reduce pass: g1 [+ g2 / 4], a; apply pass: the same + dz
     nb = 2 * (_tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e)) + _tb(dz, e)
-    _timed_bytes("shm_in_bwd", nb, lambda: check(
-        lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
-                         batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd"))
+
+    def run():
+        if fused is not None:
+            check(lib().shm_in_bwd_fused_scratch(_p(fused), fused.numel()), "shm_in_bwd_fused_scratch")
+        try:
+            check(lib().shm_in_bwd(_p(g1), ldg1, _p(g2), ldg2, _p(a), lda, _p(stats), _p(red), _p(dz), lddz, _p(dbias),
+                                   batch, h, w, c, slope, _dtg(a, g1), _stream()), "shm_in_bwd")
+        finally:
+            if fused is not None:               # one-shot state of the library: never left armed behind an error
+                lib().shm_in_bwd_fused_scratch(None, 0)
+    _timed_bytes("shm_in_bwd", nb, run)
 
 
 def in_bwd_apply(g1, ldg1, g2, ldg2, a, lda, stats, beta, red, redp, dstage, dz, lddz, dbias, batch, h, w, c, slope):

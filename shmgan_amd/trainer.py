@@ -756,6 +756,9 @@ class ShmGANwithSSpecSeg:
         if self._loss_cache is not None:
             return self._loss_cache
         L = self._last
+        tripped = self.arena.fused_timeouts()
+        if tripped:
+            raise RuntimeError(f"in_bwd_fused8_kernel: sample barrier timed out ({tripped}); set SHM_ELEM_FUSED_BWD=0 and report")
         d = (L.dl.cpu().numpy() / L.B).tolist()
         i = (L.il.cpu().numpy() / L.B).tolist()
         D1_RF, D3_RF = d[0], d[1]

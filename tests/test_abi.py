@@ -1,6 +1,7 @@
 """The C-ABI shared library loads on a CPU-only box and exports exactly what include/shmgan_hip.h
 declares; the ctypes signature table mirrors the header.  No compute call is made here."""
 import ctypes as C
+from pathlib import Path
 import re
 
 import pytest
@@ -109,6 +110,30 @@ def test_generator_gradient_buckets_partition_the_flat_buffer():
         if F == 64:
             mb = [sum(hi - lo for lo, hi in sl) * 4 / 1e6 for _, sl in plan]
             assert abs(sum(mb) - 74.1) < 0.1 and mb[1] > 45
+
+
+def test_fused_in_bwd_scratch_size_and_timeout_report():
+    """Host side of the one-pass bf16 InstanceNorm backward (include/shmgan_hip.h: SHM_IN_BWD_FUSED_DOUBLES): ops.in_bwd_fused_doubles is the
+    header's macro, the scratch exists only for bfloat16 activations, and a set timeout word is reported by name (Trainer.losses raises on it)."""
+    import re
+    import torch
+    from shmgan_amd import ops
+    from shmgan_amd.model import Arena, _fused_scratch
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "shmgan_hip.h").read_text()
+    m = re.search(r"#define SHM_IN_BWD_FUSED_DOUBLES\(batch, hw, c\) \\\n\s*(.*)", hdr)
+    assert m, "macro not found"
+    expr = re.sub(r"\(size_t\)", "", m.group(1)).replace("/", "//")
+    for batch, hw, c in ((40, 65536, 64), (8, 16384, 128), (3, 1024, 512), (1, 4096, 8)):
+        assert ops.in_bwd_fused_doubles(batch, hw, c) == eval(expr, {"batch": batch, "hw": hw, "c": c}), (batch, hw, c)
+    A = Arena(torch.device("cpu"))
+    assert _fused_scratch(A, torch.float32, 2, 4096, 64) is None
+    t = _fused_scratch(A, torch.bfloat16, 2, 4096, 64)
+    assert t.dtype == torch.float64 and t.numel() == ops.in_bwd_fused_doubles(2, 4096, 64) and float(t.abs().max()) == 0.0
+    assert _fused_scratch(A, torch.bfloat16, 2, 4096, 64) is t
+    u = _fused_scratch(A, torch.bfloat16, 4, 1024, 128)
+    assert A.fused_timeouts() == []
+    u[-1] = 4.9e-324          # the timeout word is a uint32 in the last float64: any set bit
+    assert A.fused_timeouts() == ["bwd/fused/4x1024x128"]
 
 
 def test_every_pipeline_barrier_waits_for_its_lds_reads():
