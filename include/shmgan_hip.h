@@ -251,7 +251,7 @@ int shm_in_bwd_keep_dz_sums(double* dst);
  * thread may use `scratch` = f64 [n_doubles], n_doubles >= SHM_IN_BWD_FUSED_DOUBLES(batch, h * w, c), zero on entry and zero again on return
  * (outside the per-block partial rows at its front, which every launch rewrites in full and which may hold anything).
  * One-shot (NULL disarms).  Taken for dtype SHM_BF16, c % 8 == 0, c <= 512, 256 % (c / 8) == 0, h * w a multiple of the 16384 / c pixel
- * slice and at most 256 slices per sample, tuning "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics:
+ * slice and at most 256 slices per sample (128 with a pooled gradient g2), tuning "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics:
  * the sums are added in block order (bitwise reproducible). */
 #define SHM_IN_BWD_FUSED_DOUBLES(batch, hw, c) \
     (((size_t)(batch) * ((size_t)(hw) * (size_t)(c) / 16384) * 3 * (size_t)(c) + 1) / 2 + (size_t)(batch) * (size_t)(c) + (size_t)(batch) * 288 + 1)

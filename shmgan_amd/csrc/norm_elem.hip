@@ -867,11 +867,11 @@ template <typename V>
 __device__ __forceinline__ void coh_store(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool G2>
-__global__ __launch_bounds__(256, G2 ? 2 : 3) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
+__global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
                                                                          unsigned* __restrict__ fsync, unsigned* __restrict__ ferr) {
     constexpr int U = 8;
     __shared__ double red[256 * 8];
-    __shared__ float sm12[1024];
+    __shared__ float sm12[1024], smi[1024];
     __shared__ int s_last;
     const int lanes_c = k.c >> 3, PP = 256 / lanes_c;                  // the launcher guarantees 256 % lanes_c == 0: every thread is active
     const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
@@ -907,6 +907,13 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void in_bwd_fused8_kernel(const In
     for (int e = 0; e < 8; ++e) {
         mean[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2];
         inv[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2 + 1];
+    }
+    if (pp == 0) {                    // phase 2 takes them from LDS again: sixteen registers less across the barrier
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            smi[(cl * 8 + e) * 2] = mean[e];
+            smi[(cl * 8 + e) * 2 + 1] = inv[e];
+        }
     }
     auto gval = [&](int u) {
         f32x8 g = unpack8(gq[u]);
@@ -1042,11 +1049,14 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void in_bwd_fused8_kernel(const In
     }
     int pb2 = pbase;                  // (opaque as well: the store addresses are formed here, not carried from the loads at the top)
     asm volatile("" : "+v"(pb2));
-    float m1[8], m2[8], sd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // d = inv * (g - m1 - xhat * m2) with xhat = (x - mean) * inv, as three constants per channel: d = A g - (B x + C)
+    float cA[8], cB[8], cC[8], sd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        m1[e] = sm12[(cl * 8 + e) * 2];
-        m2[e] = sm12[(cl * 8 + e) * 2 + 1];
+        const float m1 = sm12[(cl * 8 + e) * 2], m2 = sm12[(cl * 8 + e) * 2 + 1], mu = smi[(cl * 8 + e) * 2], iv = smi[(cl * 8 + e) * 2 + 1];
+        cA[e] = iv;
+        cB[e] = iv * iv * m2;
+        cC[e] = iv * m1 - cB[e] * mu;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1055,8 +1065,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 3) void in_bwd_fused8_kernel(const In
         bf16x8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float xh = (x[e] - mean[e]) * inv[e];
-            const float da = inv[e] * (g[e] - m1[e] - xh * m2[e]);
+            const float da = cA[e] * g[e] - (cB[e] * x[e] + cC[e]);
             const float d = x[e] > 0.f ? da : da * k.slope;
             sd[e] += d;
             o[e] = (bf16_t)d;
@@ -1243,11 +1252,13 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
                        (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
     // The one-pass form (in_bwd_fused8_kernel, "elem.fused_bwd"): bf16 tensors, whole slices of 8 x (2048 / c) pixels, at most 256 blocks per sample
+    // (128 with a pooled gradient: that form holds three slices, 204 registers, two blocks per CU -- with 256-block samples only two samples
+    // are resident and it loses to the two passes, 498 against 453 us at n = 40, 256 x 256 x 64)
     {
         const int lanes8 = c / 8, pp8 = lanes8 > 0 && 256 % lanes8 == 0 ? 256 / lanes8 : 0;
         const int slice = 8 * pp8;
         if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && c % 8 == 0 && c <= 512 && pp8 > 0 && ldg1 % 8 == 0 && lda % 8 == 0 &&
-            lddz % 8 == 0 && (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= 256 && batch <= 65535 &&
+            lddz % 8 == 0 && (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= (g2 ? 128 : 256) && batch <= 65535 &&
             fscr_n >= fused_scratch_doubles(batch, hw, c)) {
             float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));
             unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);

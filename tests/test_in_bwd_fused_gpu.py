@@ -78,7 +78,7 @@ def _reference(a, g, g2, stats, n, h, c, slope=0.2):
 
 # (n, h, c, pooled): 64 channels -> slices of 256 pixels (16 / 64 / 256 blocks per sample), 128 -> 128 pixels, 256 -> 64, 512 -> 32; 8 / 16 / 32
 # channels -> 2048 / 1024 / 512-pixel slices
-SHAPES = [(3, 64, 64, False), (2, 128, 64, True), (2, 256, 64, False), (5, 64, 128, True), (3, 32, 256, False), (2, 16, 512, True),
+SHAPES = [(3, 64, 64, False), (2, 128, 64, True), (2, 256, 64, False), (2, 128, 128, True), (5, 64, 128, True), (3, 32, 256, False), (2, 16, 512, True),
           (2, 64, 32, False), (1, 64, 8, True), (41, 16, 64, False)]
 
 
@@ -125,16 +125,18 @@ def test_fused_without_bias_gradient():
 
 @pytest.mark.parametrize("n,h,c,why", [(2, 24, 64, "ragged: 576 pixels are not whole 256-pixel slices"),
                                        (1, 512, 64, "1024 slices per sample: more than a resident sample group"),
+                                       (1, 256, 64, "pooled form: 256 slices per sample, two blocks per CU"),
                                        (2, 8, 64, "a 64-pixel map is smaller than one slice"),
                                        (2, 32, 24, "3 channel lanes do not divide a block")])
 def test_shapes_outside_the_form_run_two_passes(n, h, c, why):
     ops = _ops()
     rng = np.random.default_rng(11)
-    a, g, g2, stats = _operands(rng, n, h, c, False)
+    pool = why.startswith("pooled")
+    a, g, g2, stats = _operands(rng, n, h, c, pool)
     scratch = torch.zeros(ops.in_bwd_fused_doubles(n, h * h, c), dtype=torch.float64, device="cuda")
-    z1, b1, k1 = _run(a, g, None, stats, n, h, c, scratch)
+    z1, b1, k1 = _run(a, g, g2, stats, n, h, c, scratch)
     assert "fused" not in k1, (k1, why)
-    zr, br = _reference(a, g, None, stats, n, h, c)
+    zr, br = _reference(a, g, g2, stats, n, h, c)
     assert float((z1.double() - zr).norm() / zr.norm()) < 4e-3
     assert float(scratch.abs().max()) == 0.0
 

@@ -34,5 +34,5 @@ for n, h, c in shapes:
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 20 * 1e3)
     mb = a.numel() * 2 / 1e6
-    print(f"n={n:3d} h={h:3d} c={c:3d} tensor {mb:7.1f} MB  two-pass {out[0]:7.1f} us ({5 * mb / out[0] / 1e3:5.2f} TB/s of 5 passes)  "
-          f"one pass {out[1]:7.1f} us ({3 * mb / out[1] / 1e3:5.2f} TB/s of 3 passes)  timeout word {float(scratch[-1])}", flush=True)
+    print(f"n={n:3d} h={h:3d} c={c:3d} tensor {mb:7.1f} MB  two-pass {out[0]:7.1f} us ({5 * mb / out[0]:5.2f} TB/s of 5 passes)  "
+          f"one pass {out[1]:7.1f} us ({3 * mb / out[1]:5.2f} TB/s of 3 passes)  timeout word {float(scratch[-1])}", flush=True)
