@@ -250,11 +250,14 @@ int shm_in_bwd_keep_dz_sums(double* dst);
  * the apply phase, the blocks of a sample meet at a per-sample barrier; 3 tensor passes over HBM instead of 5).  The NEXT shm_in_bwd call of this
  * thread may use `scratch` = f64 [n_doubles], n_doubles >= SHM_IN_BWD_FUSED_DOUBLES(batch, h * w, c), zero on entry and zero again on return
  * (outside the per-block partial rows at its front, which every launch rewrites in full and which may hold anything).
- * One-shot (NULL disarms).  Taken for dtype SHM_BF16, c % 8 == 0, c <= 512, 256 % (c / 8) == 0, h * w a multiple of the 16384 / c pixel
- * slice and at most 256 slices per sample (128 with a pooled gradient g2), tuning "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics:
- * the sums are added in block order (bitwise reproducible). */
-#define SHM_IN_BWD_FUSED_DOUBLES(batch, hw, c) \
-    (((size_t)(batch) * ((size_t)(hw) * (size_t)(c) / 16384) * 3 * (size_t)(c) + 1) / 2 + (size_t)(batch) * (size_t)(c) + (size_t)(batch) * 288 + 1)
+ * One-shot (NULL disarms).  Taken for dtype SHM_BF16, c in {8, 16, 32} or a multiple of 64 up to 1024, h * w a multiple of the
+ * 16384 / min(c, 64) pixel slice and at most 256 slices per map (128 with a pooled gradient g2; "elem.fused_max_slices"), tuning
+ * "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics: the sums are added in block order (bitwise
+ * reproducible). */
+#define SHM_IN_BWD_FUSED_CB(c) ((c) < 64 ? (c) : 64)
+#define SHM_IN_BWD_FUSED_DOUBLES(batch, hw, c)                                                                                      \
+    (((size_t)(batch) * ((size_t)(hw) * SHM_IN_BWD_FUSED_CB(c) / 16384) * 3 * (size_t)(c) + 1) / 2 + (size_t)(batch) * (size_t)(c) + \
+     (size_t)(batch) * ((size_t)(c) / SHM_IN_BWD_FUSED_CB(c)) * 288 + 1)
 int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles);
 /* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers
  * normalise a on the fly, only the pool's consumer needs a tensor.  Same bits as shm_in_apply_pool's `pooled`. */

@@ -60,6 +60,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"wgrad.f32_split", "SHM_WGRAD_F32_SPLIT", 0, 0, 1},
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
     {"elem.fused_bwd", "SHM_ELEM_FUSED_BWD", 1, 0, 1},
+    {"elem.fused_max_slices", "SHM_ELEM_FUSED_MAX_SLICES", 256, 1, 512},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -844,12 +845,13 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const InBwdArgs k) {
 // block), phase 2 stores 1.2, departure 2.3: 23 us per block with 768 resident.  Starting the samples of the first resident generation a fraction
 // of a period apart changed nothing (the launch is bound by that latency chain times the residency, not by a memory phase all blocks share).
 constexpr int SHM_FUSED_FLAGS = 16, SHM_FUSED_SYNC_WORDS = 32 * (SHM_FUSED_FLAGS + 2);
-// scratch (float64 units): partials f32 [batch][bpi][3 c] (sum g, sum g * xhat interleaved, then sum dz) | means f32 [batch][c][2] | sync u32
-// [batch][SYNC_WORDS] | timeout word.  bpi = blocks per sample = h * w * c / 16384.
-static size_t fused_row_doubles(int batch, size_t bpi, int c) { return ((size_t)batch * bpi * 3 * c + 1) / 2; }        // fp32 rows
+// scratch (float64 units): partials f32 [batch][c / CB][bpi][3 CB] (sum g, sum g * xhat interleaved, then sum dz) | means f32 [batch][c][2] | sync u32
+// [batch][c / CB][SYNC_WORDS] | timeout word.  CB = min(c, 64) channels per barrier group, bpi = blocks per group = h * w * CB / 16384.
+static size_t fused_row_doubles(int batch, size_t bpi, int c) { return ((size_t)batch * bpi * 3 * c + 1) / 2; }        // fp32 rows: [batch][c / CB][bpi][3 CB]
 static size_t fused_scratch_doubles(int batch, int hw, int c) {
-    const size_t bpi = (size_t)hw * c / 16384;
-    return fused_row_doubles(batch, bpi, c) + (size_t)batch * c + (size_t)batch * (SHM_FUSED_SYNC_WORDS / 2) + 1;
+    const int cb = c < 64 ? c : 64;
+    const size_t bpi = (size_t)hw * cb / 16384;
+    return fused_row_doubles(batch, bpi, c) + (size_t)batch * c + (size_t)batch * (c / cb) * (SHM_FUSED_SYNC_WORDS / 2) + 1;
 }
 __device__ __forceinline__ f32x8 unpack8(const shm_u32x4 u) {
     f32x8 r;
@@ -871,18 +873,23 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
                                                                          unsigned* __restrict__ fsync, unsigned* __restrict__ ferr) {
     constexpr int U = 8;
     __shared__ double red[256 * 8];
-    __shared__ float sm12[1024], smi[1024];
+    __shared__ float sm12[128], smi[128];
     __shared__ int s_last;
-    const int lanes_c = k.c >> 3, PP = 256 / lanes_c;                  // the launcher guarantees 256 % lanes_c == 0: every thread is active
+    // A barrier GROUP is (sample, block of CB = min(c, 64) channels): its blocks are the 16384 / CB-pixel slices of the map, blockIdx.x.  (With the
+    // whole channel range in one group the 256- and 512-channel levels had short slices, rows of 3 c values and a last arriver adding
+    // bpi * c / 256 values per thread: slower than the two passes at n = 20.)  A pixel's CB channels are one 128-byte line (c >= 64).
+    const int CB = k.c < 64 ? k.c : 64, c0 = blockIdx.y * CB;
+    const int lanes_c = CB >> 3, PP = 256 / lanes_c;                   // CB is a power of two (launcher): every thread is active
     const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
-    const int n = k.rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, hw = k.h * k.w;
+    const int n = k.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, hw = k.h * k.w;
+    const int gidx = n * gridDim.y + blockIdx.y;                       // the group
     const int pbase = blockIdx.x * (U * PP) + pp;                      // pixel of slot u: pbase + u * PP (hw % (U * PP) == 0)
-    const int bpi = gridDim.x, c3 = 3 * k.c;
-    float* const prow0 = fpart + (size_t)n * bpi * c3;                 // the sample's rows; row b = [c][2] sums, then [c] bias-gradient partials
+    const int bpi = gridDim.x, c3 = 3 * CB;
+    float* const prow0 = fpart + (size_t)gidx * bpi * c3;              // the group's rows; row b = [CB][2] sums, then [CB] bias-gradient partials
     float* const prow = prow0 + (size_t)blockIdx.x * c3;               // (fp32: a row holds sums over one slice, and the means are fp32 in the end)
 
 #ifdef SHM_FUSED_STAMP
-    unsigned long long* const stamp = (unsigned long long*)(ferr + 2) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* const stamp = (unsigned long long*)(ferr + 2) + ((size_t)gidx * gridDim.x + blockIdx.x) * 8;
 #define FSTAMP(i) do { if (threadIdx.x == 0) stamp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
@@ -894,19 +901,19 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     for (int u = 0; u < U; ++u) {
         const int p = pbase + u * PP;
         const size_t off = (size_t)n * hw + p;
-        gq[u] = *(const shm_u32x4*)((const bf16_t*)k.g1 + off * k.ldg1 + cl * 8);
-        aq[u] = *(const shm_u32x4*)((const bf16_t*)k.a + off * k.lda + cl * 8);
+        gq[u] = *(const shm_u32x4*)((const bf16_t*)k.g1 + off * k.ldg1 + c0 + cl * 8);
+        aq[u] = *(const shm_u32x4*)((const bf16_t*)k.a + off * k.lda + c0 + cl * 8);
         if constexpr (G2) {
             const int y = p / k.w, x = p - y * k.w;
             const size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
-            hq[u] = *(const shm_u32x4*)((const bf16_t*)k.g2 + q * k.ldg2 + cl * 8);
+            hq[u] = *(const shm_u32x4*)((const bf16_t*)k.g2 + q * k.ldg2 + c0 + cl * 8);
         }
     }
     float mean[8], inv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        mean[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2];
-        inv[e] = (float)k.stats[((size_t)n * k.c + cl * 8 + e) * 2 + 1];
+        mean[e] = (float)k.stats[((size_t)n * k.c + c0 + cl * 8 + e) * 2];
+        inv[e] = (float)k.stats[((size_t)n * k.c + c0 + cl * 8 + e) * 2 + 1];
     }
     if (pp == 0) {                    // phase 2 takes them from LDS again: sixteen registers less across the barrier
 #pragma unroll
@@ -934,10 +941,10 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     };
     auto finish = [&](int nv, float* dst, int stride) {
         __syncthreads();
-        for (int t = threadIdx.x; t < k.c * nv; t += 256) {
-            const int j = t / k.c, ch = t - j * k.c;
+        for (int t = threadIdx.x; t < CB * nv; t += 256) {
+            const int j = t / CB, ch = t - j * CB;
             float sum = 0.f;
-            for (int q = 0; q < PP; ++q) sum += redf[j * 2048 + q * k.c + ch];
+            for (int q = 0; q < PP; ++q) sum += redf[j * 2048 + q * CB + ch];
             coh_store(&dst[ch * stride + j], sum);
         }
     };
@@ -1006,8 +1013,8 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     // waits for the acknowledgement of its stores (vmcnt) and then counts its arrival.  And no crowd on one address: 256 blocks polling the arrival
     // counter queue their reads in front of the arrivals themselves (measured: 41 us per sample).  The LAST ARRIVER (it alone knows every row is
     // in) publishes the means and raises SHM_FUSED_FLAGS copies of the release flag, each in its own 128-byte line; block b polls copy b % 16.
-    unsigned* const sy = fsync + (size_t)n * SHM_FUSED_SYNC_WORDS;        // [0] arrivals, [32] departures, [64 + 32 j] flag copy j
-    float* const res = fres + (size_t)n * k.c * 2;
+    unsigned* const sy = fsync + (size_t)gidx * SHM_FUSED_SYNC_WORDS;     // [0] arrivals, [32] departures, [64 + 32 j] flag copy j
+    float* const res = fres + ((size_t)n * k.c + c0) * 2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FSTAMP(2);
@@ -1015,9 +1022,9 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     __syncthreads();
     FSTAMP(3);
     if (s_last) {
-        const int RG = rowsum(prow0, k.c);
-        for (int v = threadIdx.x; v < 2 * k.c; v += 256) {
-            const float r = (float)(total(v, k.c, RG) / hw);
+        const int RG = rowsum(prow0, CB);
+        for (int v = threadIdx.x; v < 2 * CB; v += 256) {
+            const float r = (float)(total(v, CB, RG) / hw);
             sm12[v] = r;
             coh_store(res + v, r);
         }
@@ -1037,7 +1044,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < k.c * 2; i += 256) sm12[i] = coh_load(res + i);
+        for (int i = threadIdx.x; i < CB * 2; i += 256) sm12[i] = coh_load(res + i);
     }
     __syncthreads();
     FSTAMP(4);
@@ -1070,13 +1077,13 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
             sd[e] += d;
             o[e] = (bf16_t)d;
         }
-        *(bf16x8_t*)((bf16_t*)k.dz + ((size_t)n * hw + pb2 + u * PP) * k.lddz + cl * 8) = o;
+        *(bf16x8_t*)((bf16_t*)k.dz + ((size_t)n * hw + pb2 + u * PP) * k.lddz + c0 + cl * 8) = o;
     }
     FSTAMP(5);
     if (k.dbias) {
         __syncthreads();
         park(sd, 0);
-        finish(1, prow + 2 * k.c, 1);
+        finish(1, prow + 2 * CB, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's row is written before its departure is counted
     }
     __syncthreads();
@@ -1085,10 +1092,10 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     FSTAMP(6);
     if (s_last) {                     // every block of the sample is through: the bias-gradient staging of the sample, then a clean scratch
         if (k.dbias) {
-            const int RG = rowsum(prow0 + 2 * k.c, k.c / 2);
-            for (int ch = threadIdx.x; ch < k.c; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + ch] = total(ch, k.c / 2, RG);
+            const int RG = rowsum(prow0 + 2 * CB, CB / 2);
+            for (int ch = threadIdx.x; ch < CB; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch] = total(ch, CB / 2, RG);
         }
-        for (int i = threadIdx.x; i < k.c * 2; i += 256) coh_store(res + i, 0.f);
+        for (int i = threadIdx.x; i < CB * 2; i += 256) coh_store(res + i, 0.f);
         if (threadIdx.x < SHM_FUSED_FLAGS + 2) coh_store(sy + 32 * threadIdx.x, 0u);
     }
 #ifdef SHM_FUSED_STAMP
@@ -1251,19 +1258,22 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     // bf16 activations: the reduce pass with eight channels (16 bytes) per thread
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
                        (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
-    // The one-pass form (in_bwd_fused8_kernel, "elem.fused_bwd"): bf16 tensors, whole slices of 8 x (2048 / c) pixels, at most 256 blocks per sample
-    // (128 with a pooled gradient: that form holds three slices, 204 registers, two blocks per CU -- with 256-block samples only two samples
-    // are resident and it loses to the two passes, 498 against 453 us at n = 40, 256 x 256 x 64)
+    // The one-pass form (in_bwd_fused8_kernel, "elem.fused_bwd"): bf16 tensors, barrier groups of (sample, CB = min(c, 64) channels), whole slices of
+    // 16384 / CB pixels, at most "elem.fused_max_slices" (256) blocks per group -- 128 with a pooled gradient: that form holds three slices,
+    // 204 registers, two blocks per CU; with 256-block groups only two are resident and it loses to the two passes (498 against 453 us at n = 40,
+    // 256 x 256 x 64)
     {
-        const int lanes8 = c / 8, pp8 = lanes8 > 0 && 256 % lanes8 == 0 ? 256 / lanes8 : 0;
-        const int slice = 8 * pp8;
-        if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && c % 8 == 0 && c <= 512 && pp8 > 0 && ldg1 % 8 == 0 && lda % 8 == 0 &&
-            lddz % 8 == 0 && (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= (g2 ? 128 : 256) && batch <= 65535 &&
+        const int cb = c < 64 ? c : 64;
+        const bool cb_ok = c >= 8 && (c < 64 ? (c & (c - 1)) == 0 : c % 64 == 0);
+        const int slice = cb_ok ? 16384 / cb : 1;
+        if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && cb_ok && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && lddz % 8 == 0 &&
+            (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= (g2 ? 128 : shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES)) && batch <= 65535 &&
             fscr_n >= fused_scratch_doubles(batch, hw, c)) {
+            const int ncb = c / cb;
             float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));
             unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);
-            unsigned* const ferr = fsync + (size_t)batch * SHM_FUSED_SYNC_WORDS;
-            const dim3 gridf(hw / slice, batch);
+            unsigned* const ferr = fsync + (size_t)batch * ncb * SHM_FUSED_SYNC_WORDS;
+            const dim3 gridf(hw / slice, ncb, batch);
             if (g2) hipLaunchKernelGGL((in_bwd_fused8_kernel<true>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
             else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
             shm_set_last_kernel(g2 ? "in_bwd_fused8_kernel<true>" : "in_bwd_fused8_kernel<false>");

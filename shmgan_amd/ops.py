@@ -363,7 +363,8 @@ def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
 
 def in_bwd_fused_doubles(batch, hw, c):
     """SHM_IN_BWD_FUSED_DOUBLES: float64 elements of the one-pass form's scratch (per-block partial rows, means, counters and flags)."""
-    return (batch * (hw * c // 16384) * 3 * c + 1) // 2 + batch * c + batch * 288 + 1
+    cb = min(c, 64)
+    return (batch * (hw * cb // 16384) * 3 * c + 1) // 2 + batch * c + batch * (c // cb) * 288 + 1
 
 
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, fused=None):

@@ -120,9 +120,9 @@ def test_fused_in_bwd_scratch_size_and_timeout_report():
     from shmgan_amd import ops
     from shmgan_amd.model import Arena, _fused_scratch
     hdr = (Path(__file__).resolve().parent.parent / "include" / "shmgan_hip.h").read_text()
-    m = re.search(r"#define SHM_IN_BWD_FUSED_DOUBLES\(batch, hw, c\) \\\n\s*(.*)", hdr)
+    m = re.search(r"#define SHM_IN_BWD_FUSED_DOUBLES\(batch, hw, c\)\s*\\\n((?:.*\\\n)*.*)", hdr)
     assert m, "macro not found"
-    expr = re.sub(r"\(size_t\)", "", m.group(1)).replace("/", "//")
+    expr = re.sub(r"\(size_t\)", "", m.group(1)).replace("\\\n", " ").replace("/", "//").replace("SHM_IN_BWD_FUSED_CB(c)", "min(c, 64)")
     for batch, hw, c in ((40, 65536, 64), (8, 16384, 128), (3, 1024, 512), (1, 4096, 8)):
         assert ops.in_bwd_fused_doubles(batch, hw, c) == eval(expr, {"batch": batch, "hw": hw, "c": c}), (batch, hw, c)
     A = Arena(torch.device("cpu"))

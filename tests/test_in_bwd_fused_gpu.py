@@ -43,7 +43,7 @@ def _operands(rng, n, h, c, pool, gshift=0.0):
 
 def _clean(scratch, n, h, c):
     """Zero on return: everything behind the per-block partial rows (means, both counters and the flags of every sample, the timeout word)."""
-    rows = (n * (h * h * c // 16384) * 3 * c + 1) // 2
+    rows = (n * (h * h * min(c, 64) // 16384) * 3 * c + 1) // 2
     tail = scratch[rows:]
     return torch.equal(tail.view(torch.int64), torch.zeros_like(tail).view(torch.int64))
 
