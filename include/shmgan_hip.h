@@ -82,6 +82,7 @@ const char* shm_last_kernel(void);
  *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
  *                               3 at unit stride only, 4 both
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
+ *   "elem.fused_max_slices"     the one-pass form: most slices (= blocks that must be resident together) per barrier group, default 256, at most 512
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
  *                               producer just wrote is still in the Infinity Cache), 0 front to back
  *   "elem.reduce_blocks"        block target of the InstanceNorm-backward reduce pass, 0 automatic (1024 fp32 / 512 bf16: every block ends

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     float* const prow = prow0 + (size_t)blockIdx.x * c3;               // (fp32: a row holds sums over one slice, and the means are fp32 in the end)
 
 #ifdef SHM_FUSED_STAMP
-    unsigned long long* const stamp = (unsigned long long*)(ferr + 2) + ((size_t)gidx * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* const stamp = (unsigned long long*)(ferr + 2) + ((size_t)gidx * gridDim.x + blockIdx.x) * 12;
 #define FSTAMP(i) do { if (threadIdx.x == 0) stamp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
@@ -1022,7 +1022,9 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     __syncthreads();
     FSTAMP(3);
     if (s_last) {
+        FSTAMP(8);
         const int RG = rowsum(prow0, CB);
+        FSTAMP(9);
         for (int v = threadIdx.x; v < 2 * CB; v += 256) {
             const float r = (float)(total(v, CB, RG) / hw);
             sm12[v] = r;
@@ -1030,6 +1032,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the means are written before a flag goes up
         __syncthreads();
+        FSTAMP(10);
         if (threadIdx.x < SHM_FUSED_FLAGS) coh_store(sy + 64 + 32 * threadIdx.x, 1u);
     } else {
         if (threadIdx.x == 0) {

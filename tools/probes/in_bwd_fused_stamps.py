@@ -37,19 +37,36 @@ ops.in_stats(a, c, stats, n, h * h, c, 1e-6)
 dz = torch.empty_like(a)
 db = torch.zeros(c, dtype=torch.float64, device="cuda")
 red = torch.zeros(n * c * 3, dtype=torch.float64, device="cuda")
-bpi = h * h * c // 16384
+cb = min(c, 64)
+bpi = h * h * cb // 16384
+ng = n * (c // cb)
 base = ops.in_bwd_fused_doubles(n, h * h, c)
-scratch = torch.zeros(base + n * bpi * 8 + 8, dtype=torch.float64, device="cuda")
+scratch = torch.zeros(base + ng * bpi * 12 + 8, dtype=torch.float64, device="cuda")
 for _ in range(4):
+    scratch[base:].zero_()
     ops.in_bwd(g, c, None, 0, a, c, stats, red, dz, c, db, n, h, h, c, 0.2, fused=scratch)
     assert "fused" in ops.last_kernel()
 torch.cuda.synchronize()
-st = scratch[base:base + n * bpi * 8].view(torch.int64).cpu().numpy().reshape(n, bpi, 8).astype(np.float64)
-st = (st - st[:, :, 0].min()) / 100.0            # 100 MHz -> us
+raw = scratch[base:base + ng * bpi * 12].view(torch.int64).cpu().numpy().reshape(ng, bpi, 12).astype(np.float64)
+t0 = raw[:, :, 0].min()
+st = (raw[:, :, :8] - t0) / 100.0            # 100 MHz -> us
 names = ["start", "loaded", "rows out", "arrived", "released", "stored", "departed", "end"]
-print(f"n={n} h={h} c={c}: {bpi} blocks per sample; us from the first start (min / median / max over a sample's blocks)")
-for s in list(range(min(n, 10))) + ([n - 1] if n > 10 else []):
-    print(f"sample {s:2d}: " + "  ".join(f"{nm} {np.min(st[s, :, i]):6.1f}/{np.median(st[s, :, i]):6.1f}/{np.max(st[s, :, i]):6.1f}" for i, nm in enumerate(names)))
+print(f"n={n} h={h} c={c}: {ng} barrier groups of {bpi} blocks; us from the first start (min / median / max over a group's blocks)")
+for s in list(range(min(ng, 6))) + ([ng - 1] if ng > 6 else []):
+    print(f"group {s:3d}: " + "  ".join(f"{nm} {np.min(st[s, :, i]):6.1f}/{np.median(st[s, :, i]):6.1f}/{np.max(st[s, :, i]):6.1f}" for i, nm in enumerate(names)))
 d = np.diff(st, axis=2)
 print("median phase lengths (us): " + "  ".join(f"{names[i]}->{names[i + 1]} {np.median(d[:, :, i]):.1f}" for i in range(7)))
+# the last arriver's chain: its arrival -> row sums start -> row sums done -> means acknowledged; the others' release after that
+la = raw[:, :, 8] > 0
+chain = []
+for gi in range(ng):
+    b = np.nonzero(la[gi])[0]
+    if len(b) != 1:
+        continue
+    r = raw[gi, b[0]]
+    rel = np.median(raw[gi, ~la[gi], 4]) if bpi > 1 else r[10]
+    chain.append([(r[2] - np.median(raw[gi, :, 2])) / 100, (r[8] - r[2]) / 100, (r[9] - r[8]) / 100, (r[10] - r[9]) / 100, (rel - r[10]) / 100])
+chain = np.array(chain)
+print("last arriver (median us): behind the median block's rows " + "  ".join(f"{nm} {v:.1f}" for nm, v in zip(
+    ["", "-> arrival counted + barrier", "-> row sums", "-> means acknowledged", "-> the others released"], np.median(chain, axis=0))))
 print(f"whole launch {st[:, :, 7].max():.1f} us")
