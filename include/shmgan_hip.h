@@ -252,7 +252,8 @@ int shm_in_bwd_keep_dz_sums(double* dst);
  * thread may use `scratch` = f64 [n_doubles], n_doubles >= SHM_IN_BWD_FUSED_DOUBLES(batch, h * w, c), zero on entry and zero again on return
  * (outside the per-block partial rows at its front, which every launch rewrites in full and which may hold anything).
  * One-shot (NULL disarms).  Taken for dtype SHM_BF16, c in {8, 16, 32} or a multiple of 64 up to 1024, h * w a multiple of the
- * 16384 / min(c, 64) pixel slice and at most 256 slices per map (128 with a pooled gradient g2; "elem.fused_max_slices"), tuning
+ * 16384 / min(c, 64) pixel slice and at most 256 slices per map ("elem.fused_max_slices"; with a pooled gradient g2: c a multiple of 64 and
+ * whole tiles of (256 / Wt) rows x Wt = min(w, 128) columns), tuning
  * "elem.fused_bwd" = 1 (default); every other call runs the two passes.  No float atomics: the sums are added in block order (bitwise
  * reproducible). */
 #define SHM_IN_BWD_FUSED_CB(c) ((c) < 64 ? (c) : 64)

@@ -869,7 +869,7 @@ template <typename V>
 __device__ __forceinline__ void coh_store(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool G2>
-__global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
+__global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
                                                                          unsigned* __restrict__ fsync, unsigned* __restrict__ ferr) {
     constexpr int U = 8;
     __shared__ double red[256 * 8];
@@ -895,18 +895,37 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
 #define FSTAMP(i) do { } while (0)
 #endif
     FSTAMP(0);
+    // Pixel of slot u.  Plain form: pbase + u * PP (a slice is 256 consecutive pixels).  Pooled form (CB = 64, PP = 32): a slice is a tile of
+    // R rows x Wt = min(w, 128) columns, R * Wt = 256, and a thread owns two 2 x 2 QUADS of it (quad pp and pp + 32 of the tile's 64): one pooled
+    // gradient value serves four pixels, two loads instead of eight -- with eight the form needs 204 registers and two blocks per CU.
+    int qbase = 0, wt2 = 1;                                              // pooled form: pixel index of the tile's origin, quads per tile row
+    if constexpr (G2) {
+        const int wt = k.w < 128 ? k.w : 128, tpr = k.w / wt, ty = blockIdx.x / tpr, tx = blockIdx.x - ty * tpr;
+        wt2 = wt >> 1;
+        qbase = ty * (256 / wt) * k.w + tx * wt;
+    }
+    auto pix = [&](int u, int base) {
+        if constexpr (G2) {
+            const int q = pp + 32 * (u >> 2), qy = q / wt2, qx = q - qy * wt2;
+            return base + (2 * qy + ((u >> 1) & 1)) * k.w + 2 * qx + (u & 1);
+        } else {
+            return base + u * PP;
+        }
+    };
     shm_u32x4 gq[U], aq[U];
-    [[maybe_unused]] shm_u32x4 hq[U];
+    [[maybe_unused]] shm_u32x4 hq[2];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int p = pbase + u * PP;
+        const int p = pix(u, G2 ? qbase : pbase);
         const size_t off = (size_t)n * hw + p;
         gq[u] = *(const shm_u32x4*)((const bf16_t*)k.g1 + off * k.ldg1 + c0 + cl * 8);
         aq[u] = *(const shm_u32x4*)((const bf16_t*)k.a + off * k.lda + c0 + cl * 8);
         if constexpr (G2) {
-            const int y = p / k.w, x = p - y * k.w;
-            const size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
-            hq[u] = *(const shm_u32x4*)((const bf16_t*)k.g2 + q * k.ldg2 + c0 + cl * 8);
+            if ((u & 3) == 0) {
+                const int y = p / k.w, x = p - y * k.w;
+                const size_t q = ((size_t)n * (k.h >> 1) + (y >> 1)) * (k.w >> 1) + (x >> 1);
+                hq[u >> 2] = *(const shm_u32x4*)((const bf16_t*)k.g2 + q * k.ldg2 + c0 + cl * 8);
+            }
         }
     }
     float mean[8], inv[8];
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
     auto gval = [&](int u) {
         f32x8 g = unpack8(gq[u]);
         if constexpr (G2) {
-            const f32x8 h = unpack8(hq[u]);
+            const f32x8 h = unpack8(hq[u >> 2]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] += 0.25f * h[e];
         }
@@ -1055,9 +1074,10 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         asm volatile("" : "+v"(gq[u]), "+v"(aq[u]));
-        if constexpr (G2) asm volatile("" : "+v"(hq[u]));
+        if constexpr (G2)
+            if ((u & 3) == 0) asm volatile("" : "+v"(hq[u >> 2]));
     }
-    int pb2 = pbase;                  // (opaque as well: the store addresses are formed here, not carried from the loads at the top)
+    int pb2 = G2 ? qbase : pbase;     // (opaque as well: the store addresses are formed here, not carried from the loads at the top)
     asm volatile("" : "+v"(pb2));
     // d = inv * (g - m1 - xhat * m2) with xhat = (x - mean) * inv, as three constants per channel: d = A g - (B x + C)
     float cA[8], cB[8], cC[8], sd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1080,7 +1100,7 @@ __global__ __launch_bounds__(256, G2 ? 2 : 4) void in_bwd_fused8_kernel(const In
             sd[e] += d;
             o[e] = (bf16_t)d;
         }
-        *(bf16x8_t*)((bf16_t*)k.dz + ((size_t)n * hw + pb2 + u * PP) * k.lddz + c0 + cl * 8) = o;
+        *(bf16x8_t*)((bf16_t*)k.dz + ((size_t)n * hw + pix(u, pb2)) * k.lddz + c0 + cl * 8) = o;
     }
     FSTAMP(5);
     if (k.dbias) {
@@ -1262,15 +1282,16 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
     const bool wide8 = (dtype == SHM_BF16 || dtype == SHM_BF16_GF32) && c % 8 == 0 && c >= 8 && c <= 1024 && (r1 || ldg1 % 8 == 0) && lda % 8 == 0 &&
                        (!g2 || ldg2 % 8 == 0) && 256 / (c / 8) >= 1;
     // The one-pass form (in_bwd_fused8_kernel, "elem.fused_bwd"): bf16 tensors, barrier groups of (sample, CB = min(c, 64) channels), whole slices of
-    // 16384 / CB pixels, at most "elem.fused_max_slices" (256) blocks per group -- 128 with a pooled gradient: that form holds three slices,
-    // 204 registers, two blocks per CU; with 256-block groups only two are resident and it loses to the two passes (498 against 453 us at n = 40,
-    // 256 x 256 x 64)
+    // 16384 / CB pixels, at most "elem.fused_max_slices" (256) blocks per group; with a pooled gradient: 64-channel groups and whole tiles
     {
         const int cb = c < 64 ? c : 64;
         const bool cb_ok = c >= 8 && (c < 64 ? (c & (c - 1)) == 0 : c % 64 == 0);
         const int slice = cb_ok ? 16384 / cb : 1;
+        // pooled form: tiles of (256 / Wt) rows x Wt = min(w, 128) columns
+        const int wt = w < 128 ? w : 128;
+        const bool g2_tiles = cb == 64 && wt >= 2 && (wt & (wt - 1)) == 0 && w % wt == 0 && 256 % wt == 0 && (256 / wt) % 2 == 0 && h % (256 / wt) == 0;
         if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && cb_ok && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && lddz % 8 == 0 &&
-            (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= (g2 ? 128 : shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES)) && batch <= 65535 &&
+            (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES) && batch <= 65535 && (!g2 || g2_tiles) &&
             fscr_n >= fused_scratch_doubles(batch, hw, c)) {
             const int ncb = c / cb;
             float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));

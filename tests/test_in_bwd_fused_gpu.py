@@ -76,10 +76,10 @@ def _reference(a, g, g2, stats, n, h, c, slope=0.2):
     return dz, dz.sum((0, 1, 2))
 
 
-# (n, h, c, pooled): 64 channels -> slices of 256 pixels (16 / 64 / 256 blocks per sample), 128 -> 128 pixels, 256 -> 64, 512 -> 32; 8 / 16 / 32
-# channels -> 2048 / 1024 / 512-pixel slices
-SHAPES = [(3, 64, 64, False), (2, 128, 64, True), (2, 256, 64, False), (2, 128, 128, True), (5, 64, 128, True), (3, 32, 256, False), (2, 16, 512, True),
-          (2, 64, 32, False), (1, 64, 8, True), (41, 16, 64, False)]
+# (n, h, c, pooled): barrier groups of 64 channels with 256-pixel slices (16 / 64 / 256 blocks per group; 128 .. 512 channels: 2 .. 8 groups per
+# sample); 8 / 32 channels -> 2048 / 512-pixel slices; pooled: tiles of 2 x 128, 4 x 64, 16 x 16 pixels
+SHAPES = [(3, 64, 64, False), (2, 128, 64, True), (2, 256, 64, False), (2, 256, 64, True), (2, 128, 128, True), (5, 64, 128, True), (3, 32, 256, False),
+          (2, 16, 512, True), (2, 64, 32, False), (1, 64, 8, False), (41, 16, 64, False)]
 
 
 @pytest.mark.parametrize("gshift", [0.0, 25.0])
@@ -125,7 +125,7 @@ def test_fused_without_bias_gradient():
 
 @pytest.mark.parametrize("n,h,c,why", [(2, 24, 64, "ragged: 576 pixels are not whole 256-pixel slices"),
                                        (1, 512, 64, "1024 slices per sample: more than a resident sample group"),
-                                       (1, 256, 64, "pooled form: 256 slices per sample, two blocks per CU"),
+                                       (1, 64, 8, "pooled form: 64-channel groups only"),
                                        (2, 8, 64, "a 64-pixel map is smaller than one slice"),
                                        (2, 32, 24, "3 channel lanes do not divide a block")])
 def test_shapes_outside_the_form_run_two_passes(n, h, c, why):

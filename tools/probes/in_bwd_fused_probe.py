@@ -9,7 +9,7 @@ from shmgan_amd import ops
 BF = torch.bfloat16
 pool = "--pool" in sys.argv
 CASES = [0, 1]
-if "--big" in sys.argv:
+if "--big" in sys.argv or "--max512" in sys.argv:
     ops.set_tuning("elem.fused_max_slices", 512)
 shapes = [(20, 256, 128), (20, 128, 256), (20, 64, 512), (4, 256, 128)] if "--big" in sys.argv else [(40, 256, 64), (40, 128, 128), (40, 64, 256), (40, 32, 512), (8, 256, 64), (16, 128, 64), (16, 64, 128), (16, 32, 256), (16, 16, 512)]
 for n, h, c in shapes:
