@@ -370,8 +370,8 @@ def in_bwd_fused_doubles(batch, hw, c):
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, fused=None):
     """fused: float64 scratch of in_bwd_fused_doubles(batch, h * w, c) elements (zero on entry, zero on return): the call may run the one-pass
     bf16 form (shm_in_bwd_fused_scratch); the library falls back to reduce + apply on shapes that form does not take."""
-    e = batch * h * w * c                          # reduce pass: g1 [+ g2 / 4], a; apply pass: the same + dz
-    nb = 2 * (_tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e)) + _tb(dz, e)
+    e = batch * h * w * c                          # algorithmic bytes: g1 [+ g2 / 4] and a read once, dz written (what the one-pass form moves;
+    nb = _tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e) + _tb(dz, e)        # the two-pass form reads g and a twice)
 
     def run():
         if fused is not None:
