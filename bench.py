@@ -55,7 +55,7 @@ def main():
                     help="bf16 mode only: element type of the gradient-signal tensors (float32 = SHM_BF16_GF32)")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f32x3"],
                     help="f32 = BASELINE configs[1] (default, the headline line: exact-fp32 MFMA); bf16 = configs[3]/[4] (bf16 MFMA path); f32x3 = fp32 "
-                         "tensors with the 3x3 unit-stride weight gradients as six bf16 MFMA products of exact three-plane splits (opt-in, wgrad.f32_split)")
+                         "tensors with the 3x3 unit-stride convolutions as six bf16 MFMA products of exact three-plane splits (opt-in: wgrad.f32_split, conv.f32_split)")
     args = ap.parse_args()
 
     # Before torch is imported or any torch.cuda function runs (device_count() may already bring HSA up, and HSA reads this at
@@ -99,6 +99,7 @@ def main():
 
     if args.dtype == "f32x3":
         ops.set_tuning("wgrad.f32_split", 1)
+        ops.set_tuning("conv.f32_split", 1)
     S, F, B = args.image_size, args.filter_size, args.batch
     model = ShmGANwithSSpecSeg(image_size=S, filter_size=F, batch_size=B, device=dev,
                                compute_dtype="bfloat16" if args.dtype == "bf16" else "float32",          # f32x3: fp32 tensors
@@ -197,7 +198,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SHMGAN train_step {S}x{S} 5-view, batch {B}/GPU, filter_size {F}, "
                                    + {"f32": "fp32", "bf16": "bf16 operands / fp32 accumulate",
-                                      "f32x3": "fp32 tensors, 3x3 unit-stride weight gradients from six bf16 MFMA products of three-plane splits"}[args.dtype]
+                                      "f32x3": "fp32 tensors, 3x3 unit-stride convolutions (forward, input gradient, weight gradient) from six bf16 MFMA products of three-plane splits"}[args.dtype]
                                    + (" (BASELINE configs[1])" if (S, B, F, args.dtype) == (256, 8, 64, "f32") else "")
                                    + (" (BASELINE configs[3])" if (S, B, F, args.dtype) == (512, 4, 64, "bf16") else "")
                                    + (" (BASELINE configs[4], per GPU)" if (S, B, F, args.dtype) == (256, 32, 64, "bf16") else ""),
@@ -280,6 +281,7 @@ def main():
             # the opt-in fp32-from-bf16-planes weight gradient (csrc/conv_wgrad_x3.hip) on the same model, same process:
             # the headline above stays the exact-fp32 MFMA step
             ops.set_tuning("wgrad.f32_split", 1)
+            ops.set_tuning("conv.f32_split", 1)
             for i in range(2):
                 model.train_step(*inputs, draws=draws_for(1000 + i), next_batch=inputs)
             torch.cuda.synchronize()
@@ -289,10 +291,12 @@ def main():
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t2
             ops.set_tuning("wgrad.f32_split", 0)
+            ops.set_tuning("conv.f32_split", 0)
             out["extra"] = {"f32x3": {"ms_per_step": round(dt3 / args.steps * 1e3, 3), "value": round(B * args.steps / dt3, 3), "unit": "images/sec",
                                       "steps": args.steps, "warmup": 2,
                                       "arithmetic": "3xbf16 planes (exact truncation split of every fp32 operand), 6 products with i + j <= 2, fp32 accumulate; "
-                                                    "3x3 unit-stride weight gradients only (wgrad_halo_x3_kernel), everything else exact-fp32 MFMA",
+                                                    "3x3 unit-stride layers: weight gradients (wgrad_halo_x3_kernel) and the forward / input-gradient products with more than 64 output "
+                                                    "channels (tapgemm_halo_x3_kernel); everything else exact-fp32 MFMA",
                                       "losses_finite": bool(all(np.isfinite(v) for k, v in model.losses().items() if k != "ssim"))}}
             note(f"f32x3 (opt-in): {dt3 / args.steps * 1e3:.2f} ms/step")
         if not args.no_kernel_timer and world == 1:      # a single-GPU property; at N > 1 the other ranks would wait behind it

@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SHM_LIB_PATH"]) if os.environ.get("SHM_LIB_PATH") else _HERE / "libshmgan_hip.so"
 CSRC = _HERE / "csrc"
 HEADER = _HERE.parent / "include" / "shmgan_hip.h"
-SOURCES = ["conv_igemm.hip", "conv_wreg16.hip", "conv_pingpong.hip", "conv_wgrad.hip", "conv_wgrad_x3.hip", "conv_rgb.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wreg16.hip", "conv_pingpong.hip", "conv_wgrad.hip", "conv_wgrad_x3.hip", "conv_fwd_x3.hip", "conv_rgb.hip", "norm_elem.hip", "color.hip", "imgloss.hip", "specseg.hip", "data.hip"]
 F32, BF16 = 0, 1                 # SHM_F32 / SHM_BF16 of include/shmgan_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function", "-Wno-unused-local-typedef"]
@@ -58,6 +58,7 @@ SIGNATURES = {
     "shm_conv2d_wgrad_norm_finish": (I, [P, P, P, I, I, I, I, I, I, P]),
     "shm_in_bwd_keep_dz_sums": (I, [P]),
     "shm_in_bwd_fused_scratch": (I, [P, Z]),
+    "shm_conv2d_x3_workspace": (I, [P, Z]),
     "shm_conv2d_wgrad_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I, I]),
     "shm_in_pool": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),
@@ -120,7 +121,7 @@ def build(force=False, verbose=False, jobs=None):
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
-    shared = [CSRC / "common.h", CSRC / "ablate.h", CSRC / "tapgemm.h", CSRC / "wgrad.h", HEADER]
+    shared = [CSRC / "common.h", CSRC / "ablate.h", CSRC / "tapgemm.h", CSRC / "wgrad.h", CSRC / "x3split.h", HEADER]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
     # what the objects were built WITH: compiler, flags and source list (a change of HIPCC_FLAGS must not relink stale objects)

@@ -1,0 +1,295 @@
+// fp32 unit-stride 3x3 forward / input-gradient convolutions as SIX bf16 MFMA products ("conv.f32_split" = 1; opt-in, round 5).
+//
+//   y[p][n] = sum_{tap, k} X[p + tap][k] * W[tap][n][k]            (ShmGANwithSSpecSeg.py:244-323: Conv2D 3x3 'same' of the generator blocks and,
+//                                                                   with the taps mirrored and W^T, their input gradients)
+//
+// The exact-fp32 path (tapgemm_halo_kernel<float>) runs v_mfma_f32_32x32x2_f32 at 0.92-0.95 of a 157 TFLOP/s pipe.  As in conv_wgrad_x3.hip
+// every fp32 operand splits EXACTLY into three bf16 planes by truncation and the six plane products with i + j <= 2 carry everything above
+// 2^-24 of the product; bf16 x bf16 is exact in the MFMA's fp32 accumulators: six v_mfma_f32_32x32x16_bf16 of 32 cycles per 32 x 32 x 16
+// instead of eight fp32 MFMAs of 64.
+//
+// Structure = tapgemm_halo_kernel's static-tap form (block: 16 x 16 output pixels x 128 output channels, eight waves of 64 x 64; per 32-channel
+// chunk the 18 x 18 halo sits in LDS once and the nine taps read it through nine shifted fragment addresses; bf16 LDS rows of 64 bytes with
+// that kernel's swizzles), with the operand planes made on the way in:
+//   A: the halo chunk comes from HBM as fp32 into REGISTERS (three items of 16 halo rows per wave, two 16-byte loads per lane and item), is
+//      split (4 VALU per value + 1.5 to pack) and written as three plane images; ONE LDS stage -- the next chunk's loads are in flight in
+//      registers during this chunk's nine taps;
+//   B: the weight planes are made once per launch by x3_split_weights_kernel (bf16 [3][taps][nout][K], a few hundred KB) and travel per tap
+//      through registers into one of two LDS stages, one tap ahead.
+// Per (tap, 16-channel K step) a wave reads 2 x 3 A and 2 x 3 B fragments and issues 24 MFMAs (x2 w0, x1 w1, x0 w2, x1 w0, x0 w1, x0 w0: the
+// small products first).  One barrier per tap, one more per chunk.  LDS: 3 x 24 KiB + 2 x 3 x 8 KiB = 120 KiB, one block per CU.
+// Epilogues as tapgemm_halo_kernel's for fp32 outputs: bias + LeakyReLU + element stores through buffer descriptors, InstanceNorm statistics,
+// and the gsum form (TapGemmArgs).  Not taken (the exact kernels run): normalise-on-load sources, outputs beyond 4 GiB, K % 32 != 0.
+#include "tapgemm.h"
+#include "x3split.h"
+
+namespace {
+constexpr int X3_BN = 128, X3_HC = 18, X3_NIT = 24, X3_NW = 8, X3_NA = X3_NIT / X3_NW;
+constexpr int X3_ASTG = X3_NIT * 16 * 16;          // 4-byte words per A plane (384 rows of 64 bytes)
+constexpr int X3_BSTG = X3_BN * 16;                // words per B plane stage (128 rows of 64 bytes)
+constexpr unsigned X3_LDS = (3u * X3_ASTG + 6u * X3_BSTG) * 4u;
+
+__global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float a = w[i], b = i + 1 < n ? w[i + 1] : 0.f;
+    unsigned p0, p1, p2;
+    x3_split_pair(a, b, p0, p1, p2);
+    if (i + 1 < n) {
+        *(unsigned*)(planes + i) = p0;
+        *(unsigned*)(planes + n + i) = p1;
+        *(unsigned*)(planes + 2 * n + i) = p2;
+    } else {
+        planes[i] = (unsigned short)p0;
+        planes[n + i] = (unsigned short)p1;
+        planes[2 * n + i] = (unsigned short)p2;
+    }
+}
+}  // namespace
+
+template <bool GS>
+__global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmArgs a, const unsigned plane_bytes) {
+    constexpr int HC = X3_HC, NW = X3_NW, NA = X3_NA, ASTG = X3_ASTG, BSTG = X3_BSTG;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    float* const sA = smem;                      // [plane][ASTG]
+    float* const sB = smem + 3 * ASTG;           // [stage][plane][BSTG]
+
+    const TapPhase& P = a.ph[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ppr = a.wi >> 4, ppi = (a.hi >> 4) * ppr;
+    const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
+    const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
+    const int n0 = blockIdx.y * X3_BN;
+
+    // ---- staging lane constants.  A item it (0 .. 23) = halo rows [16 it, 16 it + 16) of 18 x 18; wave w owns items w, w + 8, w + 16; lane ->
+    // (row drow of the item, 16-byte bf16 chunk dq of its 64-byte row) = eight channels = 32 bytes of fp32 source; LDS chunk dq holds source
+    // chunk dq ^ (((R >> 1) + R / 18) & 3) (tapgemm_halo_kernel's conflict-free static-tap swizzle)
+    const int drow = lane >> 2, dq = lane & 3;
+    unsigned arow1[NA], arow2[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int hrow = 16 * (wave + NW * j) + drow;
+        const int hr = hrow / HC, hc = hrow - hr * HC;
+        const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const int pix = (img * a.hi + iy) * a.wi + ix;
+        const int coff = (dq ^ (((hrow >> 1) + hr) & 3)) * 8;
+        arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * 4u : 0xffffffffu;
+        arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * 4u : 0xffffffffu;
+    }
+    // B item of wave w = weight rows [16 w, 16 w + 16) of the block's 128: LDS chunk dq of row r holds source chunk dq ^ ((r >> 2) & 3)
+    const int brow = wave * 16 + drow;
+    const unsigned wrow = n0 + brow < a.nout ? (unsigned)((n0 + brow) * a.K + (dq ^ ((brow >> 2) & 3)) * 8) * 2u : 0xffffffffu;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    const int nch = a.K >> 5;
+
+    // stage registers
+    f32x4 ar[NA][2];
+    u32x4 br[3];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk << 5;
+        const bool second = c0 >= a.c1;                          // block-uniform
+        const unsigned cb = (unsigned)(second ? c0 - a.c1 : c0) * 4u;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const unsigned r = second ? arow2[j] : arow1[j];
+            const unsigned off = r == 0xffffffffu ? r : r + cb;
+            const unsigned off2 = r == 0xffffffffu ? r : r + cb + 16u;
+            ar[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off, 0, 0));
+            ar[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off2, 0, 0));
+        }
+    };
+    auto spill_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            u32x4 p0, p1, p2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned q0, q1, q2;
+                x3_split_pair(ar[j][e >> 1][2 * (e & 1)], ar[j][e >> 1][2 * (e & 1) + 1], q0, q1, q2);
+                p0[e] = q0;
+                p1[e] = q1;
+                p2[e] = q2;
+            }
+            float* dst = sA + (wave + NW * j) * 256 + lane * 4;
+            *(u32x4*)dst = p0;
+            *(u32x4*)(dst + ASTG) = p1;
+            *(u32x4*)(dst + 2 * ASTG) = p2;
+        }
+    };
+    auto load_b = [&](int t_wi, int chunk) {
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (chunk << 5)) * 2u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase + (unsigned)p * plane_bytes;
+            br[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+        }
+    };
+    auto spill_b = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(u32x4*)(sB + (stage * 3 + p) * BSTG + wave * 256 + lane * 4) = br[p];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addresses (words).  A: lane -> patch pixel (4 wm + 2 i + (l31 >> 4), l31 & 15), K half h: the halo row of tap t is a
+    // register for the whole block, tile i sits 36 halo rows (2304 bytes) further on (the swizzle does not change), K step kk = XOR 8 words.
+    // B: row l31 of the wave's 64 (+ 32 j), chunk (2 kk + h) ^ ((l31 >> 2) & 3)
+    const int hb0 = (4 * wm + (l31 >> 4) + 1) * HC + (l31 & 15) + 1;
+    int fs[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hrow = hb0 + P.dh[t] * HC + P.dw[t];
+        fs[t] = hrow * 16 + ((h ^ (((hrow >> 1) + hrow / HC) & 3)) << 2);
+    }
+    const int swb = (l31 >> 2) & 3;
+    const int fb0 = wn * 64 * 16 + l31 * 16 + ((0 + h) ^ swb) * 4, fb1 = wn * 64 * 16 + l31 * 16 + ((2 + h) ^ swb) * 4;
+    const int tl = lane < 9 ? lane : 0;
+    const int tapw_v = P.widx[tl];
+    int tw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tw[t] = __builtin_amdgcn_readlane(tapw_v, t);
+
+    load_a(0);
+    load_b(tw[0], 0);
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        if (chunk) SHM_LDS_BARRIER();                // every wave is past its last fragment read of the previous chunk's planes
+        spill_a();
+        if (chunk + 1 < nch) load_a(chunk + 1);      // in flight during this chunk's nine taps
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // B stage parity of step s = 9 chunk + tap: the previous step's fragments came from the other stage, and every wave finished them
+            // before it arrived at that step's barrier
+            const int stage = (chunk + tap) & 1;
+            spill_b(stage);
+            if (tap < 8)
+                load_b(tw[tap + 1], chunk);
+            else if (chunk + 1 < nch)
+                load_b(tw[0], chunk + 1);
+            SHM_LDS_BARRIER();                       // the step's weight planes (and, at tap 0, the chunk's halo planes) are complete
+            const float* Bb = sB + stage * 3 * BSTG;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 av[3][2], bv[3][2];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[p][i] = *(const f32x4*)(sA + p * ASTG + ((fs[tap] ^ (kk << 3)) + i * (2 * HC * 16)));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[p][j] = *(const f32x4*)(Bb + p * BSTG + j * 512 + (kk ? fb1 : fb0));
+                }
+                // the small products first
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[q]][i]), __builtin_bit_cast(bf16x8, bv[PB[q]][j]),
+                                                                               acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (tapgemm_halo_kernel's, fp32 outputs): bias + LeakyReLU + element stores (+ InstanceNorm statistics / gsum)
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        bj[j] = (a.bias && n < a.nout) ? a.bias[n] : 0.f;
+        asm volatile("" : "+v"(bj[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        // the 32 columns of a (wave, j) group lie in one output part (n1 % 32 == 0, launcher): part, pitch and descriptors are scalars; a lane's
+        // address is one register per 32 x 32 tile (its pixel of accumulator row 0) plus a scalar offset per row
+        const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * 64 + j * 32);
+        const int gp = nb < a.n1 ? 0 : 1;
+        const int n = nb + l31;
+        const int nl = n - (gp ? a.n1 : 0);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(gp ? a.y2 : a.y, 0, gp ? a.y2bytes : a.ybytes, 0x00020000);
+        const unsigned ldyb = (unsigned)(gp ? a.ldy2 : a.ldy) * 4u, nyb = (unsigned)(n < a.nout ? nl : 0) * 4u;
+        [[maybe_unused]] const bool on = GS && a.gred[gp] != nullptr && nb < a.nout;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
+        [[maybe_unused]] const unsigned ldab = (unsigned)a.ldgaux[gp] * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned pix0 = (unsigned)((img * a.hi + (y0 + 4 * wm + 2 * i)) * a.wi + x0 + 4 * h);
+            const unsigned yo = pix0 * ldyb + nyb;
+            [[maybe_unused]] float q[16];
+            if constexpr (GS) {
+                const unsigned ao = pix0 * ldab + nyb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));         // scalar
+                    q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, cr * ldab, 0));
+                }
+            }
+            if (n < a.nout) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));
+                    const float v = shm_lrelu(acc[i][j][r] + bj[j], a.slope);
+                    s1[j] += v;
+                    if constexpr (GS)
+                        s2[j] += v * q[r];
+                    else
+                        s2[j] = __builtin_fmaf(v, v, s2[j]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, yo, cr * ldyb, 0);
+                }
+            }
+        }
+        const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+        if constexpr (GS) {
+            if (on && h == 0 && n < a.nout) {
+                const int pc = gp ? a.nout - a.n1 : a.n1;
+                double* dst = a.gred[gp] + ((size_t)((prem * 4 + wm) % a.gslots) * a.gbatch * pc + (size_t)img * pc + nl) * 2;
+                atomicAdd(dst, (double)t1);
+                atomicAdd(dst + 1, (double)t2);
+            }
+        } else {
+            if (a.stats && h == 0 && n < a.nout) {
+                double* dst = a.stats + (size_t)((prem * 4 + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + n) * 2;
+                atomicAdd(dst, (double)t1);
+                atomicAdd(dst + 1, (double)t2);
+            }
+        }
+    }
+}
+
+// ws: bf16 [3][9 nout K] (ws_bytes >= 54 nout K).  gs_fused: the launch takes the gsum sums in its epilogue (a.gred as the launcher left them).
+int shm_x3_fwd_eligible(const TapGemmArgs& a, size_t ws_bytes) {
+    return a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0) && a.nout > 64 && a.nt == nullptr && a.ybytes != 0 &&
+           (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0)) && ws_bytes >= (size_t)54 * a.nout * a.K && (size_t)54 * a.nout * a.K < 0xfffffff0u;
+}
+
+int shm_x3_fwd_launch(const TapGemmArgs& a0, int batch, bool gs_fused, void* ws, hipStream_t st, const char* who) {
+    const size_t n = (size_t)9 * a0.nout * a0.K;
+    hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)shm_cdiv((long)((n + 1) / 2), 256)), dim3(256), 0, st, (const float*)a0.w, (unsigned short*)ws, n);
+    TapGemmArgs a = a0;
+    a.w = ws;
+    a.wbytes = (unsigned)(n * 6);
+    const dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, X3_BN), 1);
+    static const hipError_t attr0 = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    static const hipError_t attr1 = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    SHM_REQUIRE(attr0 == hipSuccess && attr1 == hipSuccess, SHM_E_HIP, "%s: cannot reserve 120 KiB of LDS", who);
+    if (gs_fused)
+        hipLaunchKernelGGL((tapgemm_halo_x3_kernel<true>), grid, dim3(512), X3_LDS, st, a, (unsigned)(n * 2));
+    else
+        hipLaunchKernelGGL((tapgemm_halo_x3_kernel<false>), grid, dim3(512), X3_LDS, st, a, (unsigned)(n * 2));
+    shm_set_last_kernel(gs_fused ? "tapgemm_halo_x3_kernel<true>" : "tapgemm_halo_x3_kernel<false>");
+    return SHM_OK;
+}

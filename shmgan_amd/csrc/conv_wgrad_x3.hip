@@ -19,20 +19,8 @@
 // re-read 6 bytes per element of every activation and gradient tensor (~20 ms per step).  Per (K step of 16 pixels, tap): one x fragment per
 // plane meets the K step's three dY fragments: x0 three MFMAs, x1 two, x2 one.
 #include "wgrad.h"
+#include "x3split.h"
 
-namespace {
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// (a, b) -> the three dwords (plane 0, 1, 2) holding the bf16 planes of a in the low half and of b in the high half
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                                   // hi16(b) : hi16(a)
-    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);          // exact
-    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-    p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);      // exact, <= 8 significant bits
-    p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-}
-}  // namespace
 
 // NM: the x source a.ntpart is the UN-normalised activation of an InstanceNorm block (SHM_NORM_EXACT, as wgrad_halo_kernel<1>): shm_in_norm on the in-image
 // pixels of the stage registers before the split; the block's 64 (mean, inv, beta) triples of the current sample sit in LDS behind the plane images
@@ -170,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned q0, q1, q2;
-                    split_pair(v[2 * e], v[2 * e + 1], q0, q1, q2);
+                    x3_split_pair(v[2 * e], v[2 * e + 1], q0, q1, q2);
                     p0[e] = q0;
                     p1[e] = q1;
                     p2[e] = q2;

@@ -61,6 +61,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"tapgemm.flat_epilogue", "SHM_TAPGEMM_FLAT_EPILOGUE", 0, 0, 1},
     {"elem.fused_bwd", "SHM_ELEM_FUSED_BWD", 1, 0, 1},
     {"elem.fused_max_slices", "SHM_ELEM_FUSED_MAX_SLICES", 256, 1, 512},
+    {"conv.f32_split", "SHM_CONV_F32_SPLIT", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};

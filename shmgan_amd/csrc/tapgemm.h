@@ -63,6 +63,11 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
 // (launch_tapgemm_t's SHM_TG_WREG case) has checked eligibility.  np8 = batch * (hi / 8) * (wi / 16) patches, ncu = compute units.
 int shm_wreg16_launch(const TapGemmArgs& a, int np8, int ncu, hipStream_t st, const char* who);
 
+// conv_fwd_x3.hip ("conv.f32_split"): fp32 unit-stride 3x3 layers of more than 64 output channels as six bf16 MFMA products of exact three-plane
+// splits; the caller (launch_tapgemm_t) has chosen a static-tap halo variant and decided whether the gsum sums are fused.  ws: bf16 [3][9 nout K]
+int shm_x3_fwd_eligible(const TapGemmArgs& a, size_t ws_bytes);
+int shm_x3_fwd_launch(const TapGemmArgs& a, int batch, bool gs_fused, void* ws, hipStream_t st, const char* who);
+
 // conv_pingpong.hip: the K = 64 layers as a one-block-per-CU ping-pong kernel (two wave groups alternating between the MFMA segment and the
 // load / epilogue / store segment); shm_pp_eligible checks the shape, the caller that no gsum / norm form is wanted.
 int shm_pp_eligible(const TapGemmArgs& a);

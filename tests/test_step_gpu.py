@@ -293,7 +293,9 @@ def test_golden_fixture_on_device(name):
     _check_grad_fixture(m, gold)
 
 
-@pytest.mark.parametrize("f32_split", [0, 1])          # 1: "wgrad.f32_split", the fp32 weight gradients from six bf16 MFMA products -- same bounds
+# f32_split 1: "wgrad.f32_split" (the fp32 weight gradients from six bf16 MFMA products), 2: plus "conv.f32_split" (the forward and input-gradient
+# convolutions too, bench.py --dtype f32x3) -- same bounds
+@pytest.mark.parametrize("f32_split", [0, 1, 2])
 @pytest.mark.parametrize("name", ["step_S256_F64_B1.npz", "step_S256_F64_B8.npz"])
 def test_golden_fixture_full_size(name, f32_split):
     """BASELINE configs[1] at full size (S=256, F=64; B=8 is the bench batch) against the committed float64-oracle
@@ -310,7 +312,8 @@ def test_golden_fixture_full_size(name, f32_split):
     m.SpecSeg.set_weights(sp.init_specseg(seed=44 + step))
     m.before_backward, pinned = _pin_kinks(m, gold)
     try:
-        ops.set_tuning("wgrad.f32_split", f32_split)
+        ops.set_tuning("wgrad.f32_split", 1 if f32_split else 0)
+        ops.set_tuning("conv.f32_split", 1 if f32_split == 2 else 0)
         timer = ops.KernelTimer() if f32_split else None
         ops.TIMER = timer
         m.train_step(*st.make_inputs(B, S), draws=st.make_draws(step, B, S, F), style_factor=st.style_factor_intended(S), apply=False)
@@ -321,6 +324,7 @@ def test_golden_fixture_full_size(name, f32_split):
     if f32_split:                                        # the knob did take the step's 3x3 unit-stride weight gradients
         names = list(timer.summary())
         assert any(k.startswith("wgrad_halo_x3_kernel") for k in names) and not any(k == "wgrad_halo_kernel" for k in names), names
+        assert any(k.startswith("tapgemm_halo_x3_kernel") for k in names) == (f32_split == 2), names
     got = m.losses()
     for k in got:
         if k != "ssim":

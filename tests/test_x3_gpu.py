@@ -147,3 +147,120 @@ def test_knob_leaves_other_launches_alone():
     ws = _ws(ops.conv2d_wgrad_workspace(n, h, h, 64, 64, 3))
     ops.conv2d_wgrad(xb, None, 0, 64, 0, dyb, 64, dw, n, h, h, 64, 64, 64, 3, 1, 0, ws)
     assert ops.last_kernel().startswith("wgrad_halo_bf16_kernel"), ops.last_kernel()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# "conv.f32_split": the 3x3 unit-stride forward / input-gradient layers (csrc/conv_fwd_x3.hip), same contract
+
+def _wk(w, cin_p):
+    """HWIO float64 -> the forward kernels' [tap][cout][K] layout (ops.transpose_taps)."""
+    ops = _ops()
+    k, _, cin, cout = w.shape
+    wt = torch.zeros(k * k * cout * cin_p, device="cuda")
+    ops.transpose_taps(dev(w), wt, k * k, cin, cout, cin_p)
+    return wt
+
+
+@pytest.mark.parametrize("n,h,cin,cout,c1", [
+    (2, 32, 64, 128, 0),         # one chunk pair, patches with every border case
+    (1, 16, 96, 192, 0),         # three 32-channel chunks; 192 outputs = one full and one half block of 128
+    (3, 16, 128, 128, 64),       # Concatenate: two sources of 64 channels
+    (1, 48, 32, 256, 0),         # one chunk, two blocks of output channels, nine patches
+])
+def test_x3_forward_matches_the_oracle_and_the_exact_kernel(n, h, cin, cout, c1):
+    ops = _ops()
+    rng = np.random.default_rng(70 + n)
+    x = rng.standard_normal((n, h, h, cin)) * np.exp(rng.standard_normal((n, h, h, cin)))
+    w = rng.standard_normal((3, 3, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    x32, w32, b32 = (v.astype(np.float32).astype(np.float64) for v in (x, w, b))
+    from util import conv_ref
+    ref = conv_ref(x32, w32, 1) + b32
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    xa, xb = (dev(x), None) if not c1 else (dev(x[..., :c1]), dev(x[..., c1:]))
+    outs = {}
+    ops.set_tuning("tapgemm.variant", "halo128_st")          # (small test maps would go to the 64 x 64 DMA tile: the step's layers take the halo kernels)
+    for split in (1, 0):
+        ops.set_tuning("conv.f32_split", split)
+        y = torch.full((n, h, h, cout), 5.0, device="cuda")
+        stats = torch.zeros(n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+        ops.conv2d_in_fwd(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, _wk(w, cin), dev(b), y, cout, n, h, h, cin, cout, 3, 1, 0.2, stats, 1e-6, scratch=scr)
+        k = ops.last_kernel()
+        torch.cuda.synchronize()
+        assert float(scr.abs().max()) == 0.0
+        outs[split] = (y, stats.clone(), k)
+    (y3, s3, k3), (y1, s1, k1) = outs[1], outs[0]
+    assert k3 == "tapgemm_halo_x3_kernel<false>" and "x3" not in k1, (k3, k1)
+    e3, e1 = rel_l2(host(y3), ref), rel_l2(host(y1), ref)
+    print(f"rel-L2 against float64: six bf16 products {e3:.2e}, exact-fp32 MFMA {e1:.2e}")
+    assert e3 < TOL and e3 < 4 * e1 + 1e-7
+    # the fused InstanceNorm statistics (mean, 1 / sqrt(var + eps)) of the two paths
+    assert rel_l2(host(s3), host(s1)) < 1e-5
+    # run to run: the same bits
+    ops.set_tuning("conv.f32_split", 1)
+    y4 = torch.empty_like(y3)
+    ops.conv2d_fwd(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, _wk(w, cin), dev(b), y4, cout, n, h, h, cin, cout, 3, 1, 0.2)
+    assert ops.last_kernel() == "tapgemm_halo_x3_kernel<false>" and torch.equal(y4, y3)
+
+
+@pytest.mark.parametrize("n,h,cin,cout,n1", [(2, 32, 128, 64, 0), (2, 16, 256, 128, 128), (1, 32, 192, 96, 64)])
+def test_x3_input_gradient_with_gsum(n, h, cin, cout, n1):
+    """dx (and the Concatenate split dx / dx2) and the InstanceNorm-backward sums of the gsum epilogue, against the exact-fp32 launch."""
+    ops = _ops()
+    rng = np.random.default_rng(80 + n)
+    w = dev(rng.standard_normal((3, 3, cin, cout)) * 0.1)
+    dy = dev(rng.standard_normal((n, h, h, cout)) * np.exp(rng.standard_normal((n, h, h, cout))))
+    c0 = n1 if n1 else cin
+    c1 = cin - n1 if n1 else 0
+    aux0 = dev(rng.standard_normal((n, h, h, c0)))
+    aux1 = dev(rng.standard_normal((n, h, h, c1))) if n1 else None
+    res = {}
+    ops.set_tuning("tapgemm.variant", "halo128_st")
+    for split in (1, 0):
+        ops.set_tuning("conv.f32_split", split)
+        dx = torch.full((n, h, h, c0), 7.0, device="cuda")
+        dx2 = torch.full((n, h, h, c1), 7.0, device="cuda") if n1 else None
+        red0 = torch.zeros(ops.GSUM_SLOTS * n * c0 * 2, dtype=torch.float64, device="cuda")
+        red1 = torch.zeros(ops.GSUM_SLOTS * n * c1 * 2, dtype=torch.float64, device="cuda") if n1 else None
+        ops.conv2d_dgrad(dy, cout, w, dx, dx2, n1, c0, c1, n, h, h, cin, cout, 3, 1, gsum=(aux0, c0, red0), gsum2=(aux1, c1, red1) if n1 else None)
+        k = ops.last_kernel()
+        torch.cuda.synchronize()
+        res[split] = (dx, dx2, red0.view(ops.GSUM_SLOTS, -1).sum(0), None if red1 is None else red1.view(ops.GSUM_SLOTS, -1).sum(0), k)
+    a, b = res[1], res[0]
+    assert a[4] == "tapgemm_halo_x3_kernel<true>" and "x3" not in b[4], (a[4], b[4])
+    assert rel_l2(host(a[0]), host(b[0])) < 2e-6 and rel_l2(host(a[2]), host(b[2])) < 1e-5
+    if n1:
+        assert rel_l2(host(a[1]), host(b[1])) < 2e-6 and rel_l2(host(a[3]), host(b[3])) < 1e-5
+    # against float64
+    xt = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(xt, host(w) if False else torch.from_numpy(host(w)), 1), xt, nchw(host(dy)))
+    from util import nhwc
+    ref = nhwc(ref)
+    got = host(a[0]) if not n1 else np.concatenate([host(a[0]), host(a[1])], -1)
+    assert rel_l2(got, ref) < TOL
+
+
+def test_x3_forward_nan_and_the_one_shot_workspace():
+    ops = _ops()
+    rng = np.random.default_rng(90)
+    n, h, cin, cout = 1, 16, 64, 128
+    x = dev(rng.standard_normal((n, h, h, cin)))
+    x[0, 3, 5, 7] = float("nan")
+    x[0, 9, 2, 40] = float("inf")
+    wk = _wk(rng.standard_normal((3, 3, cin, cout)) * 0.1, cin)
+    y = torch.empty((n, h, h, cout), device="cuda")
+    ops.set_tuning("conv.f32_split", 1)
+    ops.set_tuning("tapgemm.variant", "halo128_st")
+    ops.conv2d_fwd(x, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 1.0)
+    assert ops.last_kernel() == "tapgemm_halo_x3_kernel<false>"
+    bad = ~torch.isfinite(y)
+    assert bool(bad[0, 2:5, 4:7].all()) and bool(bad[0, 8:11, 1:4].all())           # every output the two values reach
+    assert bool(torch.isfinite(y[0, 13:, 8:]).all())
+    # shapes the kernel does not take run the exact kernels, also right after an armed call
+    y64 = torch.empty((n, h, h, 64), device="cuda")
+    ops.conv2d_fwd(x, None, 0, cin, 0, _wk(rng.standard_normal((3, 3, cin, 64)) * 0.1, cin), None, y64, 64, n, h, h, cin, 64, 3, 1, 1.0)
+    assert "x3" not in ops.last_kernel()
+    ops.set_tuning("conv.f32_split", 0)
+    ops.conv2d_fwd(torch.nan_to_num(x, 0.0, 0.0, 0.0), None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 1.0)
+    assert "x3" not in ops.last_kernel() and bool(torch.isfinite(y).all())
