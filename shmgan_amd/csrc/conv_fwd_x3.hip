@@ -19,15 +19,24 @@
 // Per (tap, 16-channel K step) a wave reads 2 x 3 A and 2 x 3 B fragments and issues 24 MFMAs (x2 w0, x1 w1, x0 w2, x1 w0, x0 w1, x0 w0: the
 // small products first).  One barrier per tap, one more per chunk.  LDS: 3 x 24 KiB + 2 x 3 x 8 KiB = 120 KiB, one block per CU.
 // Epilogues as tapgemm_halo_kernel's for fp32 outputs: bias + LeakyReLU + element stores through buffer descriptors, InstanceNorm statistics,
-// and the gsum form (TapGemmArgs).  Not taken (the exact kernels run): normalise-on-load sources, outputs beyond 4 GiB, K % 32 != 0.
+// and the gsum form (TapGemmArgs); a normalise-on-load source (SHM_NORM_EXACT) is normalised in the stage registers before the split.  Layers of
+// at most 64 output channels run a block of 32 x 16 pixels x 64 channels (eight waves along M).  Not taken (the exact kernels run): SHM_NORM_SCALED
+// sources, outputs beyond 4 GiB, K % 32 != 0.
 #include "tapgemm.h"
 #include "x3split.h"
 
 namespace {
-constexpr int X3_BN = 128, X3_HC = 18, X3_NIT = 24, X3_NW = 8, X3_NA = X3_NIT / X3_NW;
-constexpr int X3_ASTG = X3_NIT * 16 * 16;          // 4-byte words per A plane (384 rows of 64 bytes)
-constexpr int X3_BSTG = X3_BN * 16;                // words per B plane stage (128 rows of 64 bytes)
-constexpr unsigned X3_LDS = (3u * X3_ASTG + 6u * X3_BSTG) * 4u;
+// Two block shapes, eight waves of 64 x 64 each: BN = 128 output channels x 16 x 16 pixels (waves 4 (M) x 2 (N)) and, for the layers of at most 64
+// output channels, BN = 64 x a patch of 32 x 16 pixels (waves 8 x 1) -- the same fragment reads per MFMA
+template <int BN>
+struct X3Shape {
+    static constexpr int HC = 18, NW = 8, PH = BN == 128 ? 16 : 32, WGN = BN / 64, WGM = NW / WGN;
+    static constexpr int NROW = (PH + 2) * HC, NIT = (NROW + 15) / 16, NA = (NIT + NW - 1) / NW;       // 24 / 39 items of 16 halo rows, 3 / 5 per wave
+    static constexpr int NBI = BN / 16;                                                               // weight items: 8 / 4
+    static constexpr int ASTG = NIT * 256;             // 4-byte words per A plane (rows of 64 bytes)
+    static constexpr int BSTG = BN * 16;               // words per B plane stage
+    static constexpr unsigned LDS = (3u * ASTG + 6u * BSTG) * 4u;       // 120 KiB / 141 KiB: one block per CU
+};
 
 __global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
@@ -47,9 +56,10 @@ __global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __re
 }
 }  // namespace
 
-template <bool GS>
+template <bool GS, int BN>
 __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmArgs a, const unsigned plane_bytes) {
-    constexpr int HC = X3_HC, NW = X3_NW, NA = X3_NA, ASTG = X3_ASTG, BSTG = X3_BSTG;
+    typedef X3Shape<BN> SH;
+    constexpr int HC = SH::HC, NW = SH::NW, NA = SH::NA, NIT = SH::NIT, ASTG = SH::ASTG, BSTG = SH::BSTG, PH = SH::PH, WGN = SH::WGN, WGM = SH::WGM;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     float* const sA = smem;                      // [plane][ASTG]
     float* const sB = smem + 3 * ASTG;           // [stage][plane][BSTG]
@@ -58,30 +68,40 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ppr = a.wi >> 4, ppi = (a.hi >> 4) * ppr;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int ppr = a.wi >> 4, ppi = (a.hi / PH) * ppr;
     const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
-    const int y0 = (prem / ppr) << 4, x0 = (prem % ppr) << 4;
-    const int n0 = blockIdx.y * X3_BN;
+    const int y0 = (prem / ppr) * PH, x0 = (prem % ppr) << 4;
+    const int n0 = blockIdx.y * BN;
 
-    // ---- staging lane constants.  A item it (0 .. 23) = halo rows [16 it, 16 it + 16) of 18 x 18; wave w owns items w, w + 8, w + 16; lane ->
+    // ---- staging lane constants.  A item it = halo rows [16 it, 16 it + 16) of the (PH + 2) x 18 halo; wave w owns items w, w + 8, ...; lane ->
     // (row drow of the item, 16-byte bf16 chunk dq of its 64-byte row) = eight channels = 32 bytes of fp32 source; LDS chunk dq holds source
     // chunk dq ^ (((R >> 1) + R / 18) & 3) (tapgemm_halo_kernel's conflict-free static-tap swizzle)
     const int drow = lane >> 2, dq = lane & 3;
     unsigned arow1[NA], arow2[NA];
+    unsigned inimg = 0;                            // bit j: the lane's row of item j is a pixel of the image (what a normalising source touches)
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int hrow = 16 * (wave + NW * j) + drow;
         const int hr = hrow / HC, hc = hrow - hr * HC;
         const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-        const bool v = hrow < HC * HC && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        const bool v = hrow < SH::NROW && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+        inimg |= (v ? 1u : 0u) << j;
         const int pix = (img * a.hi + iy) * a.wi + ix;
         const int coff = (dq ^ (((hrow >> 1) + hr) & 3)) * 8;
         arow1[j] = v ? (unsigned)(pix * a.ldx + coff) * 4u : 0xffffffffu;
         arow2[j] = v ? (unsigned)(pix * a.ldx2 + coff) * 4u : 0xffffffffu;
     }
-    // B item of wave w = weight rows [16 w, 16 w + 16) of the block's 128: LDS chunk dq of row r holds source chunk dq ^ ((r >> 2) & 3)
+    // the lane's first channel within a 32-channel chunk, item by item (two bits each): only the swizzle differs between items
+    unsigned coffs = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int hrow = 16 * (wave + NW * j) + drow;
+        coffs |= (unsigned)(dq ^ (((hrow >> 1) + hrow / HC) & 3)) << (2 * j);
+    }
+    // B item of wave w (< BN / 16) = weight rows [16 w, 16 w + 16) of the block's BN: LDS chunk dq of row r holds source chunk dq ^ ((r >> 2) & 3)
     const int brow = wave * 16 + drow;
+    const bool bwave = wave < SH::NBI;             // wave-uniform
     const unsigned wrow = n0 + brow < a.nout ? (unsigned)((n0 + brow) * a.K + (dq ^ ((brow >> 2) & 3)) * 8) * 2u : 0xffffffffu;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
@@ -91,22 +111,40 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     // stage registers
     f32x4 ar[NA][2];
     u32x4 br[3];
+    // normalise-on-load (TapGemmArgs::nt, SHM_NORM_EXACT): source a.ntpart is the UN-normalised activation of an InstanceNorm block; shm_in_norm
+    // on the in-image values of the stage registers before the split (padding stays zero), the (mean, inv, beta) rows of the block's sample
+    // straight from the table (L2): 6 x 16 bytes per lane, item and chunk
+    const float* const ntb = a.nt ? a.nt + (size_t)img * SHM_NT_PLANES * a.ntc : nullptr;
+    int ncs = -1;                                  // first channel (within the normalised part) of the chunk in the stage registers, -1: as stored
     auto load_a = [&](int chunk) {
         const int c0 = chunk << 5;
         const bool second = c0 >= a.c1;                          // block-uniform
         const unsigned cb = (unsigned)(second ? c0 - a.c1 : c0) * 4u;
+        ncs = (ntb && (int)second == a.ntpart) ? (second ? c0 - a.c1 : c0) : -1;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const unsigned r = second ? arow2[j] : arow1[j];
-            const unsigned off = r == 0xffffffffu ? r : r + cb;
-            const unsigned off2 = r == 0xffffffffu ? r : r + cb + 16u;
-            ar[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off, 0, 0));
-            ar[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off2, 0, 0));
+            if ((NA - 1) * NW + NW <= NIT || j < NA - 1 || wave + NW * j < NIT) {
+                const unsigned r = second ? arow2[j] : arow1[j];
+                const unsigned off = r == 0xffffffffu ? r : r + cb;
+                const unsigned off2 = r == 0xffffffffu ? r : r + cb + 16u;
+                ar[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off, 0, 0));
+                ar[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsx2 : rsx, off2, 0, 0));
+            }
         }
     };
     auto spill_a = [&]() {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
+            if (!((NA - 1) * NW + NW <= NIT || j < NA - 1 || wave + NW * j < NIT)) continue;
+            if (ncs >= 0 && ((inimg >> j) & 1u)) {
+                const float* t = ntb + ncs + 8 * ((coffs >> (2 * j)) & 3u);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f32x4 m4 = *(const f32x4*)(t + 4 * hf), i4 = *(const f32x4*)(t + a.ntc + 4 * hf), b4 = *(const f32x4*)(t + 2 * a.ntc + 4 * hf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ar[j][hf][e] = shm_in_norm(ar[j][hf][e], m4[e], i4[e], b4[e]);
+                }
+            }
             u32x4 p0, p1, p2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -123,6 +161,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         }
     };
     auto load_b = [&](int t_wi, int chunk) {
+        if (!bwave) return;
         const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (chunk << 5)) * 2u;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -131,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         }
     };
     auto spill_b = [&](int stage) {
+        if (!bwave) return;
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(u32x4*)(sB + (stage * 3 + p) * BSTG + wave * 256 + lane * 4) = br[p];
     };
@@ -256,13 +296,13 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         if constexpr (GS) {
             if (on && h == 0 && n < a.nout) {
                 const int pc = gp ? a.nout - a.n1 : a.n1;
-                double* dst = a.gred[gp] + ((size_t)((prem * 4 + wm) % a.gslots) * a.gbatch * pc + (size_t)img * pc + nl) * 2;
+                double* dst = a.gred[gp] + ((size_t)((prem * WGM + wm) % a.gslots) * a.gbatch * pc + (size_t)img * pc + nl) * 2;
                 atomicAdd(dst, (double)t1);
                 atomicAdd(dst + 1, (double)t2);
             }
         } else {
             if (a.stats && h == 0 && n < a.nout) {
-                double* dst = a.stats + (size_t)((prem * 4 + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + n) * 2;
+                double* dst = a.stats + (size_t)((prem * WGM + wm) % a.stats_slots) * a.stats_stride + ((size_t)img * a.nout + n) * 2;
                 atomicAdd(dst, (double)t1);
                 atomicAdd(dst + 1, (double)t2);
             }
@@ -271,9 +311,22 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
 }
 
 // ws: bf16 [3][9 nout K] (ws_bytes >= 54 nout K).  gs_fused: the launch takes the gsum sums in its epilogue (a.gred as the launcher left them).
+// Layers of at most 64 output channels take the 32 x 16-pixel block (map height % 32 == 0); a normalising source only in SHM_NORM_EXACT mode.
 int shm_x3_fwd_eligible(const TapGemmArgs& a, size_t ws_bytes) {
-    return a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0) && a.nout > 64 && a.nt == nullptr && a.ybytes != 0 &&
-           (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0)) && ws_bytes >= (size_t)54 * a.nout * a.K && (size_t)54 * a.nout * a.K < 0xfffffff0u;
+    return a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0) && (a.nout > 64 || a.hi % 32 == 0) && (a.nt == nullptr || (a.ntmode == 0 && a.ntc % 32 == 0)) &&
+           a.ybytes != 0 && (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0)) && ws_bytes >= (size_t)54 * a.nout * a.K &&
+           (size_t)54 * a.nout * a.K < 0xfffffff0u;
+}
+
+template <bool GS, int BN>
+static int x3_launch_t(const TapGemmArgs& a, int batch, unsigned plane_bytes, hipStream_t st, const char* who) {
+    typedef X3Shape<BN> SH;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<GS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS);
+    SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, SH::LDS, hipGetErrorString(attr));
+    const dim3 grid(batch * (a.hi / SH::PH) * (a.wi / 16), shm_cdiv(a.nout, BN), 1);
+    hipLaunchKernelGGL((tapgemm_halo_x3_kernel<GS, BN>), grid, dim3(512), SH::LDS, st, a, plane_bytes);
+    shm_set_last_kernel("tapgemm_halo_x3_kernel<%s, %d>", GS ? "true" : "false", BN);
+    return SHM_OK;
 }
 
 int shm_x3_fwd_launch(const TapGemmArgs& a0, int batch, bool gs_fused, void* ws, hipStream_t st, const char* who) {
@@ -282,14 +335,7 @@ int shm_x3_fwd_launch(const TapGemmArgs& a0, int batch, bool gs_fused, void* ws,
     TapGemmArgs a = a0;
     a.w = ws;
     a.wbytes = (unsigned)(n * 6);
-    const dim3 grid(batch * (a.hi / 16) * (a.wi / 16), shm_cdiv(a.nout, X3_BN), 1);
-    static const hipError_t attr0 = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    static const hipError_t attr1 = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    SHM_REQUIRE(attr0 == hipSuccess && attr1 == hipSuccess, SHM_E_HIP, "%s: cannot reserve 120 KiB of LDS", who);
-    if (gs_fused)
-        hipLaunchKernelGGL((tapgemm_halo_x3_kernel<true>), grid, dim3(512), X3_LDS, st, a, (unsigned)(n * 2));
-    else
-        hipLaunchKernelGGL((tapgemm_halo_x3_kernel<false>), grid, dim3(512), X3_LDS, st, a, (unsigned)(n * 2));
-    shm_set_last_kernel(gs_fused ? "tapgemm_halo_x3_kernel<true>" : "tapgemm_halo_x3_kernel<false>");
-    return SHM_OK;
+    const unsigned pb = (unsigned)(n * 2);
+    if (a.nout > 64) return gs_fused ? x3_launch_t<true, 128>(a, batch, pb, st, who) : x3_launch_t<false, 128>(a, batch, pb, st, who);
+    return gs_fused ? x3_launch_t<true, 64>(a, batch, pb, st, who) : x3_launch_t<false, 64>(a, batch, pb, st, who);
 }

@@ -2442,7 +2442,7 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
         g_x3_ws = nullptr;
         g_x3_bytes = 0;
         if constexpr (sizeof(T) == 4 && sizeof(TO) == 4) {
-            if (x3ws && shm_tune(SHM_TUNE_CONV_F32_SPLIT) == 1 && halo_ok && !want_nm &&
+            if (x3ws && shm_tune(SHM_TUNE_CONV_F32_SPLIT) == 1 && halo_ok && (!want_nm || a.ntmode == 0) &&
                 (v == SHM_TG_HALO128_ST || v == SHM_TG_HALO64_ST || (v == SHM_TG_WREG && forced == SHM_TG_AUTO)) &&
                 (!want_gs || gs_fused) && shm_x3_fwd_eligible(a, x3n))
                 return shm_x3_fwd_launch(a, batch, gs_fused, x3ws, st, who);

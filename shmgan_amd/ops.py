@@ -237,7 +237,7 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
     label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
-    if nt_x is None and nt_x2 is None:
+    if (nt_x is None and nt_x2 is None) or norm_mode == NORM_EXACT:
         _arm_x3(x, y, cout, cin, ksize, stride)
     if nt_x is None and nt_x2 is None and nt_out is None:
         _timed("", flops, lambda: check(

@@ -166,6 +166,8 @@ def _wk(w, cin_p):
     (1, 16, 96, 192, 0),         # three 32-channel chunks; 192 outputs = one full and one half block of 128
     (3, 16, 128, 128, 64),       # Concatenate: two sources of 64 channels
     (1, 48, 32, 256, 0),         # one chunk, two blocks of output channels, nine patches
+    (2, 32, 128, 64, 0),         # 64 output channels: the 32 x 16-pixel block (one patch row of two)
+    (1, 64, 64, 48, 32),         # ... ragged output channels, two sources of 32, four patch rows
 ])
 def test_x3_forward_matches_the_oracle_and_the_exact_kernel(n, h, cin, cout, c1):
     ops = _ops()
@@ -191,7 +193,8 @@ def test_x3_forward_matches_the_oracle_and_the_exact_kernel(n, h, cin, cout, c1)
         assert float(scr.abs().max()) == 0.0
         outs[split] = (y, stats.clone(), k)
     (y3, s3, k3), (y1, s1, k1) = outs[1], outs[0]
-    assert k3 == "tapgemm_halo_x3_kernel<false>" and "x3" not in k1, (k3, k1)
+    x3name = f"tapgemm_halo_x3_kernel<false, {128 if cout > 64 else 64}>"
+    assert k3 == x3name and "x3" not in k1, (k3, k1)
     e3, e1 = rel_l2(host(y3), ref), rel_l2(host(y1), ref)
     print(f"rel-L2 against float64: six bf16 products {e3:.2e}, exact-fp32 MFMA {e1:.2e}")
     assert e3 < TOL and e3 < 4 * e1 + 1e-7
@@ -201,10 +204,10 @@ def test_x3_forward_matches_the_oracle_and_the_exact_kernel(n, h, cin, cout, c1)
     ops.set_tuning("conv.f32_split", 1)
     y4 = torch.empty_like(y3)
     ops.conv2d_fwd(xa, xb, c1, c1 if c1 else cin, cin - c1 if c1 else 0, _wk(w, cin), dev(b), y4, cout, n, h, h, cin, cout, 3, 1, 0.2)
-    assert ops.last_kernel() == "tapgemm_halo_x3_kernel<false>" and torch.equal(y4, y3)
+    assert ops.last_kernel() == x3name and torch.equal(y4, y3)
 
 
-@pytest.mark.parametrize("n,h,cin,cout,n1", [(2, 32, 128, 64, 0), (2, 16, 256, 128, 128), (1, 32, 192, 96, 64)])
+@pytest.mark.parametrize("n,h,cin,cout,n1", [(2, 32, 128, 64, 0), (2, 16, 256, 128, 128), (1, 32, 192, 96, 64), (2, 32, 64, 64, 0), (1, 64, 64, 128, 0)])
 def test_x3_input_gradient_with_gsum(n, h, cin, cout, n1):
     """dx (and the Concatenate split dx / dx2) and the InstanceNorm-backward sums of the gsum epilogue, against the exact-fp32 launch."""
     ops = _ops()
@@ -228,7 +231,7 @@ def test_x3_input_gradient_with_gsum(n, h, cin, cout, n1):
         torch.cuda.synchronize()
         res[split] = (dx, dx2, red0.view(ops.GSUM_SLOTS, -1).sum(0), None if red1 is None else red1.view(ops.GSUM_SLOTS, -1).sum(0), k)
     a, b = res[1], res[0]
-    assert a[4] == "tapgemm_halo_x3_kernel<true>" and "x3" not in b[4], (a[4], b[4])
+    assert a[4] == f"tapgemm_halo_x3_kernel<true, {128 if cin > 64 else 64}>" and "x3" not in b[4], (a[4], b[4])
     assert rel_l2(host(a[0]), host(b[0])) < 2e-6 and rel_l2(host(a[2]), host(b[2])) < 1e-5
     if n1:
         assert rel_l2(host(a[1]), host(b[1])) < 2e-6 and rel_l2(host(a[3]), host(b[3])) < 1e-5
@@ -253,14 +256,58 @@ def test_x3_forward_nan_and_the_one_shot_workspace():
     ops.set_tuning("conv.f32_split", 1)
     ops.set_tuning("tapgemm.variant", "halo128_st")
     ops.conv2d_fwd(x, None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 1.0)
-    assert ops.last_kernel() == "tapgemm_halo_x3_kernel<false>"
+    assert ops.last_kernel() == "tapgemm_halo_x3_kernel<false, 128>"
     bad = ~torch.isfinite(y)
     assert bool(bad[0, 2:5, 4:7].all()) and bool(bad[0, 8:11, 1:4].all())           # every output the two values reach
     assert bool(torch.isfinite(y[0, 13:, 8:]).all())
-    # shapes the kernel does not take run the exact kernels, also right after an armed call
+    # shapes the kernel does not take run the exact kernels, also right after an armed call (64 output channels on a map of 16 rows: no
+    # 32-row patch; 48 input channels: not whole 32-channel chunks)
     y64 = torch.empty((n, h, h, 64), device="cuda")
     ops.conv2d_fwd(x, None, 0, cin, 0, _wk(rng.standard_normal((3, 3, cin, 64)) * 0.1, cin), None, y64, 64, n, h, h, cin, 64, 3, 1, 1.0)
+    assert "x3" not in ops.last_kernel()
+    ops.conv2d_fwd(x[..., :48].contiguous(), None, 0, 48, 0, _wk(rng.standard_normal((3, 3, 48, cout)) * 0.1, 48), None, y, cout, n, h, h, 48, cout, 3, 1, 1.0)
     assert "x3" not in ops.last_kernel()
     ops.set_tuning("conv.f32_split", 0)
     ops.conv2d_fwd(torch.nan_to_num(x, 0.0, 0.0, 0.0), None, 0, cin, 0, wk, None, y, cout, n, h, h, cin, cout, 3, 1, 1.0)
     assert "x3" not in ops.last_kernel() and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("n,h,cin,cout,part", [(2, 32, 64, 64, 0), (2, 16, 128, 128, 0), (1, 32, 128, 128, 1)])
+def test_x3_forward_with_a_normalising_source(n, h, cin, cout, part):
+    """SHM_NORM_EXACT source (the consumer applies the producer's InstanceNorm): the x3 kernel normalises in its stage registers -- against the
+    exact kernel on the same operands and against the two-pass path (shm_in_apply, then the plain product)."""
+    ops = _ops()
+    rng = np.random.default_rng(95 + n)
+    c1 = 0 if part == 0 else cin // 2
+    cn = cin if part == 0 else cin - c1                      # channels of the normalised source
+    a = dev(rng.standard_normal((n, h, h, cn)) * rng.uniform(0.5, 2.0, (n, 1, 1, cn)) + rng.uniform(-1, 1, (n, 1, 1, cn)))
+    other = dev(rng.standard_normal((n, h, h, c1))) if part else None
+    beta = dev(rng.uniform(-0.5, 0.5, cn))
+    stats = torch.zeros(n * cn * 2, dtype=torch.float64, device="cuda")
+    ops.in_stats(a, cn, stats, n, h * h, cn, 1e-6)
+    nt = torch.full((n, 4, cn), 9.0, device="cuda")
+    ops.in_norm_table(stats, beta, nt, n, cn)
+    ahat = torch.empty_like(a)
+    ops.in_apply(a, cn, stats, beta, ahat, cn, n, h * h, cn)
+    wk = _wk(rng.standard_normal((3, 3, cin, cout)) * 0.1, cin)
+    b = dev(rng.standard_normal(cout))
+    ops.set_tuning("tapgemm.variant", "halo128_st" if cout > 64 else "halo64_st")
+
+    def run(split, folded):
+        ops.set_tuning("conv.f32_split", split)
+        y = torch.full((n, h, h, cout), 5.0, device="cuda")
+        st_ = torch.zeros(n * cout * 2, dtype=torch.float64, device="cuda")
+        scr = torch.zeros(ops.STATS_SLOTS * n * cout * 2, dtype=torch.float64, device="cuda")
+        src = a if folded else ahat
+        xa, xb = (src, None) if part == 0 else (other, src)
+        ops.conv2d_in_fwd(xa, xb, c1, c1 if part else cin, cn if part else 0, wk, b, y, cout, n, h, h, cin, cout, 3, 1, 0.2, st_, 1e-6, scratch=scr,
+                          nt_x=nt if (folded and part == 0) else None, nt_x2=nt if (folded and part == 1) else None)
+        k = ops.last_kernel()
+        torch.cuda.synchronize()
+        return y, k
+    y3, k3 = run(1, True)
+    assert k3 == f"tapgemm_halo_x3_kernel<false, {128 if cout > 64 else 64}>", k3
+    y3p, k3p = run(1, False)                                  # the plain x3 product on the normalised tensor: the same values go into the split
+    assert k3p == k3 and torch.equal(y3, y3p)
+    y1, k1 = run(0, True)
+    assert "x3" not in k1 and rel_l2(host(y3), host(y1)) < 2e-6
