@@ -244,6 +244,11 @@ def main():
                 for name, rec in tj.items():
                     if same_symbol(name):
                         traffic = rec["hbm_bytes_per_launch"]
+            # f32x3: a six-product kernel issues six bf16 MFMA FLOPs per algorithmic fp32 FLOP -- priced on the pipe it runs on
+            x3_dom = args.dtype == "f32x3" and "x3" in dom
+            if x3_dom:
+                out_extra_x3 = {"fp32_equivalent_tflops": round(ach, 2), "mfma_flops_per_fp32_flop": 6}
+                ach, peak = ach * 6.0, MFMA_BF16_PEAK_TFLOPS
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -257,6 +262,10 @@ def main():
                 "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
             }
+            if x3_dom:
+                out["roofline"].update(out_extra_x3)
+                out["roofline"]["note"] = ("achieved / peak: bf16 MFMA FLOPs issued (6 per algorithmic fp32 FLOP) against the dense bf16 peak; "
+                                           "kernels[*].tflops and whole_step_conv_tflops stay fp32-equivalent")
             # the HBM-bound side of the step (north star: ">= 70 % of the memory-bandwidth roofline"): the entry point with the most
             # time among the elementwise passes, algorithmic bytes (every tensor read or written once) over its HIP-event time
             bs = timer.bytes_summary()
