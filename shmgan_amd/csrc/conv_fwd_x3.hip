@@ -252,6 +252,29 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         bj[j] = (a.bias && n < a.nout) ? a.bias[n] : 0.f;
         asm volatile("" : "+v"(bj[j]));
     }
+    // gsum: every aux value of the wave's four 32 x 32 tiles first (64 loads per lane in one round trip: one block per CU, nothing else hides the
+    // latency; the fragment and stage registers are dead by now), then the stores
+    [[maybe_unused]] float q[2][2][16];
+    if constexpr (GS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nb = __builtin_amdgcn_readfirstlane(n0 + wn * 64 + j * 32);
+            const int gp = nb < a.n1 ? 0 : 1;
+            const int n = nb + l31;
+            const bool on = a.gred[gp] != nullptr && nb < a.nout;
+            const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
+            const unsigned ldab = (unsigned)a.ldgaux[gp] * 4u, nab = (unsigned)(n < a.nout ? n - (gp ? a.n1 : 0) : 0) * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned ao = (unsigned)((img * a.hi + (y0 + 4 * wm + 2 * i)) * a.wi + x0 + 4 * h) * ldab + nab;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));         // scalar
+                    q[j][i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, cr * ldab, 0));
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         // the 32 columns of a (wave, j) group lie in one output part (n1 % 32 == 0, launcher): part, pitch and descriptors are scalars; a lane's
@@ -263,21 +286,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(gp ? a.y2 : a.y, 0, gp ? a.y2bytes : a.ybytes, 0x00020000);
         const unsigned ldyb = (unsigned)(gp ? a.ldy2 : a.ldy) * 4u, nyb = (unsigned)(n < a.nout ? nl : 0) * 4u;
         [[maybe_unused]] const bool on = GS && a.gred[gp] != nullptr && nb < a.nout;
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.gaux[gp], 0, on ? 0xfffffff0u : 0u, 0x00020000);
-        [[maybe_unused]] const unsigned ldab = (unsigned)a.ldgaux[gp] * 4u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned pix0 = (unsigned)((img * a.hi + (y0 + 4 * wm + 2 * i)) * a.wi + x0 + 4 * h);
             const unsigned yo = pix0 * ldyb + nyb;
-            [[maybe_unused]] float q[16];
-            if constexpr (GS) {
-                const unsigned ao = pix0 * ldab + nyb;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned cr = (unsigned)((r >> 3) * a.wi + 8 * ((r >> 2) & 1) + (r & 3));         // scalar
-                    q[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, ao, cr * ldab, 0));
-                }
-            }
             if (n < a.nout) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
                     const float v = shm_lrelu(acc[i][j][r] + bj[j], a.slope);
                     s1[j] += v;
                     if constexpr (GS)
-                        s2[j] += v * q[r];
+                        s2[j] += v * q[j][i][r];
                     else
                         s2[j] = __builtin_fmaf(v, v, s2[j]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsy, yo, cr * ldyb, 0);
