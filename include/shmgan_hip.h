@@ -79,7 +79,7 @@ const char* shm_last_kernel(void);
  *                               products of the exact three-plane bf16 splits of x and dY with fp32 accumulation (wgrad_halo_x3_kernel; rounds like an
  *                               fp32 dot product, rel-L2 ~1e-7), 0 (default) = exact-fp32 MFMA.  Opt-in: bench.py --dtype f32x3
  *   "conv.f32_split"            fp32 3x3 unit-stride forward / input gradient: 1 = six bf16 MFMA products of exact three-plane splits where
- *                               shm_conv2d_x3_workspace was given and the shape fits (tapgemm_halo_x3_kernel), 0 (default) = exact-fp32 MFMA.  Opt-in
+ *                               the shape fits (tapgemm_halo_x3_kernel), 0 (default) = exact-fp32 MFMA.  Opt-in
  *   "elem.fused_bwd"            bf16 shm_in_bwd: 1 (default) = the one-pass form where shm_in_bwd_fused_scratch was given and the shape fits, 0 = two passes
  *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
  *                               3 at unit stride only, 4 both
@@ -264,14 +264,12 @@ int shm_in_bwd_keep_dz_sums(double* dst);
      (size_t)(batch) * ((size_t)(c) / SHM_IN_BWD_FUSED_CB(c)) * 288 + 1)
 int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles);
 
-/* Opt-in fp32 arithmetic from bf16 MFMAs for the 3x3 unit-stride forward / input-gradient layers (round 5, tuning "conv.f32_split" = 1,
- * csrc/conv_fwd_x3.hip; the weight gradient's twin is "wgrad.f32_split"): every fp32 operand is split EXACTLY into three bf16 planes and the six
- * plane products with i + j <= 2 accumulate in fp32 -- the result rounds like an fp32 dot product (rel-L2 ~1e-7 against float64).  The NEXT
- * shm_conv2d_fwd / shm_conv2d_in_fwd / shm_conv2d_dgrad (and their _gsum forms) call of this thread may use `ws` (>= 54 * nout * K bytes: the bf16
- * planes of its weights) and run tapgemm_halo_x3_kernel when the launcher would have taken a static-tap halo kernel for it: fp32 tensors, more
- * than 64 output channels, K % 32 == 0, no normalise-on-load source, outputs below 4 GiB.  One-shot (consumed by the next launch, taken or
- * not; NULL disarms); every other call runs the exact-fp32 kernels. */
-int shm_conv2d_x3_workspace(void* ws, size_t bytes);
+/* Opt-in fp32 arithmetic from bf16 MFMAs for the 3x3 unit-stride forward / input-gradient layers: tuning "conv.f32_split" = 1 (round 5,
+ * csrc/conv_fwd_x3.hip; the weight gradient's twin is "wgrad.f32_split").  Every fp32 operand is split EXACTLY into three bf16 planes and the six
+ * plane products with i + j <= 2 accumulate in fp32 -- the result rounds like an fp32 dot product (rel-L2 ~4e-7 against float64, the exact-fp32
+ * MFMA's own figure).  shm_conv2d_fwd / shm_conv2d_in_fwd(_norm, SHM_NORM_EXACT) / shm_conv2d_dgrad and their _gsum forms then run
+ * tapgemm_halo_x3_kernel where the launcher would have taken a static-tap halo or weights-in-registers kernel: fp32 tensors, K % 32 == 0, outputs
+ * below 4 GiB, more than 64 output channels or a map height that is a multiple of 32.  Nothing else changes: no extra arguments, no workspace. */
 /* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers
  * normalise a on the fly, only the pool's consumer needs a tensor.  Same bits as shm_in_apply_pool's `pooled`. */
 int shm_in_pool(const void* a, int lda, const double* stats, const float* beta, void* pooled, int ldp, int batch, int h, int w,

@@ -47,7 +47,7 @@ enum ShmTune {
     SHM_TUNE_TAPGEMM_FLAT_EPILOGUE,   // 1 = treat the outputs as larger than 4 GiB (tests: the 64-bit-address epilogues and the kernels that do not need buffer stores)
     SHM_TUNE_ELEM_FUSED_BWD,          // 1 = bf16 InstanceNorm backward in one pass where eligible and shm_in_bwd_fused_scratch was given (in_bwd_fused8_kernel), 0 = two passes
     SHM_TUNE_ELEM_FUSED_MAX_SLICES,   // in_bwd_fused8_kernel: most slices (= blocks) per sample; a sample's blocks must be resident together (1024 fit an idle chip)
-    SHM_TUNE_CONV_F32_SPLIT,          // fp32 3x3 unit-stride forward / input-gradient layers (> 64 output channels): 1 = six bf16 MFMA products of exact three-plane splits (conv_fwd_x3.hip; needs shm_conv2d_x3_workspace), 0 = exact-fp32 MFMA (default)
+    SHM_TUNE_CONV_F32_SPLIT,          // fp32 3x3 unit-stride forward / input-gradient layers (> 64 output channels): 1 = six bf16 MFMA products of exact three-plane splits (conv_fwd_x3.hip), 0 = exact-fp32 MFMA (default)
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);

@@ -14,8 +14,9 @@
 //   A: the halo chunk comes from HBM as fp32 into REGISTERS (three items of 16 halo rows per wave, two 16-byte loads per lane and item), is
 //      split (4 VALU per value + 1.5 to pack) and written as three plane images; ONE LDS stage -- the next chunk's loads are in flight in
 //      registers during this chunk's nine taps;
-//   B: the weight planes are made once per launch by x3_split_weights_kernel (bf16 [3][taps][nout][K], a few hundred KB) and travel per tap
-//      through registers into one of two LDS stages, one tap ahead.
+//   B: the tap's weight slice (BN rows x 32 channels, fp32) travels through registers one tap ahead, is split there and written as three planes
+//      into one of two LDS stages (a plane tensor made by a kernel of its own in front of every launch cost a launch, a workspace argument and
+//      0.4 ms per step; splitting 8 values per lane and tap costs ~45 VALU beside 48 MFMAs).
 // Per (tap, 16-channel K step) a wave reads 2 x 3 A and 2 x 3 B fragments and issues 24 MFMAs (x2 w0, x1 w1, x0 w2, x1 w0, x0 w1, x0 w0: the
 // small products first).  One barrier per tap, one more per chunk.  LDS: 3 x 24 KiB + 2 x 3 x 8 KiB = 120 KiB, one block per CU.
 // Epilogues as tapgemm_halo_kernel's for fp32 outputs: bias + LeakyReLU + element stores through buffer descriptors, InstanceNorm statistics,
@@ -38,26 +39,10 @@ struct X3Shape {
     static constexpr unsigned LDS = (3u * ASTG + 6u * BSTG) * 4u;       // 120 KiB / 141 KiB: one block per CU
 };
 
-__global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, size_t n) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (i >= n) return;
-    const float a = w[i], b = i + 1 < n ? w[i + 1] : 0.f;
-    unsigned p0, p1, p2;
-    x3_split_pair(a, b, p0, p1, p2);
-    if (i + 1 < n) {
-        *(unsigned*)(planes + i) = p0;
-        *(unsigned*)(planes + n + i) = p1;
-        *(unsigned*)(planes + 2 * n + i) = p2;
-    } else {
-        planes[i] = (unsigned short)p0;
-        planes[n + i] = (unsigned short)p1;
-        planes[2 * n + i] = (unsigned short)p2;
-    }
-}
 }  // namespace
 
 template <bool GS, int BN>
-__global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmArgs a, const unsigned plane_bytes) {
+__global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmArgs a) {
     typedef X3Shape<BN> SH;
     constexpr int HC = SH::HC, NW = SH::NW, NA = SH::NA, NIT = SH::NIT, ASTG = SH::ASTG, BSTG = SH::BSTG, PH = SH::PH, WGN = SH::WGN, WGM = SH::WGM;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -102,15 +87,14 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     // B item of wave w (< BN / 16) = weight rows [16 w, 16 w + 16) of the block's BN: LDS chunk dq of row r holds source chunk dq ^ ((r >> 2) & 3)
     const int brow = wave * 16 + drow;
     const bool bwave = wave < SH::NBI;             // wave-uniform
-    const unsigned wrow = n0 + brow < a.nout ? (unsigned)((n0 + brow) * a.K + (dq ^ ((brow >> 2) & 3)) * 8) * 2u : 0xffffffffu;
+    const unsigned wrow = n0 + brow < a.nout ? (unsigned)((n0 + brow) * a.K + (dq ^ ((brow >> 2) & 3)) * 8) * 4u : 0xffffffffu;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
     const int nch = a.K >> 5;
 
     // stage registers
-    f32x4 ar[NA][2];
-    u32x4 br[3];
+    f32x4 ar[NA][2], br[2];
     // normalise-on-load (TapGemmArgs::nt, SHM_NORM_EXACT): source a.ntpart is the UN-normalised activation of an InstanceNorm block; shm_in_norm
     // on the in-image values of the stage registers before the split (padding stays zero), the (mean, inv, beta) rows of the block's sample
     // straight from the table (L2): 6 x 16 bytes per lane, item and chunk
@@ -162,17 +146,26 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     };
     auto load_b = [&](int t_wi, int chunk) {
         if (!bwave) return;
-        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (chunk << 5)) * 2u;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase + (unsigned)p * plane_bytes;
-            br[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
-        }
+        const unsigned wbase = (unsigned)((t_wi * a.nout) * a.K + (chunk << 5)) * 4u;
+        const unsigned off = wrow == 0xffffffffu ? wrow : wrow + wbase;
+        br[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+        br[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wrow == 0xffffffffu ? wrow : off + 16u, 0, 0));
     };
     auto spill_b = [&](int stage) {
         if (!bwave) return;
+        u32x4 p0, p1, p2;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *(u32x4*)(sB + (stage * 3 + p) * BSTG + wave * 256 + lane * 4) = br[p];
+        for (int e = 0; e < 4; ++e) {
+            unsigned q0, q1, q2;
+            x3_split_pair(br[e >> 1][2 * (e & 1)], br[e >> 1][2 * (e & 1) + 1], q0, q1, q2);
+            p0[e] = q0;
+            p1[e] = q1;
+            p2[e] = q2;
+        }
+        float* dst = sB + stage * 3 * BSTG + wave * 256 + lane * 4;
+        *(u32x4*)dst = p0;
+        *(u32x4*)(dst + BSTG) = p1;
+        *(u32x4*)(dst + 2 * BSTG) = p2;
     };
 
     f32x16 acc[2][2];
@@ -322,32 +315,25 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     }
 }
 
-// ws: bf16 [3][9 nout K] (ws_bytes >= 54 nout K).  gs_fused: the launch takes the gsum sums in its epilogue (a.gred as the launcher left them).
-// Layers of at most 64 output channels take the 32 x 16-pixel block (map height % 32 == 0); a normalising source only in SHM_NORM_EXACT mode.
-int shm_x3_fwd_eligible(const TapGemmArgs& a, size_t ws_bytes) {
+// gs_fused: the launch takes the gsum sums in its epilogue (a.gred as the launcher left them).  Layers of at most 64 output channels take the
+// 32 x 16-pixel block (map height % 32 == 0); a normalising source only in SHM_NORM_EXACT mode.
+int shm_x3_fwd_eligible(const TapGemmArgs& a) {
     return a.K % 32 == 0 && (a.x2 == nullptr || a.c1 % 32 == 0) && (a.nout > 64 || a.hi % 32 == 0) && (a.nt == nullptr || (a.ntmode == 0 && a.ntc % 32 == 0)) &&
-           a.ybytes != 0 && (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0)) && ws_bytes >= (size_t)54 * a.nout * a.K &&
-           (size_t)54 * a.nout * a.K < 0xfffffff0u;
+           a.ybytes != 0 && (a.y2 == nullptr || (a.y2bytes != 0 && a.n1 % 32 == 0));
 }
 
 template <bool GS, int BN>
-static int x3_launch_t(const TapGemmArgs& a, int batch, unsigned plane_bytes, hipStream_t st, const char* who) {
+static int x3_launch_t(const TapGemmArgs& a, int batch, hipStream_t st, const char* who) {
     typedef X3Shape<BN> SH;
     static const hipError_t attr = hipFuncSetAttribute((const void*)tapgemm_halo_x3_kernel<GS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS);
     SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "%s: cannot reserve %u bytes of LDS: %s", who, SH::LDS, hipGetErrorString(attr));
     const dim3 grid(batch * (a.hi / SH::PH) * (a.wi / 16), shm_cdiv(a.nout, BN), 1);
-    hipLaunchKernelGGL((tapgemm_halo_x3_kernel<GS, BN>), grid, dim3(512), SH::LDS, st, a, plane_bytes);
+    hipLaunchKernelGGL((tapgemm_halo_x3_kernel<GS, BN>), grid, dim3(512), SH::LDS, st, a);
     shm_set_last_kernel("tapgemm_halo_x3_kernel<%s, %d>", GS ? "true" : "false", BN);
     return SHM_OK;
 }
 
-int shm_x3_fwd_launch(const TapGemmArgs& a0, int batch, bool gs_fused, void* ws, hipStream_t st, const char* who) {
-    const size_t n = (size_t)9 * a0.nout * a0.K;
-    hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)shm_cdiv((long)((n + 1) / 2), 256)), dim3(256), 0, st, (const float*)a0.w, (unsigned short*)ws, n);
-    TapGemmArgs a = a0;
-    a.w = ws;
-    a.wbytes = (unsigned)(n * 6);
-    const unsigned pb = (unsigned)(n * 2);
-    if (a.nout > 64) return gs_fused ? x3_launch_t<true, 128>(a, batch, pb, st, who) : x3_launch_t<false, 128>(a, batch, pb, st, who);
-    return gs_fused ? x3_launch_t<true, 64>(a, batch, pb, st, who) : x3_launch_t<false, 64>(a, batch, pb, st, who);
+int shm_x3_fwd_launch(const TapGemmArgs& a, int batch, bool gs_fused, hipStream_t st, const char* who) {
+    if (a.nout > 64) return gs_fused ? x3_launch_t<true, 128>(a, batch, st, who) : x3_launch_t<false, 128>(a, batch, st, who);
+    return gs_fused ? x3_launch_t<true, 64>(a, batch, st, who) : x3_launch_t<false, 64>(a, batch, st, who);
 }

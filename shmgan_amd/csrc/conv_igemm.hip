@@ -2246,15 +2246,6 @@ __global__ __launch_bounds__(512, 2) void tapgemm_phase4_kernel(const TapGemmArg
 }
 
 static thread_local double* g_conv_stats = nullptr;     // set by shm_conv2d_in_fwd around its conv launch
-// "conv.f32_split": workspace for the bf16 weight planes of the NEXT convolution launch of this thread (bf16 [3][taps][nout][K] = 54 nout K
-// bytes for a 3x3 layer); one-shot, consumed (and disarmed) by whichever tap-GEMM launch comes next, taken or not
-static thread_local void* g_x3_ws = nullptr;
-static thread_local size_t g_x3_bytes = 0;
-extern "C" int shm_conv2d_x3_workspace(void* ws, size_t bytes) {
-    g_x3_ws = ws;
-    g_x3_bytes = ws ? bytes : 0;
-    return SHM_OK;
-}
 static thread_local int g_conv_hw = 0, g_conv_slots = 1;
 
 // gsum request of the *_gsum entry points around their launch, and whether the kernel that ran took it (otherwise the entry
@@ -2434,19 +2425,11 @@ static int launch_tapgemm_t(const TapGemmArgs& a_in, int batch, int nphase, hipS
     }
     auto grid1d = [&](int bm, int bn) { return dim3(shm_cdiv(a.M, bm), shm_cdiv(a.nout, bn), nphase); };
     const int npatch = batch * (a.hi / 16) * (a.wi / 16);
-    // "conv.f32_split" (opt-in): the fp32 static-tap halo layers as six bf16 MFMA products (conv_fwd_x3.hip); the caller armed a workspace for
-    // the weight planes (shm_conv2d_x3_workspace, one-shot)
-    {
-        void* const x3ws = g_x3_ws;
-        const size_t x3n = g_x3_bytes;
-        g_x3_ws = nullptr;
-        g_x3_bytes = 0;
-        if constexpr (sizeof(T) == 4 && sizeof(TO) == 4) {
-            if (x3ws && shm_tune(SHM_TUNE_CONV_F32_SPLIT) == 1 && halo_ok && (!want_nm || a.ntmode == 0) &&
-                (v == SHM_TG_HALO128_ST || v == SHM_TG_HALO64_ST || (v == SHM_TG_WREG && forced == SHM_TG_AUTO)) &&
-                (!want_gs || gs_fused) && shm_x3_fwd_eligible(a, x3n))
-                return shm_x3_fwd_launch(a, batch, gs_fused, x3ws, st, who);
-        }
+    // "conv.f32_split" (opt-in): the fp32 static-tap halo layers (and the weights-in-registers layers) as six bf16 MFMA products (conv_fwd_x3.hip)
+    if constexpr (sizeof(T) == 4 && sizeof(TO) == 4) {
+        if (shm_tune(SHM_TUNE_CONV_F32_SPLIT) == 1 && halo_ok && (!want_nm || a.ntmode == 0) &&
+            (v == SHM_TG_HALO128_ST || v == SHM_TG_HALO64_ST || (v == SHM_TG_WREG && forced == SHM_TG_AUTO)) && (!want_gs || gs_fused) && shm_x3_fwd_eligible(a))
+            return shm_x3_fwd_launch(a, batch, gs_fused, st, who);
     }
     switch (v) {
     case SHM_TG_HALO128:

@@ -64,9 +64,9 @@ struct TapGemmArgs {            // x, x2, w, y, y2 are float or bf16 tensors (ke
 int shm_wreg16_launch(const TapGemmArgs& a, int np8, int ncu, hipStream_t st, const char* who);
 
 // conv_fwd_x3.hip ("conv.f32_split"): fp32 unit-stride 3x3 layers of more than 64 output channels as six bf16 MFMA products of exact three-plane
-// splits; the caller (launch_tapgemm_t) has chosen a static-tap halo variant and decided whether the gsum sums are fused.  ws: bf16 [3][9 nout K]
-int shm_x3_fwd_eligible(const TapGemmArgs& a, size_t ws_bytes);
-int shm_x3_fwd_launch(const TapGemmArgs& a, int batch, bool gs_fused, void* ws, hipStream_t st, const char* who);
+// splits; the caller (launch_tapgemm_t) has chosen a static-tap halo variant and decided whether the gsum sums are fused
+int shm_x3_fwd_eligible(const TapGemmArgs& a);
+int shm_x3_fwd_launch(const TapGemmArgs& a, int batch, bool gs_fused, hipStream_t st, const char* who);
 
 // conv_pingpong.hip: the K = 64 layers as a one-block-per-CU ping-pong kernel (two wave groups alternating between the MFMA segment and the
 // load / epilogue / store segment); shm_pp_eligible checks the shape, the caller that no gsum / norm form is wanted.

@@ -128,36 +128,6 @@ def set_tuning(key, value):
     if isinstance(value, str):
         value = TAPGEMM_VARIANTS[value]
     check(lib().shm_set_tuning(key.encode(), int(value)), "shm_set_tuning")
-    global _X3_ON
-    if key == "conv.f32_split":
-        _X3_ON = bool(value)
-    elif key == "reset":
-        _X3_ON = get_tuning("conv.f32_split") == 1
-
-
-# "conv.f32_split" (opt-in: fp32 3x3 unit-stride forward / input-gradient layers as six bf16 MFMA products, csrc/conv_fwd_x3.hip): the kernel
-# needs room for the bf16 planes of the launch's weights (54 nout K bytes).  One buffer per (device, stream, size): launches of one stream are
-# ordered, so the layers of a stream share it.
-_X3_ON = None
-_X3_POOL = {}
-
-
-def x3_release():
-    _X3_POOL.clear()
-
-
-def _arm_x3(x, y, nout, k, ksize, stride):
-    global _X3_ON
-    if _X3_ON is None:
-        _X3_ON = get_tuning("conv.f32_split") == 1
-    if not _X3_ON or ksize != 3 or stride != 1 or x.dtype != torch.float32 or y.dtype != torch.float32:
-        return
-    nbytes = 54 * nout * k
-    key = (x.device, _stream(), nbytes)
-    ws = _X3_POOL.get(key)
-    if ws is None:
-        ws = _X3_POOL[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(lib().shm_conv2d_x3_workspace(_p(ws), nbytes), "shm_conv2d_x3_workspace")
 
 
 def get_tuning(key):
@@ -209,7 +179,6 @@ def conv2d_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, cout,
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
     label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
-    _arm_x3(x, y, cout, cin, ksize, stride)
     if gsum is None:
         _timed("", flops, lambda: check(
             lib().shm_conv2d_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
@@ -237,8 +206,6 @@ def conv2d_in_fwd(x, x2, c1, ldx, ldx2, wk, bias, y, ldy, batch, hi, wi, cin, co
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * (cin_real or cin) * cout
     label = f"fwd n{batch} h{hi} {cin}->{cout} k{ksize} s{stride}"
-    if (nt_x is None and nt_x2 is None) or norm_mode == NORM_EXACT:
-        _arm_x3(x, y, cout, cin, ksize, stride)
     if nt_x is None and nt_x2 is None and nt_out is None:
         _timed("", flops, lambda: check(
             lib().shm_conv2d_in_fwd(_p(x), _p(x2), c1, ldx, ldx2, _p(wk), _p(bias), _p(y), ldy, batch, hi, wi,
@@ -308,7 +275,6 @@ def conv2d_dgrad(dy, lddy, w, dx, dx2, n1, lddx, lddx2, batch, hi, wi, cin, cout
     ho, wo = -(-hi // stride), -(-wi // stride)
     flops = 2.0 * batch * ho * wo * ksize * ksize * cin * cout
     label = f"dgrad n{batch} h{hi} {cin}<-{cout} k{ksize} s{stride}"
-    _arm_x3(dy, dx, cin, cout, ksize, stride)
     if gsum is None and gsum2 is None:
         _timed("", flops, lambda: check(
             lib().shm_conv2d_dgrad(_p(dy), lddy, _p(w), _p(dx), _p(dx2), n1, lddx, lddx2, batch, hi, wi, cin,

@@ -154,7 +154,6 @@ class ShmGANwithSSpecSeg:
             self._lane.join()
         torch.cuda.synchronize(self.device)
         self.arena.t.clear()
-        ops.x3_release()
         self._ws = self._prefetched = self._loss_cache = None
         self.G = self.D = self.SpecSeg = None
         self.specular_candidate = None

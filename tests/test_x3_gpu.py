@@ -244,7 +244,7 @@ def test_x3_input_gradient_with_gsum(n, h, cin, cout, n1):
     assert rel_l2(got, ref) < TOL
 
 
-def test_x3_forward_nan_and_the_one_shot_workspace():
+def test_x3_forward_nan_and_fallbacks():
     ops = _ops()
     rng = np.random.default_rng(90)
     n, h, cin, cout = 1, 16, 64, 128
@@ -260,7 +260,7 @@ def test_x3_forward_nan_and_the_one_shot_workspace():
     bad = ~torch.isfinite(y)
     assert bool(bad[0, 2:5, 4:7].all()) and bool(bad[0, 8:11, 1:4].all())           # every output the two values reach
     assert bool(torch.isfinite(y[0, 13:, 8:]).all())
-    # shapes the kernel does not take run the exact kernels, also right after an armed call (64 output channels on a map of 16 rows: no
+    # shapes the kernel does not take run the exact kernels (64 output channels on a map of 16 rows: no
     # 32-row patch; 48 input channels: not whole 32-channel chunks)
     y64 = torch.empty((n, h, h, 64), device="cuda")
     ops.conv2d_fwd(x, None, 0, cin, 0, _wk(rng.standard_normal((3, 3, cin, 64)) * 0.1, cin), None, y64, 64, n, h, h, cin, 64, 3, 1, 1.0)
