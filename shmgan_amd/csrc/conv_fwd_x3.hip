@@ -93,8 +93,9 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
     const int nch = a.K >> 5;
 
-    // stage registers
+    // stage registers.  Item wave + 8 j of the halo exists for every wave when NIT is a multiple of 8 (24); with 39 items wave 7 has no fifth one
     f32x4 ar[NA][2], br[2];
+    auto item_exists = [&](int j) { return NA * NW <= NIT || j < NA - 1 || wave + NW * j < NIT; };
     // normalise-on-load (TapGemmArgs::nt, SHM_NORM_EXACT): source a.ntpart is the UN-normalised activation of an InstanceNorm block; shm_in_norm
     // on the in-image values of the stage registers before the split (padding stays zero), the (mean, inv, beta) rows of the block's sample
     // straight from the table (L2): 6 x 16 bytes per lane, item and chunk
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
         ncs = (ntb && (int)second == a.ntpart) ? (second ? c0 - a.c1 : c0) : -1;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            if ((NA - 1) * NW + NW <= NIT || j < NA - 1 || wave + NW * j < NIT) {
+            if (item_exists(j)) {
                 const unsigned r = second ? arow2[j] : arow1[j];
                 const unsigned off = r == 0xffffffffu ? r : r + cb;
                 const unsigned off2 = r == 0xffffffffu ? r : r + cb + 16u;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_halo_x3_kernel(const TapGemmAr
     auto spill_a = [&]() {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            if (!((NA - 1) * NW + NW <= NIT || j < NA - 1 || wave + NW * j < NIT)) continue;
+            if (!item_exists(j)) continue;
             if (ncs >= 0 && ((inimg >> j) & 1u)) {
                 const float* t = ntb + ncs + 8 * ((coffs >> (2 * j)) & 3u);
 #pragma unroll
