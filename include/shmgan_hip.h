@@ -84,7 +84,10 @@ const char* shm_last_kernel(void);
  *   "wgrad.bf16_wide"           bf16 weight gradient, the eight-wave 64 ci x 128 co block (cout >= 128): 0 automatic (= 2), 1 never, 2 at stride 2 only,
  *                               3 at unit stride only, 4 both
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
- *   "elem.fused_max_slices"     the one-pass form: most slices (= blocks that must be resident together) per barrier group, default 256, at most 512
+ *   "elem.fused_max_slices"     the one-pass form: most slices (= blocks that must be resident together) per barrier group, default 256, at most 512; the launcher also
+ *                               requires twice the group's blocks to fit the device (shm_set_abort_words below)
+ *   "elem.fused_test_stall"     tests only: 1 = the one-pass form's barriers wait for one block more than the grid has, i.e. every barrier
+ *                               times out (~1 s per resident generation of blocks) and the abort words are set; default 0
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
  *                               producer just wrote is still in the Infinity Cache), 0 front to back
  *   "elem.reduce_blocks"        block target of the InstanceNorm-backward reduce pass, 0 automatic (1024 fp32 / 512 bf16: every block ends
@@ -263,6 +266,15 @@ int shm_in_bwd_keep_dz_sums(double* dst);
     (((size_t)(batch) * ((size_t)(hw) * SHM_IN_BWD_FUSED_CB(c) / 16384) * 3 * (size_t)(c) + 1) / 2 + (size_t)(batch) * (size_t)(c) + \
      (size_t)(batch) * ((size_t)(c) / SHM_IN_BWD_FUSED_CB(c)) * 288 + 1)
 int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles);
+/* The one-pass form's barrier needs every block of a group resident at once.  The launcher takes it only when TWICE the group's blocks fit the
+ * current device (its CU count x hipOccupancyMaxActiveBlocksPerMultiprocessor of the kernel, queried once: a partitioned or smaller part falls
+ * back to the two passes), and a barrier that still waits ~1 s gives up instead of hanging: the launch then completes with wrong means, sets the
+ * last u32 of `scratch` and the caller's ABORT WORDS:
+ *   dev_word   u32 in device memory, OR-ed to non-zero.  shm_adam_clip reads it ON THE DEVICE and applies nothing while it is set: gradients
+ *              built on unfinished sums never reach the weights, however far the host has run ahead of the stream;
+ *   host_word  u32 in mapped (pinned) host memory, set to 1: the host sees it without synchronising.
+ * Both stay set until the caller clears them; NULLs disarm.  Persistent per calling thread (configuration, like the tuning table). */
+int shm_set_abort_words(unsigned* dev_word, unsigned* host_word);
 
 /* Opt-in fp32 arithmetic from bf16 MFMAs for the 3x3 unit-stride forward / input-gradient layers: tuning "conv.f32_split" = 1 (round 5,
  * csrc/conv_fwd_x3.hip; the weight gradient's twin is "wgrad.f32_split").  Every fp32 operand is split EXACTLY into three bf16 planes and the six
@@ -515,7 +527,8 @@ int shm_resize_bilinear_u8(const unsigned char* src, int hin, int win, int c, fl
 /* ---- optimizer (SHM.py:169-175, 859-872) ------------------------------------------
  * tf.clip_by_value(g,-1,1) + Keras adam_v2.Adam: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
  * w -= alpha * m / (sqrt(v) + eps); alpha = lr_t*sqrt(1-b2^t)/(1-b1^t) computed by the caller.
- * gscale multiplies g before the clip (1/world_size for data parallel). */
+ * gscale multiplies g before the clip (1/world_size for data parallel).  With shm_set_abort_words armed on this thread the
+ * kernel checks the device word first and leaves w, m, v untouched while it is non-zero. */
 int shm_adam_clip(float* w, float* m, float* v, const float* g, size_t n, float alpha, float beta1,
                   float beta2, float eps, float gscale, void* stream);
 

@@ -376,7 +376,9 @@ extern "C" int shm_dhead_losses(const float* rf, const float* cls, double* loss,
 
 // ------------------------------------------------------------------------- clip + Adam
 __global__ void adam_clip_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g, size_t n,
-                                 float alpha, float b1, float b2, float eps, float gscale) {
+                                 float alpha, float b1, float b2, float eps, float gscale, const unsigned* __restrict__ abort_word) {
+    // a kernel of this step gave up (shm_set_abort_words): its gradients are built on unfinished sums -- apply nothing
+    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -391,7 +393,8 @@ __global__ void adam_clip_kernel(float* __restrict__ w, float* __restrict__ m, f
 
 extern "C" int shm_adam_clip(float* w, float* m, float* v, const float* g, size_t n, float alpha, float beta1, float beta2, float eps, float gscale, void* stream) {
     if (n == 0) return SHM_OK;
-    hipLaunchKernelGGL(adam_clip_kernel, dim3(grid1d(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n, alpha, beta1, beta2, eps, gscale);
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(grid1d(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n, alpha, beta1, beta2, eps, gscale,
+                       shm_abort_dev_word());
     SHM_LAUNCH_CHECK("shm_adam_clip");
     return SHM_OK;
 }

@@ -48,9 +48,11 @@ enum ShmTune {
     SHM_TUNE_ELEM_FUSED_BWD,          // 1 = bf16 InstanceNorm backward in one pass where eligible and shm_in_bwd_fused_scratch was given (in_bwd_fused8_kernel), 0 = two passes
     SHM_TUNE_ELEM_FUSED_MAX_SLICES,   // in_bwd_fused8_kernel: most slices (= blocks) per sample; a sample's blocks must be resident together (1024 fit an idle chip)
     SHM_TUNE_CONV_F32_SPLIT,          // fp32 3x3 unit-stride forward / input-gradient layers (> 64 output channels): 1 = six bf16 MFMA products of exact three-plane splits (conv_fwd_x3.hip), 0 = exact-fp32 MFMA (default)
+    SHM_TUNE_ELEM_FUSED_TEST_STALL,   // tests only: 1 = in_bwd_fused8_kernel's barriers wait for one block more than the grid has (the timeout path)
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);
+const unsigned* shm_abort_dev_word();       // this thread's shm_set_abort_words device word (norm_elem.hip), or null
 
 // Barrier of the LDS-DMA pipelines.  A stage is refilled by DMA instructions issued AFTER the barrier that follows its last use, so a
 // wave must not enter that barrier with fragment reads of the stage still queued: the MFMAs that consume them are register-only
@@ -75,8 +77,15 @@ __device__ __forceinline__ shm_u32x4 shm_rsrc_words(const void* p, unsigned byte
     const unsigned long long a = (unsigned long long)p;
     return shm_u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
 }
+// m0 is written behind the compiler's back and hipcc refuses "m0" as a clobber ("reserved register ... may not be preserved", -Winline-asm): the
+// asm saves and restores it, so a compiler-issued m0 consumer in the same kernel (an LDS-DMA builtin whose m0 hipcc set earlier, movrel, sendmsg)
+// still finds its value (round-5 advisor).  Two scalar moves per DMA, in the shadow of the MFMAs.
 __device__ __forceinline__ void shm_dma16(const shm_u32x4 rs, const unsigned lds_addr, const unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rs)
+                 : "memory");
 }
 __device__ __forceinline__ unsigned shm_lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;

@@ -62,6 +62,7 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.fused_bwd", "SHM_ELEM_FUSED_BWD", 1, 0, 1},
     {"elem.fused_max_slices", "SHM_ELEM_FUSED_MAX_SLICES", 256, 1, 512},
     {"conv.f32_split", "SHM_CONV_F32_SPLIT", 0, 0, 1},
+    {"elem.fused_test_stall", "SHM_ELEM_FUSED_TEST_STALL", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -871,7 +872,10 @@ __device__ __forceinline__ void coh_store(V* p, V v) { __hip_atomic_store(p, v, 
 
 template <bool G2>
 __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
-                                                                         unsigned* __restrict__ fsync, unsigned* __restrict__ ferr) {
+                                                                         unsigned* __restrict__ fsync, unsigned* __restrict__ ferr,
+                                                                         unsigned* __restrict__ abort_dev, unsigned* __restrict__ abort_host,
+                                                                         const unsigned arrivals) {
+    // arrivals: blocks a group's barrier waits for = gridDim.x (one more under "elem.fused_test_stall": the timeout path under test)
     constexpr int U = 8;
     __shared__ double red[256 * 8];
     __shared__ float sm12[128], smi[128];
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const In
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FSTAMP(2);
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == arrivals;
     __syncthreads();
     FSTAMP(3);
     if (s_last) {
@@ -1062,8 +1066,13 @@ __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const In
             int spins = 0;
             while (coh_load(flag) == 0u) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 20)) {
+                if (++spins > (arrivals == gridDim.x ? 1 << 20 : 1 << 10)) {          // (the stalled test form gives up after ~1 ms)
+                    // gave up: this launch goes on with wrong means.  The scratch's own word names the buffer; the caller's abort words
+                    // (shm_set_abort_words) make it fatal: shm_adam_clip applies nothing while the device word is set, and the host word
+                    // (mapped host memory) lets the trainer see it without a synchronisation
                     __hip_atomic_fetch_or(ferr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (abort_dev) __hip_atomic_fetch_or(abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (abort_host) __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -1256,6 +1265,42 @@ extern "C" int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles) {
     return SHM_OK;
 }
 
+// shm_set_abort_words: where a kernel that had to give up (today: a barrier of in_bwd_fused8_kernel that timed out) says so for THIS thread's
+// later calls.  dev_word: u32 in device memory, OR-ed to non-zero; shm_adam_clip reads it on the device and applies NOTHING while it is set, so a
+// gradient built on unfinished sums never reaches the weights, however far the host has run ahead.  host_word: u32 in mapped (pinned) host
+// memory, set to 1 by the same kernel: the caller polls it without a device synchronisation.  Both stay set until the caller clears them.
+// NULLs disarm.  Persistent per thread (like the tuning table this is configuration, not data-path state).
+static thread_local unsigned* g_abort_dev = nullptr;
+static thread_local unsigned* g_abort_host = nullptr;
+extern "C" int shm_set_abort_words(unsigned* dev_word, unsigned* host_word) {
+    g_abort_dev = dev_word;
+    g_abort_host = host_word;
+    return SHM_OK;
+}
+const unsigned* shm_abort_dev_word() { return g_abort_dev; }
+
+// Blocks of in_bwd_fused8_kernel<G2> the current device holds at once (CUs x occupancy; queried once per device and form).  The kernel's
+// barrier only completes if a whole group is resident, and two such launches may run side by side (two streams), each stuck with LESS than a
+// group resident only while free slots remain -- so a group is limited to HALF of this figure (advisor, round 5: a CPX partition, a CU mask or a
+// smaller part holds far fewer than the 1024 / 768 blocks of a whole MI355X, and the launcher used to assume them).  0 if the query fails.
+static int fused_resident_blocks(bool g2) {
+    static int cache[16][2];                 // 0 = not asked yet, -1 = the query failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    int v = __atomic_load_n(&cache[dev][g2], __ATOMIC_RELAXED);
+    if (v == 0) {
+        int cus = 0, per_cu = 0;
+        hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess)
+            e = g2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<true>, 256, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<false>, 256, 0);
+        if (e != hipSuccess) (void)hipGetLastError();
+        v = (e == hipSuccess && cus > 0 && per_cu > 0) ? cus * per_cu : -1;
+        __atomic_store_n(&cache[dev][g2], v, __ATOMIC_RELAXED);
+    }
+    return v > 0 ? v : 0;
+}
+
 static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2, int ldg2, const float* r1_dz, const float* r1_w, const void* a, int lda,
                        const double* stats, double* red, void* dz, int lddz, double* dbias, int batch, int h, int w, int c, float slope, int dtype,
                        void* stream) {
@@ -1295,14 +1340,15 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         const bool g2_tiles = cb == 64 && wt >= 2 && (wt & (wt - 1)) == 0 && w % wt == 0 && 256 % wt == 0 && (256 / wt) % 2 == 0 && h % (256 / wt) == 0;
         if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && cb_ok && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && lddz % 8 == 0 &&
             (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES) && batch <= 65535 && (!g2 || g2_tiles) &&
-            fscr_n >= fused_scratch_doubles(batch, hw, c)) {
+            fscr_n >= fused_scratch_doubles(batch, hw, c) && 2 * (hw / slice) <= fused_resident_blocks(g2 != nullptr)) {
             const int ncb = c / cb;
             float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));
             unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);
             unsigned* const ferr = fsync + (size_t)batch * ncb * SHM_FUSED_SYNC_WORDS;
             const dim3 gridf(hw / slice, ncb, batch);
-            if (g2) hipLaunchKernelGGL((in_bwd_fused8_kernel<true>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
-            else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr);
+            const unsigned arrivals = gridf.x + (shm_tune(SHM_TUNE_ELEM_FUSED_TEST_STALL) ? 1u : 0u);
+            if (g2) hipLaunchKernelGGL((in_bwd_fused8_kernel<true>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
+            else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
             shm_set_last_kernel(g2 ? "in_bwd_fused8_kernel<true>" : "in_bwd_fused8_kernel<false>");
             const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
             SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);

@@ -92,20 +92,27 @@ class Arena:
             for d in shape:
                 n *= int(d)
             flat = torch.zeros(n + int(slack), dtype=dtype, device=self.device)
-            torch.cuda.current_stream(self.device).synchronize()
+            if torch.device(self.device).type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
             t = flat[:n].view(tuple(shape))
             self.t[key] = t
             self.t[key + ("storage",)] = flat
         return t
 
-    def fused_timeouts(self):
+    def fused_timeouts(self, clear=True):
         """Names of the one-pass InstanceNorm-backward scratches (_fused_scratch) whose timeout word is set: a sample barrier of
-        in_bwd_fused8_kernel gave up waiting (the launch then went on with wrong means instead of hanging).  One device-to-host copy."""
+        in_bwd_fused8_kernel gave up waiting (the launch then went on with wrong means instead of hanging).  One device-to-host copy.
+        The words are u32 flags in the last float64 slot: compared as integers (a 1 read as a float64 is a denormal, and flush-to-zero
+        anywhere on the way would hide it: round-5 advisor) and cleared once reported, so the scratch is "zero on entry" again."""
         items = [(k[0], t) for k, t in self.t.items() if isinstance(k[0], str) and k[0].startswith("bwd/fused/")]
         if not items:
             return []
-        words = torch.stack([t[-1] for _, t in items]).cpu().tolist()
-        return [name for (name, _), w in zip(items, words) if w != 0.0]
+        words = torch.stack([t[-1:].view(torch.int64)[0] for _, t in items]).cpu().tolist()
+        hit = [(name, t) for (name, t), w in zip(items, words) if w != 0]
+        if clear:
+            for _, t in hit:
+                t[-1:].zero_()
+        return [name for name, _ in hit]
 
     def nbytes(self):
         # a get_slack tensor is a view of its "storage" entry: count the storage

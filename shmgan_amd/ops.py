@@ -42,6 +42,8 @@ class KernelTimer:
         e0.record()
         fn()
         e1.record()
+        if callable(nbytes):                 # bytes that depend on the path the entry point took (known after the call)
+            nbytes = nbytes()
         self.brecs.append((name, nbytes, e0, e1))
 
     def bytes_summary(self):
@@ -361,6 +363,14 @@ def in_apply(a, lda, stats, beta, out, ldo, batch, hw, c):
         lib().shm_in_apply(_p(a), lda, _p(stats), _p(beta), _p(out), ldo, batch, hw, c, _dt(a), _stream()), "shm_in_apply"))
 
 
+def set_abort_words(dev_word, host_word):
+    """shm_set_abort_words: dev_word a uint32 / int32 CUDA tensor of one element, host_word a PINNED host tensor of one element (ROCm maps
+    pinned host memory into the device's address space at the same address); None, None disarms."""
+    if host_word is not None:
+        assert host_word.is_pinned() and not host_word.is_cuda and dev_word.is_cuda
+    check(lib().shm_set_abort_words(_p(dev_word), _p(host_word)), "shm_set_abort_words")
+
+
 def in_bwd_fused_doubles(batch, hw, c):
     """SHM_IN_BWD_FUSED_DOUBLES: float64 elements of the one-pass form's scratch (per-block partial rows, means, counters and flags)."""
     cb = min(c, 64)
@@ -370,8 +380,13 @@ def in_bwd_fused_doubles(batch, hw, c):
 def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w, c, slope, fused=None):
     """fused: float64 scratch of in_bwd_fused_doubles(batch, h * w, c) elements (zero on entry, zero on return): the call may run the one-pass
     bf16 form (shm_in_bwd_fused_scratch); the library falls back to reduce + apply on shapes that form does not take."""
-    e = batch * h * w * c                          # algorithmic bytes: g1 [+ g2 / 4] and a read once, dz written (what the one-pass form moves;
-    nb = _tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e) + _tb(dz, e)        # the two-pass form reads g and a twice)
+    e = batch * h * w * c
+    rd = _tb(g1, e * (1.25 if g2 is not None else 1.0)) + _tb(a, e)
+
+    def nb():
+        # bytes of the path the call took: the one-pass form reads g1 [+ g2 / 4] and a once and writes dz; reduce + apply read g and a twice
+        # (round-5 advisor: three passes were counted for every call, understating the two-pass calls)
+        return (rd if last_kernel().startswith("in_bwd_fused8") else 2 * rd) + _tb(dz, e)
 
     def run():
         if fused is not None:

@@ -59,6 +59,12 @@ LOSS_NAMES = ["total_Generator_loss", "total_Discriminator_loss", "total_Classif
               "ssim_cyc_loss", "content_loss", "style_loss", "total_NST_loss", "Spec_loss"]
 
 
+class KernelAbortError(RuntimeError):
+    """A kernel of an earlier step gave up (a barrier of the one-pass InstanceNorm backward timed out) and went on with wrong numbers.
+    The optimizer kernels refused every update from that moment on (shm_set_abort_words), so the weights are those of the last good
+    step; the run must not continue."""
+
+
 _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32,
            "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
 
@@ -123,6 +129,11 @@ class ShmGANwithSSpecSeg:
         self._reducer = GradReducer(self.device)
         self._prefetched = None          # _prologue() of the next batch, issued by train_step(next_batch=)
         self._loss_cache = None
+        # abort words (include/shmgan_hip.h, shm_set_abort_words): a device word the optimizer kernel checks before it touches the
+        # weights, and a word in pinned host memory the host polls without synchronising (_check_abort)
+        self._abort_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._abort_np = self._abort_host.numpy()
         # test diagnostics: called with no arguments between the last forward pass and the first backward kernel of a step
         # (tests/test_step_gpu.py pins LeakyReLU signs there; never set on the hot path)
         self.before_backward = None
@@ -147,16 +158,53 @@ class ShmGANwithSSpecSeg:
             self._ws = torch.empty(max(n, 32 << 20), dtype=torch.float32, device=self.device)
         return self._ws
 
+    def _arm_abort(self):
+        """Point the library's abort words at this trainer's pair (per-thread state of the library: several trainers may live in
+        one process, the one that steps owns them)."""
+        ops.set_abort_words(self._abort_dev, self._abort_host)
+
+    def _check_abort(self, sync=False):
+        """Raise KernelAbortError if a kernel of this trainer gave up.  Without `sync` this is one read of host memory (the kernel
+        wrote the pinned word itself), so it costs the step nothing; it sees every abort whose kernel has finished -- the host runs
+        ahead of the device, so an abort of step t may only be seen at the top of step t + 2, and the device-side check in
+        shm_adam_clip is what keeps the weights clean in between.  sync=True (losses(), checkpoints, release()) waits for the device
+        first and is exact."""
+        if self._abort_host is None:
+            return
+        if sync:
+            torch.cuda.synchronize(self.device)
+        if int(self._abort_np[0]) != 0 or (sync and int(self._abort_dev.item()) != 0):
+            names = self.arena.fused_timeouts()
+            raise KernelAbortError(
+                f"in_bwd_fused8_kernel: a group barrier timed out (scratch {names or 'unknown'}): the step's gradients are built on "
+                "unfinished sums.  No optimizer update has been applied since (shm_adam_clip checks the abort word on the device); "
+                "the weights are those of the last good step.  Set SHM_ELEM_FUSED_BWD=0 (two-pass InstanceNorm backward) and report; "
+                "clear_abort() re-arms this trainer")
+
+    def clear_abort(self):
+        """Clear the abort words (after a KernelAbortError, once its cause is dealt with)."""
+        torch.cuda.synchronize(self.device)
+        self._abort_dev.zero_()
+        self._abort_np[0] = 0
+        self.arena.fused_timeouts()
+        torch.cuda.synchronize(self.device)
+
     def release(self):
         """Drop every device buffer this trainer holds (arena, split-K workspace, both models and their optimizer state) so that
-        another trainer can be built in the same process (bench.py's extra configurations); the object is unusable afterwards."""
+        another trainer can be built in the same process (bench.py's extra configurations); the object is unusable afterwards.
+        Raises KernelAbortError (after releasing) if a kernel of this trainer gave up and nobody has heard of it yet."""
         if self._lane is not None:
             self._lane.join()
         torch.cuda.synchronize(self.device)
+        aborted = self._abort_host is not None and (int(self._abort_np[0]) != 0 or int(self._abort_dev.item()) != 0)
+        ops.set_abort_words(None, None)
+        self._abort_dev = self._abort_host = self._abort_np = None
         self.arena.t.clear()
         self._ws = self._prefetched = self._loss_cache = None
         self.G = self.D = self.SpecSeg = None
         self.specular_candidate = None
+        if aborted:
+            raise KernelAbortError("in_bwd_fused8_kernel: a group barrier timed out during this trainer's last steps (seen at release())")
 
     def _get_lane(self):
         import os
@@ -304,6 +352,8 @@ class ShmGANwithSSpecSeg:
         between) picks the result up instead of recomputing it."""
         if self.G is None:
             self.build()
+        self._arm_abort()
+        self._check_abort()              # an earlier step's kernel gave up: stop here, before anything else is issued
         G, D, A = self.G, self.D, self.arena
         S, F = self.image_size, self.filter_size
         orig = [self._dev(t) for t in (orig0, orig45, orig90, orig135, origED)]
@@ -614,6 +664,7 @@ class ShmGANwithSSpecSeg:
         collective while the file is still being written and nobody deletes a file another rank is about to open."""
         import os
         path = None
+        self._check_abort(sync=True)     # never write a checkpoint behind a step whose kernels gave up
         if self._rank() == 0:
             c = self._checkpoints()
             n = int(os.path.basename(c[-1])[5:-4]) + 1 if c else 1
@@ -756,9 +807,7 @@ class ShmGANwithSSpecSeg:
         if self._loss_cache is not None:
             return self._loss_cache
         L = self._last
-        tripped = self.arena.fused_timeouts()
-        if tripped:
-            raise RuntimeError(f"in_bwd_fused8_kernel: sample barrier timed out ({tripped}); set SHM_ELEM_FUSED_BWD=0 and report")
+        self._check_abort(sync=True)
         d = (L.dl.cpu().numpy() / L.B).tolist()
         i = (L.il.cpu().numpy() / L.B).tolist()
         D1_RF, D3_RF = d[0], d[1]
