@@ -304,8 +304,9 @@ def main():
             out["extra"] = {"f32x3": {"ms_per_step": round(dt3 / args.steps * 1e3, 3), "value": round(B * args.steps / dt3, 3), "unit": "images/sec",
                                       "steps": args.steps, "warmup": 2,
                                       "arithmetic": "3xbf16 planes (exact truncation split of every fp32 operand), 6 products with i + j <= 2, fp32 accumulate; "
-                                                    "3x3 unit-stride layers: weight gradients (wgrad_halo_x3_kernel) and the forward / input-gradient products with more than 64 output "
-                                                    "channels (tapgemm_halo_x3_kernel); everything else exact-fp32 MFMA",
+                                                    "3x3 unit-stride layers: weight gradients (wgrad_halo_x3_kernel) and the forward / input-gradient products (tapgemm_halo_x3_kernel: "
+                                                    "128-channel blocks, and 64-channel blocks on maps whose height is a multiple of 32); stride-2 / transposed / 1x1 / first layers "
+                                                    "exact-fp32 MFMA",
                                       "losses_finite": bool(all(np.isfinite(v) for k, v in model.losses().items() if k != "ssim"))}}
             note(f"f32x3 (opt-in): {dt3 / args.steps * 1e3:.2f} ms/step")
         if not args.no_kernel_timer and world == 1:      # a single-GPU property; at N > 1 the other ranks would wait behind it
@@ -404,28 +405,40 @@ def north_star_block(torch, ops, dev, n=40, h=256, c=64, reps=20):
     for _ in range(3):
         fn()
     kernel = ops.last_kernel()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)          # the clock the product kernel holds, from its own counters (shm_set_clock_probe)
+    ops.set_clock_probe(clk)
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_clock_probe(None)
     us = e0.elapsed_time(e1) / reps * 1e3
+    ck = clk.tolist()
+    kernel_clock = ck[0] / ck[1] * 0.1 if ck[1] > 0 else None          # GHz: shader-clock ticks per 10 ns tick of the last launch's patch loop
     nbytes = 2 * n * h * h * (c + c) + 2 * 9 * c * c + 16 * n * c
     gbps = nbytes / us / 1e3
     flops = 2.0 * n * h * h * 9 * c * c
     out = {"block": f"conv3x3 {c}->{c} + bias + LeakyReLU + IN statistics, {h}x{h}, n={n}, bf16", "kernel": kernel, "bytes": nbytes,
            "us": round(us, 2), "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "launches": reps,
            "flops": flops, "tflops": round(flops / us / 1e6, 1)}
-    out.update(north_star_ceiling(torch, dev, flops, 2 * n * h * h * c, us, reps))
+    out["kernel_clock_ghz"] = None if kernel_clock is None else round(kernel_clock, 3)
+    out.update(north_star_ceiling(torch, dev, flops, 2 * n * h * h * c, us, reps, kernel_clock))
     return out
 
 
-def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps):
+def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps, kernel_clock=None):
     """What the chip can do on the block's two resources taken one at a time, in this process, right after the product kernel
     (tools/probes/ceiling_ns_block.hip): the block's FLOPs as a bare v_mfma_f32_16x16x32_bf16 loop on random operands in registers (the
     product's launch geometry: 512 eight-wave blocks, four waves per SIMD) and the block's bytes as a 16-byte-per-lane streaming copy.
-    ceiling_us = max of the two; frac_of_ceiling = ceiling_us / us.  clock_ghz: d(s_memtime) / d(s_memrealtime) x 100 MHz around the MFMA loop."""
+    clock_ghz: d(s_memtime) / d(s_memrealtime) x 100 MHz around the MFMA loop.  Round 6: the copy's shape is calibrated
+    once on a 2 GB buffer (threads per block, loads in flight, blocks per CU, plain / non-temporal) and the best shape copies the block's bytes;
+    `mfma_us_at_sustained_clock` = the bare loop's cycles at the clock the PRODUCT kernel held in this run (its own s_memtime / s_memrealtime,
+    shm_set_clock_probe) -- a bare MFMA loop runs hotter than the chip allows the product's mix of HBM stream + LDS + MFMA;
+    ceiling_us = the largest of the three; frac_of_ceiling = ceiling_us / us."""
     import ctypes as C
     lib_path = ROOT / "tools" / "probes" / "libceiling_ns_block.so"
     if not lib_path.exists():
@@ -462,7 +475,37 @@ def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps):
         if L.ceil_mfma_bf16(ops_.data_ptr(), sink.data_ptr(), stamps.data_ptr(), blocks, per_wave, st) < 0:
             raise RuntimeError("ceiling probe: MFMA launch failed")
 
+    L.ceil_copy_cfg.restype = C.c_int
+    L.ceil_copy_cfg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+    def copy_cfg(s_, d_, nbytes, cfg):
+        bpc, threads, unroll, nt = cfg
+        if L.ceil_copy_cfg(s_.data_ptr(), d_.data_ptr(), nbytes, bpc * ncu, threads, unroll, nt, st) != 0:
+            raise RuntimeError(f"ceiling probe: copy launch failed {cfg}")
+    # calibration: 1 GB read + 1 GB written per launch (far beyond the 256 MB Infinity Cache), every shape, best of two rounds
+    cal_bytes = 1 << 30
+    cal_src = torch.empty(cal_bytes // 4, device=dev).normal_()
+    cal_dst = torch.empty_like(cal_src)
+    cal = {}
+    for cfg in [(bpc, th, un, nt) for th in (256, 512, 1024) for un in (4, 8) for bpc in (8, 16, 32) for nt in (1, 0)]:
+        best = 0.0
+        for _ in range(2):
+            copy_cfg(cal_src, cal_dst, cal_bytes, cfg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                copy_cfg(cal_src, cal_dst, cal_bytes, cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 2 * cal_bytes * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        cal[cfg] = best
+    del cal_src, cal_dst
+    best_cfg = max(cal, key=cal.get)
+
     def copy():
+        copy_cfg(src, dst, tensor_bytes, best_cfg)
+
+    def copy_r5():
         if L.ceil_copy(src.data_ptr(), dst.data_ptr(), tensor_bytes, 16 * ncu, st) != 0:
             raise RuntimeError("ceiling probe: copy launch failed")
     mfma_us = timed(mfma) * (flops / (per_wave * waves * 16384.0))          # scaled to the block's exact FLOPs (rounding of per_wave)
@@ -481,12 +524,20 @@ def north_star_ceiling(torch, dev, flops, tensor_bytes, us, reps):
     sv32 = stamps.view(-1, 2)[:waves32].double()
     clock32 = float((sv32[:, 0] / sv32[:, 1].clamp(min=1)).median()) * 0.1
     copy_us = timed(copy)
-    ceil_us = max(mfma_us, copy_us)
+    copy_r5_us = timed(copy_r5)
+    sustained_us = mfma_us * clock / kernel_clock if kernel_clock else None
+    ceil_us = max(mfma_us, copy_us, sustained_us or 0.0)
     return {"ceiling": {"mfma_us": round(mfma_us, 2), "mfma_tflops": round(flops / mfma_us / 1e6, 1), "mfma_clock_ghz": round(clock, 3),
+                        "mfma_us_at_sustained_clock": None if sustained_us is None else round(sustained_us, 2),
                         "mfma_32x32x16_us": round(mfma32_us, 2), "mfma_32x32x16_clock_ghz": round(clock32, 3),
                         "copy_us": round(copy_us, 2), "copy_GBps": round(2 * tensor_bytes / copy_us / 1e3, 1),
-                        "what": "bare 16x16x32 bf16 MFMA loop with the block's FLOPs (random operands in registers, 4 waves per SIMD) / 16-byte "
-                                "streaming copy of the block's activation bytes; same process, after the product kernel"},
+                        "copy_shape": {"blocks_per_cu": best_cfg[0], "threads": best_cfg[1], "loads_in_flight": best_cfg[2], "nontemporal": bool(best_cfg[3])},
+                        "copy_calibration_GBps_2GB": {"best": round(cal[best_cfg], 1), "worst": round(min(cal.values()), 1),
+                                                      "round5_shape_16x256x4_nt": round(cal[(16, 256, 4, 1)], 1)},
+                        "copy_round5_shape_us": round(copy_r5_us, 2),
+                        "what": "bare 16x16x32 bf16 MFMA loop with the block's FLOPs (random operands in registers, 4 waves per SIMD), the same "
+                                "cycles at the clock the product kernel held, and a 16-byte streaming copy of the block's activation bytes in the "
+                                "best of 36 calibrated shapes; same process, after the product kernel"},
             "ceiling_us": round(ceil_us, 2), "frac_of_ceiling": round(ceil_us / us, 4)}
 
 

@@ -86,6 +86,11 @@ const char* shm_last_kernel(void);
  *   "stats.fusion"              1 InstanceNorm statistics in the conv epilogue (default), 0 separate pass
  *   "elem.fused_max_slices"     the one-pass form: most slices (= blocks that must be resident together) per barrier group, default 256, at most 512; the launcher also
  *                               requires twice the group's blocks to fit the device (shm_set_abort_words below)
+ *   "elem.fused_hold"           the one-pass form's kernel: 0 automatic (in_bwd_fusedg_kernel -- the gradient held in registers, the activation streamed
+ *                               twice, slices of 32768 / min(c, 64) pixels, up to 2 x "elem.fused_max_slices" blocks per group -- on maps of at least
+ *                               256 x 16384 / min(c, 64) pixels without a pooled gradient, where it is measured faster; in_bwd_fused8_kernel otherwise),
+ *                               1 in_bwd_fused8_kernel only, 2 in_bwd_fusedg_kernel wherever the map has whole slices
+ *   "elem.fused_gvariant"       in_bwd_fusedg_kernel's register-budget form: 0 <2, 2, 4> (four blocks per CU; default), 1 <8, 8, 3>
  *   "elem.fused_test_stall"     tests only: 1 = the one-pass form's barriers wait for one block more than the grid has, i.e. every barrier
  *                               times out (~1 s per resident generation of blocks) and the abort words are set; default 0
  *   "elem.reverse"              1 InstanceNorm apply / backward-reduce passes walk the tensor back to front (default: the tail the
@@ -275,6 +280,10 @@ int shm_in_bwd_fused_scratch(double* scratch, size_t n_doubles);
  *   host_word  u32 in mapped (pinned) host memory, set to 1: the host sees it without synchronising.
  * Both stay set until the caller clears them; NULLs disarm.  Persistent per calling thread (configuration, like the tuning table). */
 int shm_set_abort_words(unsigned* dev_word, unsigned* host_word);
+/* Measurement hook (bench.py, north_star_block.ceiling): while dev2 (two u64 in device memory) is set on the calling thread, one wave of the
+ * middle block of every tapgemm_pp_bf16_kernel launch writes dev2[0] = shader-clock ticks (s_memtime) and dev2[1] = 100 MHz ticks (s_memrealtime)
+ * of its patch loop: the clock the kernel actually held = dev2[0] / dev2[1] x 0.1 GHz.  NULL disarms (default). */
+int shm_set_clock_probe(unsigned long long* dev2);
 
 /* Opt-in fp32 arithmetic from bf16 MFMAs for the 3x3 unit-stride forward / input-gradient layers: tuning "conv.f32_split" = 1 (round 5,
  * csrc/conv_fwd_x3.hip; the weight gradient's twin is "wgrad.f32_split").  Every fp32 operand is split EXACTLY into three bf16 planes and the six

@@ -59,6 +59,7 @@ SIGNATURES = {
     "shm_in_bwd_keep_dz_sums": (I, [P]),
     "shm_in_bwd_fused_scratch": (I, [P, Z]),
     "shm_set_abort_words": (I, [P, P]),
+    "shm_set_clock_probe": (I, [P]),
     "shm_conv2d_wgrad_norm_supported": (I, [I, I, I, I, I, I, I, I, I, I, I]),
     "shm_in_pool": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "shm_in_bwd": (I, [P, I, P, I, P, I, P, P, P, I, P, I, I, I, I, F, I, P]),

@@ -49,9 +49,12 @@ enum ShmTune {
     SHM_TUNE_ELEM_FUSED_MAX_SLICES,   // in_bwd_fused8_kernel: most slices (= blocks) per sample; a sample's blocks must be resident together (1024 fit an idle chip)
     SHM_TUNE_CONV_F32_SPLIT,          // fp32 3x3 unit-stride forward / input-gradient layers (> 64 output channels): 1 = six bf16 MFMA products of exact three-plane splits (conv_fwd_x3.hip), 0 = exact-fp32 MFMA (default)
     SHM_TUNE_ELEM_FUSED_TEST_STALL,   // tests only: 1 = in_bwd_fused8_kernel's barriers wait for one block more than the grid has (the timeout path)
+    SHM_TUNE_ELEM_FUSED_HOLD,         // one-pass bf16 InstanceNorm backward: 0 automatic (g held, a streamed twice where eligible; else g and a held), 1 = g and a held only (round 5), 2 = g held only
+    SHM_TUNE_ELEM_FUSED_GVARIANT,     // in_bwd_fusedg_kernel's register-budget form: 0 = <2, 2, 4> (four blocks per CU, two transient loads per batch; default), 1 = <8, 8, 3>
     SHM_TUNE_COUNT
 };
 int shm_tune(int id);
+unsigned long long* shm_clock_probe();       // this thread's shm_set_clock_probe buffer (norm_elem.hip), or null
 const unsigned* shm_abort_dev_word();       // this thread's shm_set_abort_words device word (norm_elem.hip), or null
 
 // Barrier of the LDS-DMA pipelines.  A stage is refilled by DMA instructions issued AFTER the barrier that follows its last use, so a

@@ -20,8 +20,11 @@
 //   * Halo image per group: [10 rows][34 pixels][128 bytes], single-buffered (it is refilled in the group's Y segment, after the barrier that ends
 //     its X segment), filled by LDS-DMA: wave w4 of the group fetches the 8-pixel column segment w4 of every halo row (ten 1 KiB items whose
 //     per-lane source offset is ONE lane constant plus a uniform term) and the two-pixel tails of rows w4, w4 + 4, w4 + 8; 16-byte chunk c of
-//     halo column hc sits at position c ^ ((hc >> 1) & 7): the 32-pixel fragment read (two chunks per pixel) and the linear DMA write are both
-//     conflict-free.  Out-of-image rows fall outside a per-image buffer descriptor (zeros), out-of-image columns get an out-of-range offset.
+//     halo column hc sits at position c ^ (hc & 6): conflict-free for the 16x16x32 fragment read at every column shift, and the DMA write is linear.
+//     (Round 6: the first swizzle, c ^ ((hc >> 1) & 7), was laid out for the 32x32x16 shape's 32-pixel fragment; under ds_read_b128's lane groups --
+//     {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... : sixteen pixels, the middle eight with the NEXT k chunk -- it was 2-way conflicted at column
+//     shifts 1 and 2: 6.67 LDS cycles per read instead of 4, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40 in profiles/r05_*_sq_pmc.json.
+//     tools/probes/pp_lds_conflicts.py models every LDS access of this kernel against the guide's lane groups.)  Out-of-image rows fall outside a per-image buffer descriptor (zeros), out-of-image columns get an out-of-range offset.
 //   * Epilogue as in conv_wreg16.hip: a lane's accumulator quads are four consecutive channels of one pixel -> 8-byte pieces into a
 //     [256 pixels][128 bytes] staging image (chunk XOR pixel & 7), barrier, 1 KiB stores of whole lines.  InstanceNorm sums on the matrix pipe
 //     from the staging image (transposed reads: mfma(F, F) diagonal = sum y^2, mfma(F, ones) = sum y; see conv_wreg16.hip), of the group's
@@ -101,7 +104,7 @@ __device__ __forceinline__ void pp_static_for(F&& f) {
 
 // MODE 0: plain product (input-gradient launches: no bias, slope 1, no statistics); 1: bias + LeakyReLU; 2: bias + LeakyReLU + InstanceNorm statistics
 template <int MODE, int XSPLIT>
-__global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmArgs a, const int npatch, const int dbg) {
+__global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmArgs a, const int npatch, const int dbg, unsigned long long* __restrict__ clk) {
     constexpr bool EPI = MODE != 0, STATS = MODE == 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     if (tid < 64) sbias[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
 
     // ---- halo DMA of patch q into the group's image (header comment).  Full item (row j, segment w4): LDS halo + j * 4352 + w4 * 1024; lane =
-    // (pixel p8 = lane >> 3 of the segment, position lane & 7): halo column 8 w4 + p8, source chunk position ^ ((4 (w4 & 1) + (p8 >> 1)) & 7)
+    // (pixel p8 = lane >> 3 of the segment, position lane & 7): halo column hc = 8 w4 + p8, source chunk position ^ (hc & 6) = position ^ (p8 & 6)
     const unsigned pixb = (unsigned)a.ldx * 2u;
     const unsigned imgb = (unsigned)(a.hi * a.wi) * pixb;
     auto dma = [&](int q) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         asm volatile("" : "+v"(ln));                     // the lane constants are re-formed per patch, not kept across the MFMA segment
         const int p8 = ln >> 3, pos = ln & 7;
         const unsigned base = (unsigned)((y0 - 1) * a.wi + x0 - 1) * pixb;           // halo (0, 0); wraps below zero on the first row / column
-        const unsigned lc = base + (unsigned)(8 * w4 + p8) * pixb + (unsigned)((pos ^ ((4 * (w4 & 1) + (p8 >> 1)) & 7)) << 4);
+        const unsigned lc = base + (unsigned)(8 * w4 + p8) * pixb + (unsigned)((pos ^ (p8 & 6)) << 4);
         // column -1 (segment 0, p8 = 0) of a patch on the left edge: the previous row's last pixel, not padding -> out of range by hand
         const bool lcut = w4 == 0 && x0 == 0;            // wave-uniform
         const unsigned rowb = (unsigned)a.wi * pixb;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
             if (lcut) off = p8 == 0 ? 0xffffffffu : off;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(halo + j * (PP_HC * 128) + w4 * 1024), 16, (int)off, 0, 0, 0);
         }
-        // tails: halo columns 32, 33 of rows w4, w4 + 4, w4 + 8 (sixteen lanes; chunk = position: ((32 + p8) >> 1) & 7 = 0)
+        // tails: halo columns 32, 33 of rows w4, w4 + 4, w4 + 8 (sixteen lanes; chunk = position: (32 + p8) & 6 = 0)
         if (ln < 16) {
             const bool rcut = x0 + PP_PW == a.wi;        // column wi: the next row's first pixel
             const unsigned lt = base + (unsigned)(32 + p8) * pixb + (unsigned)(pos << 4);
@@ -186,10 +189,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
     };
 
     // ---- fragment addresses (B operand: lane (l15, lq) holds pixel 16 pt + l15 + cs of halo row 4 wm + rr, channels 32 k32 + 8 lq ... + 7 = chunk
-    // 4 k32 + lq): position chunk ^ (((l15 + cs) >> 1) & 7) -- the tile's 16 pt leaves the swizzle alone; rr and pt are immediates, k32 an XOR of bit 6
+    // 4 k32 + lq): position chunk ^ ((l15 + cs) & 6) -- the tile's 16 pt leaves the swizzle alone; rr and pt are immediates, k32 an XOR of bit 6
     int fa[3];
 #pragma unroll
-    for (int cs = 0; cs < 3; ++cs) fa[cs] = G * PP_HALO + ((4 * wm * PP_HC) + l15 + cs) * 128 + ((lq ^ (((l15 + cs) >> 1) & 7)) << 4);
+    for (int cs = 0; cs < 3; ++cs) fa[cs] = G * PP_HALO + ((4 * wm * PP_HC) + l15 + cs) * 128 + ((lq ^ ((l15 + cs) & 6)) << 4);
 
     const bool part0 = n0 < a.n1;                        // block-uniform: the 64 channels lie in one output part (launcher)
     const __amdgpu_buffer_rsrc_t rsy = part0 ? __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000)
@@ -403,6 +406,12 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         tl0 = __builtin_amdgcn_s_memtime();
         rl0 = __builtin_amdgcn_s_memrealtime();
     }
+    // clock probe (shm_set_clock_probe, bench.py's north-star ceiling): shader-clock and 100 MHz counters around the patch loop of one wave
+    unsigned long long ck0 = 0, cr0 = 0;
+    if (clk) {
+        ck0 = __builtin_amdgcn_s_memtime();
+        cr0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int i = 0; i < per; ++i) {
         const int q = q0 + i;
         const bool act = q < q1;                 // group-uniform
@@ -477,6 +486,10 @@ __global__ __launch_bounds__(512, 2) void tapgemm_pp_bf16_kernel(const TapGemmAr
         SHM_LDS_BARRIER();
         SHM_LDS_BARRIER();
     }
+    if (clk && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - ck0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
     if constexpr (STATS)
         if (q0 < q1) {
             xstats_tail((q1 - 1) / ppi);
@@ -518,7 +531,7 @@ int shm_pp_launch(const TapGemmArgs& a, int batch, int ncu, hipStream_t st, cons
     do {                                                                                                                                \
         static const hipError_t at_ = hipFuncSetAttribute((const void*)tapgemm_pp_bf16_kernel<EPI_, XS_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
         att = at_;                                                                                                                      \
-        if (att == hipSuccess) hipLaunchKernelGGL((tapgemm_pp_bf16_kernel<EPI_, XS_>), dim3(gx, nyw, 1), dim3(512), PP_LDS, st, a, npatch, prio); \
+        if (att == hipSuccess) hipLaunchKernelGGL((tapgemm_pp_bf16_kernel<EPI_, XS_>), dim3(gx, nyw, 1), dim3(512), PP_LDS, st, a, npatch, prio, shm_clock_probe()); \
     } while (0)
     const int mode = !epi ? 0 : a.stats ? 2 : 1;
     if (mode == 2) PP_LAUNCH(2, 48);

@@ -63,6 +63,8 @@ const TuneDef kTune[SHM_TUNE_COUNT] = {
     {"elem.fused_max_slices", "SHM_ELEM_FUSED_MAX_SLICES", 256, 1, 512},
     {"conv.f32_split", "SHM_CONV_F32_SPLIT", 0, 0, 1},
     {"elem.fused_test_stall", "SHM_ELEM_FUSED_TEST_STALL", 0, 0, 1},
+    {"elem.fused_hold", "SHM_ELEM_FUSED_HOLD", 0, 0, 2},
+    {"elem.fused_gvariant", "SHM_ELEM_FUSED_GVARIANT", 0, 0, 1},
 };
 std::atomic<int> g_tune[SHM_TUNE_COUNT];
 std::atomic<int> g_tune_init{0};
@@ -1140,6 +1142,237 @@ __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const In
 #undef FSTAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same one-pass protocol with HALF the registers per byte of traffic.  in_bwd_fused8_kernel is bound by residency x latency (a
+// block holds its 64 KiB of g and a for ~23 us; 4 blocks per CU fill the register file: 768-1024 x 96 KiB of traffic per 23 us = 3.2-4.3 TB/s,
+// LABNOTES 11.6).  Here a block holds ONLY g (the gradient is dead after this kernel; the activation stays in HBM and the Infinity Cache): a slice
+// is 16 pixel slots per thread (32768 / CB pixels), g raw bf16 in 64 registers, and `a` is streamed through 16-byte transient registers twice --
+// phase 1 for sum g * (x - mean), phase 2 for the apply; the second read comes back from L2 / the Infinity Cache 20-30 us after the first.  The
+// same 4 blocks per CU now cover 192 KiB of traffic each, and a barrier group has HALF the blocks (128 on the 256 x 256 x 64 maps: the last
+// arriver's row sums, 5.9 of 13.3 us there, halve; the 512 x 512 maps of BASELINE configs[3] get 512-block groups, which twice fit the chip).
+// The register budget decides the form: 64 (g) + 16 (sums) + 8 (means) leave room for TWO transient loads of `a` per batch at four blocks per CU
+// (<2, 2, 4>: 8 spills; eight batches per phase, each a round trip); eight per batch need three blocks per CU (<8, 8, 3>).  hipcc has to be held
+// to the batches by data dependences (below).  Measured, n = 40 / 160 at 256 x 256 x 64: 287 / 1072 us (in_bwd_fused8_kernel) -> 252 / 879 (<2, 2, 4>),
+// 262 / 920 (<8, 8, 3>); on maps with fewer blocks per group the extra round trips lose (128 x 128 x 128: 122 -> 147): see the launcher.
+// Sums: sum g and sum g * (x - mean) per slice in fp32 (the centring keeps the second one free of the cancellation a raw sum g * x would meet
+// when |mean| >> 1 / inv), times inv at the end; everything else -- rows, last arriver, flags, timeout and abort words, departure -- as above.
+#define FG_LOAD(rs, base, voff, soff) __builtin_bit_cast(shm_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0))
+#define FG_STORE(v, rs, base, voff) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0)
+template <int AB, int AB2, int BPC>          // transient `a` loads in flight per batch in phase 1 / phase 2; blocks per CU the register budget is cut for
+__global__ __launch_bounds__(256, BPC) void in_bwd_fusedg_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
+                                                               unsigned* __restrict__ fsync, unsigned* __restrict__ ferr,
+                                                               unsigned* __restrict__ abort_dev, unsigned* __restrict__ abort_host, const unsigned arrivals) {
+    constexpr int U = 16;
+    __shared__ double red[256 * 8];
+    __shared__ float sm12[128], smi[128];
+    __shared__ int s_last;
+    const int CB = k.c < 64 ? k.c : 64, c0 = blockIdx.y * CB;
+    const int lanes_c = CB >> 3, PP = 256 / lanes_c;
+    const int pp = threadIdx.x / lanes_c, cl = threadIdx.x - pp * lanes_c;
+    const int n = k.rev ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z, hw = k.h * k.w;
+    const int gidx = n * gridDim.y + blockIdx.y;
+    const int pbase = blockIdx.x * (U * PP) + pp;
+    const int bpi = gridDim.x, c3 = 3 * CB;
+    float* const prow0 = fpart + (size_t)gidx * bpi * c3;
+    float* const prow = prow0 + (size_t)blockIdx.x * c3;
+    // buffer accesses: one descriptor per tensor and SAMPLE (a sample is below 4 GiB: launcher), the lane's byte offset in ONE register, the pixel
+    // slot as a scalar offset -- with flat 64-bit addresses hipcc kept sixteen address pairs alive beside the 64 registers of g and spilled 216
+    const unsigned samp_g = (unsigned)hw * (unsigned)k.ldg1 * 2u, samp_a = (unsigned)hw * (unsigned)k.lda * 2u, samp_z = (unsigned)hw * (unsigned)k.lddz * 2u;
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((char*)k.g1 + (size_t)n * samp_g, 0, samp_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((char*)k.a + (size_t)n * samp_a, 0, samp_a, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((char*)k.dz + (size_t)n * samp_z, 0, samp_z, 0x00020000);
+    const unsigned og = (unsigned)(pbase * k.ldg1 + c0 + cl * 8) * 2u, oa = (unsigned)(pbase * k.lda + c0 + cl * 8) * 2u;
+    const unsigned sg_step = (unsigned)(PP * k.ldg1) * 2u, sa_step = (unsigned)(PP * k.lda) * 2u, sz_step = (unsigned)(PP * k.lddz) * 2u;      // scalars
+    shm_u32x4 gq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) gq[u] = FG_LOAD(rsg, (const char*)k.g1 + (size_t)n * samp_g, og, (unsigned)u * sg_step);
+    float* const redf = (float*)red;
+    auto park = [&](const float (&v)[8], int j) {
+        *(f32x4*)&redf[j * 2048 + threadIdx.x * 8] = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)&redf[j * 2048 + threadIdx.x * 8 + 4] = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    auto finish = [&](int nv, float* dst, int stride) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < CB * nv; t += 256) {
+            const int j = t / CB, ch = t - j * CB;
+            float sum = 0.f;
+            for (int q = 0; q < PP; ++q) sum += redf[j * 2048 + q * CB + ch];
+            coh_store(&dst[ch * stride + j], sum);
+        }
+    };
+    auto rowsum = [&](const float* base, int npairs) {
+        const int P = npairs < 256 ? npairs : 256, RG = 256 / P, rg = threadIdx.x / P;
+        __syncthreads();
+        for (int q = threadIdx.x % P; q < npairs; q += P) {
+            double s0 = 0.0, s1 = 0.0;
+            const unsigned long long* col = (const unsigned long long*)base + q;
+            const size_t rs = (size_t)c3 / 2;
+            int b = rg;
+            for (; b + 15 * RG < bpi; b += 16 * RG) {
+                unsigned long long t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = coh_load(col + (size_t)(b + j * RG) * rs);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    s0 += (double)__uint_as_float((unsigned)t[j]);
+                    s1 += (double)__uint_as_float((unsigned)(t[j] >> 32));
+                }
+            }
+            for (; b < bpi; b += RG) {
+                const unsigned long long t = coh_load(col + (size_t)b * rs);
+                s0 += (double)__uint_as_float((unsigned)t);
+                s1 += (double)__uint_as_float((unsigned)(t >> 32));
+            }
+            red[(rg * npairs + q) * 2] = s0;
+            red[(rg * npairs + q) * 2 + 1] = s1;
+        }
+        __syncthreads();
+        return RG;
+    };
+    auto total = [&](int v, int npairs, int RG) {
+        double s = 0.0;
+        for (int r = 0; r < RG; ++r) s += red[(r * npairs + (v >> 1)) * 2 + (v & 1)];
+        return s;
+    };
+    // ---- phase 1: `a` passes through sixteen-byte transients; (sum g, inv * sum g * (x - mean)) of the slice -> the block's row
+    {
+        float mean[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mean[e] = (float)k.stats[((size_t)n * k.c + c0 + cl * 8 + e) * 2];
+        if (pp == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                smi[(cl * 8 + e) * 2] = mean[e];
+                smi[(cl * 8 + e) * 2 + 1] = (float)k.stats[((size_t)n * k.c + c0 + cl * 8 + e) * 2 + 1];
+            }
+        }
+        float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unsigned oab = oa;
+        // `a` in batches of AB transient loads (the register budget of four blocks per CU: 64 for g + 16 sums + 8 means leave ~32); the
+        // sched_barrier keeps hipcc from hoisting the next batch's loads over this batch's arithmetic (it would: 168 spills)
+#pragma unroll
+        for (int b = 0; b < U / AB; ++b) {
+            shm_u32x4 aq[AB];
+#pragma unroll
+            for (int u = 0; u < AB; ++u) aq[u] = FG_LOAD(rsa, (const char*)k.a + (size_t)n * samp_a, oab, (unsigned)(b * AB + u) * sa_step);
+            // (the g-only half of the arithmetic -- unpack, sum g -- is pure register work: left visible, LLVM hoists it for all sixteen slots to
+            // the top of the kernel, 128 live floats; the opaque copy ties it to its batch)
+#pragma unroll
+            for (int u = 0; u < AB; ++u) asm volatile("" : "+v"(gq[b * AB + u]));
+#pragma unroll
+            for (int u = 0; u < AB; ++u) {
+                const f32x8 x = unpack8(aq[u]), g = unpack8(gq[b * AB + u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sg[e] += g[e];
+                    sx[e] += g[e] * (x[e] - mean[e]);
+                }
+            }
+            // the next batch's loads wait (as far as hipcc can see) for this batch's sums: otherwise all sixteen are hoisted to the top
+            asm volatile("" : "+v"(oab) : "v"(sg[0]), "v"(sg[1]), "v"(sg[2]), "v"(sg[3]), "v"(sg[4]), "v"(sg[5]), "v"(sg[6]), "v"(sg[7]), "v"(sx[0]), "v"(sx[1]), "v"(sx[2]), "v"(sx[3]),
+                         "v"(sx[4]), "v"(sx[5]), "v"(sx[6]), "v"(sx[7]));
+        }
+        __syncthreads();                    // smi is written
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sx[e] *= smi[(cl * 8 + e) * 2 + 1];
+        park(sg, 0);
+        park(sx, 1);
+        finish(2, prow, 2);
+    }
+    // ---- the group's barrier (in_bwd_fused8_kernel: relaxed device-scope atomics, the last arriver adds the rows in block order and raises the flags)
+    unsigned* const sy = fsync + (size_t)gidx * SHM_FUSED_SYNC_WORDS;
+    float* const res = fres + ((size_t)n * k.c + c0) * 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == arrivals;
+    __syncthreads();
+    if (s_last) {
+        const int RG = rowsum(prow0, CB);
+        for (int v = threadIdx.x; v < 2 * CB; v += 256) {
+            const float r = (float)(total(v, CB, RG) / hw);
+            sm12[v] = r;
+            coh_store(res + v, r);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < SHM_FUSED_FLAGS) coh_store(sy + 64 + 32 * threadIdx.x, 1u);
+    } else {
+        if (threadIdx.x == 0) {
+            const unsigned* const flag = sy + 64 + 32 * (blockIdx.x % SHM_FUSED_FLAGS);
+            int spins = 0;
+            while (coh_load(flag) == 0u) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (arrivals == gridDim.x ? 1 << 20 : 1 << 10)) {
+                    __hip_atomic_fetch_or(ferr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (abort_dev) __hip_atomic_fetch_or(abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (abort_host) __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < CB * 2; i += 256) sm12[i] = coh_load(res + i);
+    }
+    __syncthreads();
+    // ---- phase 2: d = A g - (B x + C) from the held g and a second read of a
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(gq[u]));
+    int pb2 = pbase;
+    asm volatile("" : "+v"(pb2));
+    const unsigned oa2 = (unsigned)(pb2 * k.lda + c0 + cl * 8) * 2u, oz = (unsigned)(pb2 * k.lddz + c0 + cl * 8) * 2u;
+    float cA[8], cB[8], cC[8], sd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float m1 = sm12[(cl * 8 + e) * 2], m2 = sm12[(cl * 8 + e) * 2 + 1], mu = smi[(cl * 8 + e) * 2], iv = smi[(cl * 8 + e) * 2 + 1];
+        cA[e] = iv;
+        cB[e] = iv * iv * m2;
+        cC[e] = iv * m1 - cB[e] * mu;
+    }
+    unsigned oa2b = oa2;
+#pragma unroll
+    for (int b = 0; b < U / AB2; ++b) {
+        shm_u32x4 aq[AB2];
+#pragma unroll
+        for (int u = 0; u < AB2; ++u) aq[u] = FG_LOAD(rsa, (const char*)k.a + (size_t)n * samp_a, oa2b, (unsigned)(b * AB2 + u) * sa_step);
+#pragma unroll
+        for (int u = 0; u < AB2; ++u) asm volatile("" : "+v"(gq[b * AB2 + u]));
+#pragma unroll
+        for (int u = 0; u < AB2; ++u) {
+            const f32x8 g = unpack8(gq[b * AB2 + u]), x = unpack8(aq[u]);
+            typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float da = cA[e] * g[e] - (cB[e] * x[e] + cC[e]);
+                const float d = x[e] > 0.f ? da : da * k.slope;
+                sd[e] += d;
+                o[e] = (bf16_t)d;
+            }
+            // the slot offset goes into the VECTOR offset: behind a 16-byte buffer store whose soffset is an SGPR hipcc leaves no wait states in front of
+            // a VALU write of the store's data registers, and the MI355X needs them (common.h, round 4; tools/check_isa_hazards.py flags the form)
+            FG_STORE(__builtin_bit_cast(shm_u32x4, o), rsz, (char*)k.dz + (size_t)n * samp_z, oz + (unsigned)(b * AB2 + u) * sz_step);
+        }
+        asm volatile("" : "+v"(oa2b) : "v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]), "v"(sd[4]), "v"(sd[5]), "v"(sd[6]), "v"(sd[7]));
+    }
+    if (k.dbias) {
+        __syncthreads();
+        park(sd, 0);
+        finish(1, prow + 2 * CB, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sy + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+    __syncthreads();
+    if (s_last) {
+        if (k.dbias) {
+            const int RG = rowsum(prow0 + 2 * CB, CB / 2);
+            for (int ch = threadIdx.x; ch < CB; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch] = total(ch, CB / 2, RG);
+        }
+        for (int i = threadIdx.x; i < CB * 2; i += 256) coh_store(res + i, 0.f);
+        if (threadIdx.x < SHM_FUSED_FLAGS + 2) coh_store(sy + 32 * threadIdx.x, 0u);
+    }
+}
+
 // shm_in_bwd_apply's last launch: fold the staged bias gradient (dbias[ch] += sum over samples) and clear the gsum slot copies the
 // apply pass consumed -- "zero on entry, zero on return" for every f64 scratch, no memset in front of a launch.
 // keep != null: the per-sample sums are also copied out ([nslot = batch][c]: shm_in_bwd_keep_dz_sums)
@@ -1278,25 +1511,36 @@ extern "C" int shm_set_abort_words(unsigned* dev_word, unsigned* host_word) {
     return SHM_OK;
 }
 const unsigned* shm_abort_dev_word() { return g_abort_dev; }
+// shm_set_clock_probe: measurement hook (bench.py's north-star ceiling).  While set on this thread, the ping-pong convolution kernel
+// (tapgemm_pp_bf16_kernel) writes, from one wave of its middle block, dev2[0] = s_memtime ticks (shader clock) and dev2[1] = s_memrealtime ticks
+// (100 MHz) spent in its patch loop: dev2[0] / dev2[1] x 0.1 = the clock in GHz the kernel held.  NULL (default) disarms; no other kernel reads it.
+static thread_local unsigned long long* g_clock_probe = nullptr;
+extern "C" int shm_set_clock_probe(unsigned long long* dev2) {
+    g_clock_probe = dev2;
+    return SHM_OK;
+}
+unsigned long long* shm_clock_probe() { return g_clock_probe; }
 
 // Blocks of in_bwd_fused8_kernel<G2> the current device holds at once (CUs x occupancy; queried once per device and form).  The kernel's
 // barrier only completes if a whole group is resident, and two such launches may run side by side (two streams), each stuck with LESS than a
 // group resident only while free slots remain -- so a group is limited to HALF of this figure (advisor, round 5: a CPX partition, a CU mask or a
 // smaller part holds far fewer than the 1024 / 768 blocks of a whole MI355X, and the launcher used to assume them).  0 if the query fails.
-static int fused_resident_blocks(bool g2) {
-    static int cache[16][2];                 // 0 = not asked yet, -1 = the query failed
+static int fused_resident_blocks(int form) {          // 0: in_bwd_fused8_kernel<false>, 1: <true> (pooled), 2: in_bwd_fusedg_kernel<2, 2, 4>, 3: <8, 8, 3>
+    static int cache[16][4];                 // 0 = not asked yet, -1 = the query failed
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-    int v = __atomic_load_n(&cache[dev][g2], __ATOMIC_RELAXED);
+    int v = __atomic_load_n(&cache[dev][form], __ATOMIC_RELAXED);
     if (v == 0) {
         int cus = 0, per_cu = 0;
         hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
-            e = g2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<true>, 256, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<false>, 256, 0);
+            e = form == 1   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<true>, 256, 0)
+                : form == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fused8_kernel<false>, 256, 0)
+                : form == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fusedg_kernel<2, 2, 4>, 256, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, in_bwd_fusedg_kernel<8, 8, 3>, 256, 0);
         if (e != hipSuccess) (void)hipGetLastError();
         v = (e == hipSuccess && cus > 0 && per_cu > 0) ? cus * per_cu : -1;
-        __atomic_store_n(&cache[dev][g2], v, __ATOMIC_RELAXED);
+        __atomic_store_n(&cache[dev][form], v, __ATOMIC_RELAXED);
     }
     return v > 0 ? v : 0;
 }
@@ -1338,10 +1582,41 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         // pooled form: tiles of (256 / Wt) rows x Wt = min(w, 128) columns
         const int wt = w < 128 ? w : 128;
         const bool g2_tiles = cb == 64 && wt >= 2 && (wt & (wt - 1)) == 0 && w % wt == 0 && 256 % wt == 0 && (256 / wt) % 2 == 0 && h % (256 / wt) == 0;
-        if (fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && cb_ok && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 && lddz % 8 == 0 &&
-            (!g2 || ldg2 % 8 == 0) && hw % slice == 0 && hw / slice <= shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES) && batch <= 65535 && (!g2 || g2_tiles) &&
-            fscr_n >= fused_scratch_doubles(batch, hw, c) && 2 * (hw / slice) <= fused_resident_blocks(g2 != nullptr)) {
-            const int ncb = c / cb;
+        const bool base_ok = fscr && shm_tune(SHM_TUNE_ELEM_FUSED_BWD) && dtype == SHM_BF16 && !r1 && cb_ok && c <= 1024 && ldg1 % 8 == 0 && lda % 8 == 0 &&
+                             lddz % 8 == 0 && (!g2 || ldg2 % 8 == 0) && batch <= 65535 && fscr_n >= fused_scratch_doubles(batch, hw, c);
+        const int max_slices = shm_tune(SHM_TUNE_ELEM_FUSED_MAX_SLICES);
+        const int hold = shm_tune(SHM_TUNE_ELEM_FUSED_HOLD);          // 0 automatic, 1 the round-5 kernel only (g and a held), 2 the g-held kernel only
+        const int ncb = c / cb;
+        const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
+        // round 6: g held, a streamed twice; slices of 32768 / CB pixels (sixteen pixel slots per thread), half the blocks per group.  Groups of up
+        // to 512 blocks where twice that fits the device (the 512 x 512 x 64 maps of BASELINE configs[3]): the knob's default 256 bounds the round-5
+        // kernel, this one takes 2 x its value
+        // Measured (tools/probes/in_bwd_fusedg_ab.py, n = 40 / 160): it wins where a group has many blocks -- 256 x 256 x 64: 287 -> 252 us, n = 160:
+        // 1072 -> 879 us -- and loses on the smaller maps, whose short groups do not cover its two extra round trips (128 x 128 x 128: 122 -> 147 us):
+        // automatic dispatch takes it from 256 slices of the 8-slot kind per group on.
+        const int slice16 = 2 * slice;
+        const int fgv = shm_tune(SHM_TUNE_ELEM_FUSED_GVARIANT);
+        if (base_ok && hold != 1 && !g2 && hw % slice16 == 0 && (hold == 2 || hw / slice >= 256) && hw / slice16 <= 2 * max_slices &&
+            2 * (hw / slice16) <= fused_resident_blocks(fgv == 1 ? 3 : 2)) {
+            const int bpi = hw / slice16;
+            // ONE scratch layout for both kernels (the caller's buffer is "zero behind the partial rows" whichever kernel ran last): means, counters
+            // and flags sit behind the rows region of the 16384 / CB-pixel slicing; this kernel's rows fill half of it
+            float* const fres = (float*)(fscr + fused_row_doubles(batch, (size_t)hw * cb / 16384, c));
+            unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);
+            unsigned* const ferr = fsync + (size_t)batch * ncb * SHM_FUSED_SYNC_WORDS;
+            const dim3 gridf(bpi, ncb, batch);
+            const unsigned arrivals = gridf.x + (shm_tune(SHM_TUNE_ELEM_FUSED_TEST_STALL) ? 1u : 0u);
+            if (fgv == 1) hipLaunchKernelGGL((in_bwd_fusedg_kernel<8, 8, 3>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
+            else hipLaunchKernelGGL((in_bwd_fusedg_kernel<2, 2, 4>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
+            shm_set_last_kernel(fgv == 1 ? "in_bwd_fusedg_kernel<8, 8, 3>" : "in_bwd_fusedg_kernel<2, 2, 4>");
+            SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);
+            if (dbias) {
+                hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, (double*)nullptr, keep);
+                SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
+            }
+            return SHM_OK;
+        }
+        if (base_ok && hold != 2 && hw % slice == 0 && hw / slice <= max_slices && (!g2 || g2_tiles) && 2 * (hw / slice) <= fused_resident_blocks(g2 ? 1 : 0)) {
             float* const fres = (float*)(fscr + fused_row_doubles(batch, hw / slice, c));
             unsigned* const fsync = (unsigned*)(fres + (size_t)batch * c * 2);
             unsigned* const ferr = fsync + (size_t)batch * ncb * SHM_FUSED_SYNC_WORDS;
@@ -1350,7 +1625,6 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
             if (g2) hipLaunchKernelGGL((in_bwd_fused8_kernel<true>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
             else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
             shm_set_last_kernel(g2 ? "in_bwd_fused8_kernel<true>" : "in_bwd_fused8_kernel<false>");
-            const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
             SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);
             if (dbias) {       // (the two sum planes in front of the staging were not used: nothing to clear)
                 hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, (double*)nullptr, keep);

@@ -371,6 +371,11 @@ def set_abort_words(dev_word, host_word):
     check(lib().shm_set_abort_words(_p(dev_word), _p(host_word)), "shm_set_abort_words")
 
 
+def set_clock_probe(dev2):
+    """shm_set_clock_probe: dev2 = an int64 CUDA tensor of two elements (or None)."""
+    check(lib().shm_set_clock_probe(_p(dev2)), "shm_set_clock_probe")
+
+
 def in_bwd_fused_doubles(batch, hw, c):
     """SHM_IN_BWD_FUSED_DOUBLES: float64 elements of the one-pass form's scratch (per-block partial rows, means, counters and flags)."""
     cb = min(c, 64)
@@ -386,7 +391,7 @@ def in_bwd(g1, ldg1, g2, ldg2, a, lda, stats, red, dz, lddz, dbias, batch, h, w,
     def nb():
         # bytes of the path the call took: the one-pass form reads g1 [+ g2 / 4] and a once and writes dz; reduce + apply read g and a twice
         # (round-5 advisor: three passes were counted for every call, understating the two-pass calls)
-        return (rd if last_kernel().startswith("in_bwd_fused8") else 2 * rd) + _tb(dz, e)
+        return (rd if last_kernel().startswith("in_bwd_fused") else 2 * rd) + _tb(dz, e)
 
     def run():
         if fused is not None:

@@ -155,6 +155,7 @@ def test_group_must_fit_the_device_twice():
     ops = _ops()
     rng = np.random.default_rng(1)
     ops.set_tuning("elem.fused_max_slices", 512)
+    ops.set_tuning("elem.fused_hold", 1)             # the kernel that holds g and a (the g-held one halves the group: tests/test_in_bwd_fused_gpu.py)
     for pool, expect_fused in ((False, True), (True, False)):
         n, h, w, c = 1, 256, 512, 64              # 131072 pixels = 512 slices of 256
         a = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).cuda().to(BF)

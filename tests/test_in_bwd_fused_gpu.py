@@ -8,7 +8,8 @@ of a sample meet at a per-sample barrier.  Checked here:
   * against a float64 restatement of the InstanceNorm + LeakyReLU backward;
   * the scratch is clean again on return (means, both counters and the flags of every sample, the timeout word), and there are no float
     atomics: repeated calls on one scratch give the same bits for dz and the bias gradient;
-  * shapes the form does not take (ragged maps, more than 256 slices per sample, fp32) run the two passes, and say so in shm_last_kernel.
+  * shapes the form does not take (ragged maps, more slices per group than twice fit the chip, fp32) run the two passes, and say so in shm_last_kernel;
+  * round 6: in_bwd_fusedg_kernel (the gradient held in registers, the activation streamed twice) on the same contract and the same scratch.
 """
 import numpy as np
 import pytest
@@ -94,7 +95,9 @@ def test_fused_matches_two_passes_and_float64(n, h, c, pool, gshift):
     assert "fused" not in k0, k0
     ops.set_tuning("elem.fused_bwd", 1)
     z1, b1, k1 = _run(a, g, g2, stats, n, h, c, scratch)
-    assert k1 == ("in_bwd_fused8_kernel<true>" if pool else "in_bwd_fused8_kernel<false>"), k1
+    # automatic dispatch: the g-held kernel (round 6) from 256 eight-slot slices per group on, the kernel that holds g and a below
+    big = not pool and h * h * min(c, 64) // 16384 >= 256
+    assert k1 == ("in_bwd_fused8_kernel<true>" if pool else "in_bwd_fusedg_kernel<2, 2, 4>" if big else "in_bwd_fused8_kernel<false>"), k1
     assert _clean(scratch, n, h, c)
     # the two forms round the same float32 value to bf16 unless the last bits of the two means differ: a handful of one-ulp differences
     diff = (z0.float() - z1.float()).abs()
@@ -123,8 +126,66 @@ def test_fused_without_bias_gradient():
     assert _clean(scratch, n, h, c)
 
 
+# Round 6: in_bwd_fusedg_kernel -- g held in registers, a streamed twice, 16 pixel slots per thread.  Forced ("elem.fused_hold" = 2) on every shape that
+# has whole 32768 / CB-pixel slices, both register-budget forms, against the kernel that holds both tensors (same scratch: ONE layout), the two passes
+# and float64; the 512 x 512 x 64 map of BASELINE configs[3] (512 blocks per group) is taken automatically.
+GSHAPES = [(3, 64, 64), (2, 256, 64), (1, 512, 64), (2, 128, 128), (3, 32, 256), (2, 32, 512), (2, 64, 32), (1, 64, 8), (41, 32, 64)]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("gshift", [0.0, 25.0])
+@pytest.mark.parametrize("n,h,c", GSHAPES)
+def test_g_held_kernel_matches_the_other_forms(n, h, c, gshift, variant):
+    ops = _ops()
+    rng = np.random.default_rng(17 + n + h + c)
+    a, g, _, stats = _operands(rng, n, h, c, False, gshift)
+    scratch = torch.zeros(ops.in_bwd_fused_doubles(n, h * h, c), dtype=torch.float64, device="cuda")
+    ops.set_tuning("elem.fused_gvariant", variant)
+    name = "in_bwd_fusedg_kernel<8, 8, 3>" if variant else "in_bwd_fusedg_kernel<2, 2, 4>"
+    groups_fit = 2 * (h * h * min(c, 64) // 32768) <= (768 if variant else 1024)          # twice a group's blocks on a whole MI355X
+    ops.set_tuning("elem.fused_hold", 2)
+    zg, bg, kg = _run(a, g, None, stats, n, h, c, scratch)
+    if not groups_fit:
+        assert "fusedg" not in kg, kg
+        return
+    assert kg == name, kg
+    assert _clean(scratch, n, h, c)
+    ops.set_tuning("elem.fused_hold", 1)                       # the round-5 kernel on the SAME scratch (where it takes the shape)
+    z8, b8, k8 = _run(a, g, None, stats, n, h, c, scratch)
+    assert _clean(scratch, n, h, c)
+    ops.set_tuning("elem.fused_bwd", 0)
+    z0, b0, k0 = _run(a, g, None, stats, n, h, c, scratch)
+    assert "fused" not in k0
+    for zo, bo in ((z8, b8), (z0, b0)):
+        diff = (zo.float() - zg.float()).abs()
+        assert float((diff > 0).float().mean()) < 0.02
+        assert float(diff.double().norm() / zo.double().norm()) < 2e-3
+        assert float((bo - bg).abs().max()) <= 2e-3 * float(bo.abs().max() + 1.0)
+    zr, br = _reference(a, g, None, stats, n, h, c)
+    assert float((zg.double() - zr).norm() / zr.norm()) < 4e-3
+    assert float((bg - br).abs().max()) <= 4e-3 * float(zr.abs().sum((0, 1, 2)).max())
+    ops.set_tuning("elem.fused_bwd", 1)
+    ops.set_tuning("elem.fused_hold", 2)
+    z2, b2, _ = _run(a, g, None, stats, n, h, c, scratch)        # bitwise repeatable, also right behind the other kernels on this scratch
+    assert torch.equal(z2, zg) and torch.equal(b2, bg)
+    assert _clean(scratch, n, h, c)
+
+
+def test_g_held_kernel_is_the_automatic_choice_on_the_largest_maps():
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    for n, h, c, want in ((1, 512, 64, "in_bwd_fusedg_kernel<2, 2, 4>"), (2, 256, 64, "in_bwd_fusedg_kernel<2, 2, 4>"), (2, 256, 128, "in_bwd_fusedg_kernel<2, 2, 4>"),
+                          (2, 128, 128, "in_bwd_fused8_kernel<false>"), (2, 64, 256, "in_bwd_fused8_kernel<false>")):
+        a, g, _, stats = _operands(rng, n, h, c, False)
+        scratch = torch.zeros(ops.in_bwd_fused_doubles(n, h * h, c), dtype=torch.float64, device="cuda")
+        z, b, k = _run(a, g, None, stats, n, h, c, scratch)
+        assert k == want, (n, h, c, k)
+        zr, _ = _reference(a, g, None, stats, n, h, c)
+        assert float((z.double() - zr).norm() / zr.norm()) < 4e-3 and _clean(scratch, n, h, c)
+
+
 @pytest.mark.parametrize("n,h,c,why", [(2, 24, 64, "ragged: 576 pixels are not whole 256-pixel slices"),
-                                       (1, 512, 64, "1024 slices per sample: more than a resident sample group"),
+                                       (1, 1024, 64, "4096 / 2048 slices per group: more than a resident group"),
                                        (1, 64, 8, "pooled form: 64-channel groups only"),
                                        (2, 8, 64, "a 64-pixel map is smaller than one slice"),
                                        (2, 32, 24, "3 channel lanes do not divide a block")])

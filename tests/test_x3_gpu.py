@@ -311,3 +311,93 @@ def test_x3_forward_with_a_normalising_source(n, h, cin, cout, part):
     assert k3p == k3 and torch.equal(y3, y3p)
     y1, k1 = run(0, True)
     assert "x3" not in k1 and rel_l2(host(y3), host(y1)) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the truncation split is sign-biased -- every plane holds a value of the operand's sign, so the dropped products
+# x1 w2 + x2 w1 + x2 w2 (<= 2 * 2^-24 + 2^-32 of x w) all have the sign of x w.  On operands of ONE sign nothing cancels: the tests below drive
+# the step's longest reduction and the deepest forward product with same-sign operands and hold the six-product kernels to the exact-fp32
+# kernels' own error plus that bias, element by element.
+
+def _wgrad_ref_f64(x, dy):
+    """float64 weight gradient of a 3x3 SAME convolution on the GPU, tap by tap as [cin, N H W] x [N H W, cout] products (reference arithmetic
+    for a test, not product code).  x [n,h,w,cin], dy [n,h,w,cout] float32 CUDA tensors -> [3,3,cin,cout] float64."""
+    n, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    xp = torch.zeros((n, h + 2, w + 2, cin), dtype=torch.float64, device=x.device)
+    xp[:, 1:-1, 1:-1] = x.double()
+    d = dy.double().reshape(-1, cout)
+    out = torch.empty((3, 3, cin, cout), dtype=torch.float64, device=x.device)
+    for ky in range(3):
+        for kx in range(3):
+            out[ky, kx] = xp[:, ky:ky + h, kx:kx + w].reshape(-1, cin).t() @ d
+    return out
+
+
+def test_x3_wgrad_same_sign_operands_over_the_longest_reduction():
+    """n = 40, 256 x 256, 64 -> 64 (the cyclic pass's first-level layers: K = 40 * 65536 = 2.6 M products per weight), x in [0, 1), dY >= 0."""
+    g = torch.Generator(device="cuda").manual_seed(601)
+    n, h, cin, cout = 40, 256, 64, 64
+    x = torch.rand((n, h, h, cin), device="cuda", generator=g)
+    dy = torch.rand((n, h, h, cout), device="cuda", generator=g) * 0.01
+    ref = _wgrad_ref_f64(x, dy)
+    got3, k3 = _run(x, None, dy, cin, cout, n, h, h, 1)
+    got1, k1 = _run(x, None, dy, cin, cout, n, h, h, 0)
+    assert k3 == _x3_name(h) and k1 == "wgrad_halo_kernel", (k3, k1)
+    r3 = ((got3.double() - ref) / ref).cpu().numpy()            # every reference element is a sum of positive terms
+    r1 = ((got1.double() - ref) / ref).cpu().numpy()
+    bias_bound = 2.0 * 2.0 ** -24 + 2.0 ** -32
+    print(f"K = {n * h * h}: relative error  six bf16 products: mean {r3.mean():+.2e} max |.| {np.abs(r3).max():.2e};  exact-fp32 MFMA: mean {r1.mean():+.2e} "
+          f"max |.| {np.abs(r1).max():.2e};  dropped-product bound {bias_bound:.2e}")
+    # the split only ever loses magnitude (bias <= 0 up to accumulation rounding) and never more than the dropped products
+    assert np.abs(r3).max() <= np.abs(r1).max() + bias_bound + 2.0 ** -24
+    assert -bias_bound - 2.0 ** -24 <= r3.mean() <= np.abs(r1.mean()) + 2.0 ** -24
+    # and far inside the fp32 dot-product bound K u sum |x dy| the contract allows
+    assert np.abs(r3).max() < 1e-5
+
+
+def test_x3_forward_same_sign_operands_deepest_product():
+    """512 -> 512 (K = 4608 per output, the generator's deepest 3x3 product), x >= 0, w >= 0, no bias: the same element-wise statement."""
+    ops = _ops()
+    rng = np.random.default_rng(602)
+    n, h, cin, cout = 2, 32, 512, 512
+    x = rng.random((n, h, h, cin))
+    w = rng.random((3, 3, cin, cout)) * 0.02
+    from util import conv_ref
+    ref = conv_ref(x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64), 1)
+    ops.set_tuning("tapgemm.variant", "halo128_st")
+    res = {}
+    for split in (1, 0):
+        ops.set_tuning("conv.f32_split", split)
+        y = torch.empty((n, h, h, cout), device="cuda")
+        ops.conv2d_fwd(dev(x), None, 0, cin, 0, _wk(w, cin), None, y, cout, n, h, h, cin, cout, 3, 1, 1.0)
+        res[split] = ((host(y) - ref) / ref, ops.last_kernel())
+    (r3, k3), (r1, k1) = res[1], res[0]
+    assert k3 == "tapgemm_halo_x3_kernel<false, 128>" and "x3" not in k1, (k3, k1)
+    bias_bound = 2.0 * 2.0 ** -24 + 2.0 ** -32
+    print(f"K = {9 * cin}: relative error  six bf16 products: mean {r3.mean():+.2e} max |.| {np.abs(r3).max():.2e};  exact-fp32 MFMA: mean {r1.mean():+.2e} "
+          f"max |.| {np.abs(r1).max():.2e}")
+    assert np.abs(r3).max() <= np.abs(r1).max() + bias_bound + 2.0 ** -24
+    assert -bias_bound - 2.0 ** -24 <= r3.mean() <= np.abs(r1.mean()) + 2.0 ** -24
+
+
+@pytest.mark.parametrize("scale_log2", [-100, -120])
+def test_x3_planes_near_the_bottom_of_the_exponent_range(scale_log2):
+    """bf16 has fp32's exponent range, but a third plane sits 16 binades below its operand: for |x| < 2^-110 it is a bf16 denormal (or zero) and
+    the split degrades towards two planes (16 bits).  Documented behaviour (include/shmgan_hip.h): the result stays finite and within 2^-14
+    of the float64 product; operands of the step (activations O(1), gradients > 1e-12) are 80 binades away from this."""
+    rng = np.random.default_rng(603)
+    n, h, cin, cout = 2, 16, 64, 64
+    s = 2.0 ** scale_log2
+    x = (rng.standard_normal((n, h, h, cin)) * s).astype(np.float32)
+    dy = rng.standard_normal((n, h, h, cout)).astype(np.float32)
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(x.astype(np.float64)), wt, 1), wt, nchw(dy.astype(np.float64)))
+    got3, k3 = _run(dev(x), None, dev(dy), cin, cout, n, h, h, 1)
+    got1, _ = _run(dev(x), None, dev(dy), cin, cout, n, h, h, 0)
+    assert k3 == _x3_name(h)
+    e3, e1 = rel_l2(host(got3) / s, ref.numpy() / s), rel_l2(host(got1) / s, ref.numpy() / s)
+    print(f"|x| ~ 2^{scale_log2}: rel-L2 six bf16 products {e3:.2e}, exact-fp32 MFMA {e1:.2e}")
+    assert bool(torch.isfinite(got3).all()) and e3 < 2.0 ** -14
+    if scale_log2 >= -100:
+        assert e3 < TOL                         # the third plane is still a normal bf16 number: the full contract

@@ -6,7 +6,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from shmgan_amd import ops
 
-n, h, c = int(sys.argv[1]) if len(sys.argv) > 1 else 40, 256, 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+h, c = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 64)
+only = sys.argv[4] if len(sys.argv) > 4 else ""        # substring filter on the row names
 dev = "cuda"
 
 
@@ -45,6 +47,16 @@ for dt in (torch.float32, torch.bfloat16):
         ("lrelu_bwd (no dbias)", lambda: ops.lrelu_bwd(g, c, a, c, out, c, None, n * h * h, c, 0.2), 3 * es),
         ("avgpool2", lambda: ops.avgpool2_fwd(a, c, g2, c, n, h, h, c), 1.25 * es),
     ]
+    gs = ops.GSUM_SLOTS
+    gred = torch.zeros(gs * n * c * 2, dtype=torch.float64, device=dev)
+    gredp = torch.zeros(gs * n * c * 2, dtype=torch.float64, device=dev)
+    dstage = torch.zeros(n * c, dtype=torch.float64, device=dev)
+    rows += [
+        ("in_bwd_apply (gsum, dbias)", lambda: ops.in_bwd_apply(g, c, None, 0, a, c, stats, beta, gred, None, dstage, out, c, db, n, h, h, c, 0.2), 3 * es),
+        ("in_bwd_apply (gsum, g2)", lambda: ops.in_bwd_apply(g, c, g2, c, a, c, stats, beta, gred, gredp, dstage, out, c, db, n, h, h, c, 0.2), 3.25 * es),
+    ]
     for name, fn, bpe in rows:
+        if only not in name:
+            continue
         us = timeit(fn)
         print(f"{str(dt):16s} {name:28s} {us:8.1f} us  {nel * bpe / us / 1e3:7.0f} GB/s")
