@@ -76,8 +76,9 @@ const char* shm_last_kernel(void);
  *   "wgrad.blocks"              split-K block target, 0 automatic (1024 fp32 / 256 bf16)
  *   "wgrad.bf16_rows"           bf16 halo weight gradient: pixel rows per LDS stage, 0 automatic (4 when the map height allows), 2, 4
  *   "wgrad.f32_split"           fp32 3x3 unit-stride weight gradient (the halo kernel's shapes, plain and SHM_NORM_EXACT sources): 1 = six v_mfma_f32_32x32x16_bf16
- *                               products of the exact three-plane bf16 splits of x and dY with fp32 accumulation (wgrad_halo_x3_kernel; rounds like an
- *                               fp32 dot product, rel-L2 ~1e-7), 0 (default) = exact-fp32 MFMA.  Opt-in: bench.py --dtype f32x3
+ *                               products of the exact three-plane bf16 splits of x and dY with fp32 accumulation (wgrad_halo_x3_kernel; rel-L2 ~2.5e-7
+ *                               on random-sign operands; NOT a bit-faithful fp32 dot product -- see "conv.f32_split" below), 0 (default) = exact-fp32 MFMA.
+ *                               Opt-in: bench.py --dtype f32x3
  *   "conv.f32_split"            fp32 3x3 unit-stride forward / input gradient: 1 = six bf16 MFMA products of exact three-plane splits where
  *                               the shape fits (tapgemm_halo_x3_kernel), 0 (default) = exact-fp32 MFMA.  Opt-in
  *   "elem.fused_bwd"            bf16 shm_in_bwd: 1 (default) = the one-pass form where shm_in_bwd_fused_scratch was given and the shape fits, 0 = two passes
@@ -287,8 +288,12 @@ int shm_set_clock_probe(unsigned long long* dev2);
 
 /* Opt-in fp32 arithmetic from bf16 MFMAs for the 3x3 unit-stride forward / input-gradient layers: tuning "conv.f32_split" = 1 (round 5,
  * csrc/conv_fwd_x3.hip; the weight gradient's twin is "wgrad.f32_split").  Every fp32 operand is split EXACTLY into three bf16 planes and the six
- * plane products with i + j <= 2 accumulate in fp32 -- the result rounds like an fp32 dot product (rel-L2 ~4e-7 against float64, the exact-fp32
- * MFMA's own figure).  shm_conv2d_fwd / shm_conv2d_in_fwd(_norm, SHM_NORM_EXACT) / shm_conv2d_dgrad and their _gsum forms then run
+ * plane products with i + j <= 2 accumulate in fp32: rel-L2 ~4e-7 against float64 on random-sign operands, the exact-fp32 MFMA's own figure.
+ * Accuracy limits (round 6, tests/test_x3_gpu.py): the bf16 MFMA truncates what falls below its alignment window when it adds its products to the
+ * accumulator, ~0.3-0.5 ulp per accumulation step and always towards zero -- on operands of ONE sign the error is a one-sided shrink that grows with
+ * the accumulation chain: -5.3e-6 relative on the step's longest weight-gradient reduction (K = 2.6 M, ~320 steps per split-K slab; exact-fp32 MFMA:
+ * 2.4e-7) and -1.1e-5 on the deepest forward product (K = 4608), i.e. outside the 1e-5 single-op bound there; operands below 2^-110 lose the third
+ * plane (7e-5 at 2^-120).  The step's own operands (random-sign weights and gradients, O(1) activations) stay at the exact kernels' figures.  shm_conv2d_fwd / shm_conv2d_in_fwd(_norm, SHM_NORM_EXACT) / shm_conv2d_dgrad and their _gsum forms then run
  * tapgemm_halo_x3_kernel where the launcher would have taken a static-tap halo or weights-in-registers kernel: fp32 tensors, K % 32 == 0, outputs
  * below 4 GiB, more than 64 output channels or a map height that is a multiple of 32.  Nothing else changes: no extra arguments, no workspace. */
 /* pooled = AveragePooling2D(2)(InstanceNorm apply(a)) WITHOUT writing the normalised tensor: the encoder level's skip consumers

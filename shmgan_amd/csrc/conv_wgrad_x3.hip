@@ -6,8 +6,10 @@
 // fast.  Every fp32 operand splits EXACTLY into three bf16 planes by truncation -- x0 = x & 0xffff0000, r = x - x0 (exact), x1 = r & 0xffff0000,
 // x2 = r - x1 (eight significant bits left: a bf16 value as it stands) -- and the product of two fp32 numbers is the sum of the nine plane
 // products, of which the six with i + j <= 2 carry everything above 2^-24 of it.  bf16 x bf16 is exact in the MFMA's fp32 accumulators, so
-// the six-product sum rounds like an fp32 dot product (rel-L2 against float64 on a 512 x 576 x 128 product: 1.2e-7, the f32 MFMA's own 3.1e-7;
-// LABNOTES 10.8): six MFMAs of 32 cycles instead of eight of 64.
+// the six-product sum agrees with an fp32 dot product on random-sign operands (rel-L2 against float64 on a 512 x 576 x 128 product: 1.2e-7, the f32
+// MFMA's own 3.1e-7; LABNOTES 10.8): six MFMAs of 32 cycles instead of eight of 64.  NOT bit-faithful fp32 (round 6): the bf16 MFMA truncates below its
+// alignment window on every accumulation, towards zero -- on one-signed operands a one-sided shrink of ~0.3 ulp per step of the chain, -5.3e-6 over
+// the step's longest reduction (tests/test_x3_gpu.py::test_x3_wgrad_same_sign_operands_over_the_longest_reduction; exact-fp32 MFMA: 2.4e-7).
 //
 // Structure = wgrad_halo_bf16_kernel<2> (block: 64 ci x 64 co x 9 taps over a slice of 2 x 16-pixel patches, wave w the 32 x 32 sub-tile
 // (w >> 1, w & 1) of every tap, operands by ds_read_b64_tr_b16 from [pixel][64 channels] rows with the half-swap swizzle, deterministic

@@ -143,6 +143,9 @@ class ShmGANwithSSpecSeg:
         # pass runs under the other's convolution) LOSES 2 ms -- a single stream already fills the launch tails
         import os
         self.forward_parts = int(os.environ.get("SHM_FORWARD_PARTS", "1"))
+        # the D-loss backward on the second stream (train_step): measured on one box, A/B by the variable, bf16 22.48 -> 22.25 ms, S = 512 B = 4
+        # 42.79 -> 42.58, B = 32 79.3 -> 78.6; fp32 114.2 -> 114.2 (MFMA bound either way) -- default on in bf16, off in fp32
+        self.d_bwd_on_lane = os.environ.get("SHM_D_BWD_LANE", "1" if self.compute_dtype != torch.float32 else "0") == "1"
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
     # ------------------------------------------------------------------ workspace
@@ -438,7 +441,14 @@ class ShmGANwithSSpecSeg:
         # ---- D backward (weights) then its all-reduce overlapped with everything below
         if self.before_backward is not None:
             self.before_backward()
-        D.backward_params(drf_d, dcls_d)
+        # The D-loss backward (weights only) depends on nothing below and nothing below depends on it: the whole chain -- InstanceNorm backward,
+        # stride-2 input gradients, weight gradients -- goes to the second stream, in front of the generator's weight gradients, and the main
+        # stream goes straight on to the G-loss backward (round 6; SHM_D_BWD_LANE=0 keeps it on the main stream).  Its buffers are keyed by the
+        # batch (12 B here, 6 B for the data gradient below), the split-K workspace is used in lane order.
+        if self.d_bwd_on_lane and lane.stream is not None:
+            lane.submit(lambda: D.backward_params(drf_d, dcls_d))
+        else:
+            D.backward_params(drf_d, dcls_d)
         ev_d = self._allreduce_async(D.P.grad, after=self._get_lane().event(), tag="d")
 
         # ---- G-loss gradient through D (data gradient only), then G backward
