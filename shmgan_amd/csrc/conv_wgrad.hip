@@ -1728,7 +1728,9 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.cin_ld = cin_ld;
         hgs.cin = cin;
         hgs.cout = cout;
-        hgs.npatch = batch * (ho / 2) * (wo / 8);
+        // "wgrad.f32_split" (opt-in, round 6): the six-bf16-product form on patches of 2 x 16 output pixels (conv_wgrad_x3.hip, S2)
+        const bool x3s2 = shm_tune(SHM_TUNE_WGRAD_F32_SPLIT) == 1 && wo % 16 == 0 && !want_nm;
+        hgs.npatch = batch * (ho / 2) * (wo / (x3s2 ? 16 : 8));
         int nsh = ns < hgs.npatch ? ns : hgs.npatch;
         hgs.patches_per_split = shm_cdiv(hgs.npatch, nsh);
         nsh = shm_cdiv(hgs.npatch, hgs.patches_per_split);
@@ -1736,8 +1738,13 @@ extern "C" int shm_conv2d_wgrad_partial(const void* x, const void* x2, int c1, i
         hgs.x2bytes = a.x2bytes;
         hgs.dybytes = a.dybytes;
         ns = nsh;
-        hipLaunchKernelGGL((wgrad_halo_kernel<0, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
-        shm_set_last_kernel("wgrad_halo_kernel<0, true>");
+        if (x3s2) {
+            const int rc = shm_wgrad_x3_launch(hgs, cin, cout, nsh, 2, st, true);
+            if (rc != SHM_OK) return rc;
+        } else {
+            hipLaunchKernelGGL((wgrad_halo_kernel<0, true>), dim3(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsh), dim3(256), 0, st, hgs);
+            shm_set_last_kernel("wgrad_halo_kernel<0, true>");
+        }
     } else if (halo_ok) {
         const bool thin = thin_ok;
         WgradHaloArgs hgs{};

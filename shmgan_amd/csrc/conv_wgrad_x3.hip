@@ -26,12 +26,20 @@
 
 // NM: the x source a.ntpart is the UN-normalised activation of an InstanceNorm block (SHM_NORM_EXACT, as wgrad_halo_kernel<1>): shm_in_norm on the in-image
 // pixels of the stage registers before the split; the block's 64 (mean, inv, beta) triples of the current sample sit in LDS behind the plane images
-template <int R, bool NM = false>
+// S2 (round 6): the stride-2 layers (ShmGANwithSSpecSeg.py:353-361 the discriminator's convolutions, :298-319 the Conv2DTranspose weight gradients with the
+// operands' roles swapped) -- patches of 2 x 16 OUTPUT pixels, a 5 x 33 input halo kept as wgrad_halo8_bf16_kernel<1> keeps it: per halo row an even run
+// (columns 0, 2, .., 32 at LDS rows 0 .. 16) and an odd run (columns 1, 3, .., 31 at rows 20 .. 35), so that the sixteen pixels of a K step are sixteen
+// consecutive LDS rows for every kw (kw = 1: the odd run, kw = 2: the even run one row on).  TF SAME padding of an even map: nothing before the first
+// row / column, one zero row / column behind the last (out-of-image = out-of-range offset = zeros).
+template <int R, bool NM = false, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloArgs a) {
-    constexpr int PW = 16, HP = 20;                     // patch R x 16; halo R + 2 rows, LDS pitch 20 (18 valid)
-    constexpr int NHR = (R + 2) * HP, NPX = R * PW;     // R = 2: 80 halo rows, 32 dY rows
+    static_assert(!S2 || (R == 2 && !NM), "stride 2: stages of two output rows, plain sources");
+    constexpr int PW = 16, HP = 20;                     // patch R x 16; S1: halo R + 2 rows, LDS pitch 20 (18 valid); S2: pitch of the even run
+    constexpr int HRP = S2 ? 36 : HP;                   // LDS rows per halo row
+    constexpr int NHROW = S2 ? 2 * R + 1 : R + 2;
+    constexpr int NHR = NHROW * HRP, NPX = R * PW;      // S1, R = 2: 80 halo rows, 32 dY rows; S2: 180 halo rows
     constexpr int XP = NHR * 64, DP = NPX * 64;         // bf16 elements per x plane / dY plane
-    constexpr int NXI = NHR / 8, NDI = NPX / 8;         // items of 8 rows x 64 channels: 10 + 4
+    constexpr int NXI = (NHR + 7) / 8, NDI = NPX / 8;   // items of 8 rows x 64 channels: 10 + 4 (S2: 23 + 4; the last x item's rows 180 .. 183 are not written)
     constexpr int NIT = NXI + NDI, NJ = (NIT + 3) / 4;  // items per wave: waves below NIT % 4 (or all) take NJ, the others NJ - 1
     extern __shared__ __attribute__((aligned(1024))) unsigned short smem[];       // [x plane 0..2][dY plane 0..2][NM: mean, inv, beta x 64]
     [[maybe_unused]] float* const tab = (float*)(smem + 3 * XP + 3 * DP);
@@ -61,9 +69,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
                                               : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
 
-    int n, pr, pc;
+    const int ho = S2 ? a.h / 2 : a.h, wo = S2 ? a.w / 2 : a.w;
+    int n, pr, pc;                                      // patch origin in OUTPUT pixels
     {
-        const int ppc = a.h / R, ppi = ppc * (a.w / PW);           // patches numbered down the columns of an image, see wgrad_halo_kernel
+        const int ppc = ho / R, ppi = ppc * (wo / PW);             // patches numbered down the columns of an image, see wgrad_halo_kernel
         const int p = pid0 < a.npatch ? pid0 : 0;
         n = p / ppi;
         const int r = p - n * ppi;
@@ -78,12 +87,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
         unsigned bits;
         if (item < NXI) {
             const int hp = 8 * item + drow;
-            const int r_ = hp / HP, c_ = hp - r_ * HP;
-            off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 4u;
-            bits = !(xvalid && c_ < PW + 2) ? 16u : (r_ == 0 ? 1u : 0u) | (r_ == R + 1 ? 2u : 0u) | (c_ == 0 ? 4u : 0u) | (c_ == PW + 1 ? 8u : 0u);
+            if constexpr (S2) {
+                const int r_ = hp / HRP, t_ = hp - r_ * HRP;
+                const int c_ = t_ < HP ? 2 * t_ : 2 * (t_ - HP) + 1;
+                const bool ok = hp < NHR && (t_ < HP ? t_ <= PW : true);
+                off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 4u;
+                bits = !(xvalid && ok) ? 16u : (r_ == NHROW - 1 ? 2u : 0u) | (c_ == 2 * PW ? 8u : 0u);
+            } else {
+                const int r_ = hp / HP, c_ = hp - r_ * HP;
+                off0[j] = (unsigned)((r_ * a.w + c_) * ldX + ccX) * 4u;
+                bits = !(xvalid && c_ < PW + 2) ? 16u : (r_ == 0 ? 1u : 0u) | (r_ == R + 1 ? 2u : 0u) | (c_ == 0 ? 4u : 0u) | (c_ == PW + 1 ? 8u : 0u);
+            }
         } else {
             const int q = 8 * (item - NXI) + drow;
-            off0[j] = (unsigned)(((q >> 4) * a.w + (q & 15)) * a.lddy + coD) * 4u;
+            off0[j] = (unsigned)(((q >> 4) * wo + (q & 15)) * a.lddy + coD) * 4u;
             bits = (dvalid && item < NIT) ? 0u : 16u;
         }
         bm |= bits << (5 * j);
@@ -97,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
             spr = pr;
             spc = pc;
         }
-        const int org = (n * a.h + pr - 1) * a.w + (pc - 1);       // pixel index of halo (0,0)
-        const unsigned edges = 16u | (pr == 0 ? 1u : 0u) | (pr + R == a.h ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc + PW == a.w ? 8u : 0u);
-        const unsigned xb = (unsigned)(org * ldX) * 4u, db = (unsigned)(((n * a.h + pr) * a.w + pc) * a.lddy) * 4u;
+        const int org = S2 ? (n * a.h + 2 * pr) * a.w + 2 * pc : (n * a.h + pr - 1) * a.w + (pc - 1);       // input pixel index of halo (0,0)
+        const unsigned edges = 16u | ((!S2 && pr == 0) ? 1u : 0u) | (pr + R == ho ? 2u : 0u) | ((!S2 && pc == 0) ? 4u : 0u) | (pc + PW == wo ? 8u : 0u);
+        const unsigned xb = (unsigned)(org * ldX) * 4u, db = (unsigned)(((n * ho + pr) * wo + pc) * a.lddy) * 4u;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int item = wave + 4 * j;
@@ -111,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
             }
         }
         pr += R;
-        if (pr == a.h) {
+        if (pr == ho) {
             pr = 0;
             pc += PW;
-            if (pc == a.w) {
+            if (pc == wo) {
                 pc = 0;
                 ++n;
             }
@@ -168,9 +185,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
                 const bool isx = item < NXI;                   // wave-uniform
                 unsigned short* dst = smem + (isx ? item * 512 : 3 * XP + (item - NXI) * 512) + lane * 8;
                 const int ps = isx ? XP : DP;
-                *(u32x4*)(dst) = p0;
-                *(u32x4*)(dst + ps) = p1;
-                *(u32x4*)(dst + 2 * ps) = p2;
+                // S2: the x planes end inside the last item (180 rows = 22.5 items): its upper half belongs to the next plane
+                if (!S2 || !isx || 8 * item + drow < NHR) {
+                    *(u32x4*)(dst) = p0;
+                    *(u32x4*)(dst + ps) = p1;
+                    *(u32x4*)(dst + 2 * ps) = p2;
+                }
             }
         }
     };
@@ -188,8 +208,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
     int fa[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int row = fq + kw;
-        fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5));
+        // S1: kw shifts the row; S2: kw = 0 / 2 read the even run (2 = one row on), kw = 1 the odd run HP rows further (same bit 1: HP % 4 == 0)
+        const int row = fq + (S2 ? (kw == 2 ? 1 : 0) : kw);
+        fa[kw] = row * 64 + ((mi * 32 + fcol) ^ (((row >> 1) & 1) << 5)) + ((S2 && kw == 1) ? HP * 64 : 0);
     }
     const int fb = 3 * XP + fq * 64 + ((ni * 32 + fcol) ^ (((fq >> 1) & 1) << 5));
     auto compute = [&]() {
@@ -206,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
             for (int t = 0; t < 9; ++t) {
                 bf16x8 x[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) x[p] = tr_frag(smem + p * XP + fx[t % 3] + (qr + t / 3) * HP * 64);
+                for (int p = 0; p < 3; ++p) x[p] = tr_frag(smem + p * XP + fx[t % 3] + ((S2 ? 2 * qr : qr) + t / 3) * HRP * 64);
                 // the small products first
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], d[0], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], d[1], acc[t], 0, 0, 0);
@@ -250,9 +271,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgradHaloAr
     }
 }
 
-int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st) {
+int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st, bool stride2) {
     const dim3 grid(shm_cdiv(cin, 64), shm_cdiv(cout, 64), nsplit);
     const bool nm = hgs.nt != nullptr;               // SHM_NORM_EXACT source
+    if (stride2) {
+        constexpr unsigned kLds = (3u * 180 + 3u * 32) * 128u;       // 79.5 KiB: two blocks per CU, just
+        SHM_REQUIRE(!nm && rows == 2, SHM_E_SHAPE, "shm_conv2d_wgrad: the stride-2 x3 form takes plain sources and stages of two rows");
+        static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_halo_x3_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        SHM_REQUIRE(attr == hipSuccess, SHM_E_HIP, "shm_conv2d_wgrad: cannot reserve 79.5 KiB of LDS: %s", hipGetErrorString(attr));
+        hipLaunchKernelGGL((wgrad_halo_x3_kernel<2, false, true>), grid, dim3(256), kLds, st, hgs);
+        shm_set_last_kernel("wgrad_halo_x3_kernel<2, false, true>");
+        return SHM_OK;
+    }
     if (rows == 4) {
         constexpr unsigned kLds = (3u * (6 * 20) + 3u * (4 * 16)) * 128u + 768u;      // 69 KiB: two blocks per CU
         SHM_REQUIRE(!nm, SHM_E_SHAPE, "shm_conv2d_wgrad: the normalising x3 form runs stages of two rows");

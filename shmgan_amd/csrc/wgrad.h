@@ -63,4 +63,5 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* base) {
 
 // conv_wgrad_x3.hip ("wgrad.f32_split" = 1): the fp32 3x3 unit-stride weight gradient as six bf16 MFMA products of three-plane splits of x and dY.
 // hgs as for wgrad_halo_kernel<0> with patches of rows x 16 pixels (rows = 2 or 4); grid = (cin / 64, cout / 64, splits).
-int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st);
+// stride2: patches of 2 x 16 OUTPUT pixels of a 3x3 stride-2 layer on an even map (hgs as for wgrad_halo_kernel<0, true>, re-cut to that patch)
+int shm_wgrad_x3_launch(const WgradHaloArgs& hgs, int cin, int cout, int nsplit, int rows, hipStream_t st, bool stride2 = false);

@@ -145,6 +145,8 @@ class ShmGANwithSSpecSeg:
         self.forward_parts = int(os.environ.get("SHM_FORWARD_PARTS", "1"))
         # the D-loss backward on the second stream (train_step): measured on one box, A/B by the variable, bf16 22.48 -> 22.25 ms, S = 512 B = 4
         # 42.79 -> 42.58, B = 32 79.3 -> 78.6; fp32 114.2 -> 114.2 (MFMA bound either way) -- default on in bf16, off in fp32
+        self.d_fwd_on_lane = os.environ.get("SHM_D_FWD_LANE", "1" if self.compute_dtype != torch.float32 else "0") == "1"
+        self.img_loss_on_lane = os.environ.get("SHM_IMG_LOSS_LANE", "1" if self.compute_dtype != torch.float32 else "0") == "1"
         self.d_bwd_on_lane = os.environ.get("SHM_D_BWD_LANE", "1" if self.compute_dtype != torch.float32 else "0") == "1"
         self.style_factor = 1.0 / float(2 * 9 * self.image_size * self.image_size) ** 2   # as intended (finding 7)
 
@@ -393,14 +395,26 @@ class ShmGANwithSSpecSeg:
             attn_g = G.attention_forward(self.specular_candidate, B)
             attn_d = D.attention_forward(self.specular_candidate, B)
 
-        # ---- G(1)  SHM.py:517-538
         adt, PAD_C = self.compute_dtype, self.pad
+        # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
+        xd = A.get_slack("d/x16", (12 * B, S, S, D.in_pitch), adt, D.pad)          # one 16-byte chunk per pixel (Discriminator.in_pitch) + a K-row of slack
+        # The REAL half of the discriminator batch (D2, D4: SHM.py:563, 638-642) depends on no generator output: in bf16 its five convolution
+        # blocks run on the second stream beside the generator's forward passes (round 6); the heads wait for `ev_dreal`
+        ev_dreal = None
+        d_real_early = self.d_fwd_on_lane and lane.stream is not None and not (self.forward_parts > 1)
+        if d_real_early:
+            ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
+            for k in range(5):                                                                 # D(4) SHM.py:638-642
+                ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
+            D.start(xd, keep, [(0, B, 0), (6 * B, B, B)], attn_d)
+            lane.submit(lambda: D.trunk_rows(6 * B, 12 * B))
+            ev_dreal = lane.event()
+
+        # ---- G(1)  SHM.py:517-538
         gen_in = A.get("g1/in", (B, S, S, PAD_C), adt)
         ops.build_gen_input(ds, None, fmask, 0, gen_in, B, npix)
         gen_Y = G.forward(gen_in, "g1", attn=attn_g)
 
-        # D batch layout: [D1: B][D3: 5B][D2: B][D4: 5B]
-        xd = A.get_slack("d/x16", (12 * B, S, S, D.in_pitch), adt, D.pad)          # one 16-byte chunk per pixel (Discriminator.in_pitch) + a K-row of slack
         gen_rgb = A.get("g1/rgb", (B, S, S, 3))
         ops.yuv2rgb(gen_Y, cbcr, noise[:B], gen_rgb, xd[0:B], B, B, npix)                  # SHM.py:544-559
 
@@ -410,15 +424,38 @@ class ShmGANwithSSpecSeg:
         cyc_Y = G.forward(cyc_in, "cyc", attn=attn_g, parts=self.forward_parts)
         cyc_rgb = A.get("cyc/rgb", (5 * B, S, S, 3))
         ops.yuv2rgb(cyc_Y, cbcr, None, cyc_rgb, xd[B:6 * B], 5 * B, B, npix)
-        ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
-        for k in range(5):                                                                 # D(4) SHM.py:638-642
-            ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
+        if not d_real_early:
+            ops.pack_rgb16(orig[4], noise[B:2 * B], xd[6 * B:7 * B], B * npix)                 # D(2) SHM.py:563
+            for k in range(5):                                                                 # D(4) SHM.py:638-642
+                ops.pack_rgb16(orig[k], None, xd[(7 + k) * B:(8 + k) * B], B * npix)
+
+        # ---- image-space losses (L1, SSIM, NST: SHM.py:744-826) and their gradients wrt the two Y planes.  Nothing reads them before the
+        # G-loss backward leaves the discriminator (conv3x3_dgrad_sum1 below accumulates into dgen_y / dcyc_y), so in bf16 they run on the second
+        # stream beside the discriminator's forward pass and the G-loss backward through it (round 6: ~0.5 / 1.3 / 1.4 ms of SSIM and L1 passes
+        # were exposed per step at B = 8 / S = 512 B = 4 / B = 32); the main stream waits for `ev_img` where it needs them
+        il = A.get("loss/img", (32,), torch.float64)
+        dgen_y = A.get("loss/dgen_y", (B, S, S, 1))
+        dcyc_y = A.get("loss/dcyc_y", (5 * B, S, S, 1))
+        ws = self._img_ws(B)
+        optr = (C.c_void_p * 5)(*[t.data_ptr() for t in orig])
+        dptr = (C.c_void_p * 5)(*[t.data_ptr() for t in ds])
+        ev_img = None
+        if self.img_loss_on_lane and lane.stream is not None:
+            lane.submit(lambda: ops.image_losses(gen_rgb, cyc_rgb, cyc_Y, cbcr, optr, dptr, fmask, sf, il, dgen_y, dcyc_y, ws, B, S))
+            ev_img = lane.event()
+        else:
+            ops.image_losses(gen_rgb, cyc_rgb, cyc_Y, cbcr, optr, dptr, fmask, sf, il, dgen_y, dcyc_y, ws, B, S)
 
         # ---- D on all 12B images (noise + dropout on the D1 and D2 slices only)
         dparts = None
         if self.forward_parts > 1 and lane.stream is not None:     # fake half on the main stream, real half on the second one
             dparts = [(6 * B, 12 * B, lane.submit), (0, 6 * B, lambda fn: fn())]
-        rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)], parts=dparts, attn=attn_d, join=lane.join if dparts else None)
+        if d_real_early:
+            D.trunk_rows(0, 6 * B)                                  # the fake half, here; the real half is already under way on the second stream
+            torch.cuda.current_stream().wait_event(ev_dreal)
+            rf, cls = D.heads()
+        else:
+            rf, cls = D.forward(xd, keep, [(0, B, 0), (6 * B, B, B)], parts=dparts, attn=attn_d, join=lane.join if dparts else None)
         np_ = (S // 32) ** 2
 
         # ---- losses  SHM.py:669-844
@@ -428,13 +465,6 @@ class ShmGANwithSSpecSeg:
         drf_g = A.get("loss/drf_g", (6 * B, np_))
         ops.dhead_losses(rf, cls, dl, drf_d, dcls_d, drf_g, B, np_, T,
                          ops.XENT_TF_FUSED if self.xent_mode == "executed" else ops.XENT_INTENDED)
-        il = A.get("loss/img", (32,), torch.float64)
-        dgen_y = A.get("loss/dgen_y", (B, S, S, 1))
-        dcyc_y = A.get("loss/dcyc_y", (5 * B, S, S, 1))
-        ws = self._img_ws(B)
-        optr = (C.c_void_p * 5)(*[t.data_ptr() for t in orig])
-        dptr = (C.c_void_p * 5)(*[t.data_ptr() for t in ds])
-        ops.image_losses(gen_rgb, cyc_rgb, cyc_Y, cbcr, optr, dptr, fmask, sf, il, dgen_y, dcyc_y, ws, B, S)
         sl = A.get("loss/spec", (5,), torch.float64)                      # Spec_loss, logged only  SHM.py:792-806
         lane.submit(lambda: ops.spec_loss(cyc_Y, cbcr, dptr, self.specular_candidate, sl, B, npix))
 
@@ -458,6 +488,8 @@ class ShmGANwithSSpecSeg:
         dzd = D.backward_input_dz(6 * B, drf_g)
         weff_d = A.get("d/weff", (9, FD))
         ops.sum_input_channels(D.P.vars[0], 3, FD, 0b111, weff_d)
+        if ev_img is not None:
+            torch.cuda.current_stream().wait_event(ev_img)          # dgen_y / dcyc_y of the image losses
         ops.conv3x3_dgrad_sum1(dzd[0:B], FD, weff_d, dgen_y, 1, B, S, S, FD, 2, 1)
         ops.conv3x3_dgrad_sum1(dzd[B:6 * B], FD, weff_d, dcyc_y, 1, 5 * B, S, S, FD, 2, 1)
         dzg = G.backward(dcyc_y, "cyc", need_dx="dz")

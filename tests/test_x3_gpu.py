@@ -126,8 +126,72 @@ def test_x3_wgrad_is_exact_on_small_integers_and_keeps_specials():
     assert not np.isfinite(g[:, :, :, 4]).any() and np.isfinite(np.delete(g, 4, axis=3)).all()
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [
+    (2, 32, 32, 64, 128),       # one patch column of 16 output pixels, bottom / right padding in every patch
+    (3, 16, 64, 128, 64),       # two (ci) tiles, patches with a right-hand neighbour
+    (1, 64, 64, 64, 64),        # 32 patches: several stages per block
+    (2, 32, 32, 96, 80),        # ragged channel tiles
+    (5, 8, 32, 64, 64),         # blocks that cross image boundaries
+])
+def test_x3_wgrad_stride2_matches_the_oracle_and_the_exact_kernel(n, h, w, cin, cout):
+    """Round 6: the stride-2 layers (SHM.py:353-361; the Conv2DTranspose weight gradients of SHM.py:298-319 are the same product with the
+    operands' roles swapped) on the six-product kernel: wgrad_halo_x3_kernel<2, false, true>, patches of 2 x 16 OUTPUT pixels."""
+    ops = _ops()
+    rng = np.random.default_rng(160 + n)
+    ho, wo = h // 2, w // 2
+    x = rng.standard_normal((n, h, w, cin)) * np.exp(rng.standard_normal((n, h, w, cin)))
+    dy = rng.standard_normal((n, ho, wo, cout))
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    xr, dr = x.astype(np.float32).astype(np.float64), dy.astype(np.float32).astype(np.float64)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(xr), wt, 2), wt, nchw(dr))
+
+    def run(split, accumulate=0, dw=None):
+        ops.set_tuning("wgrad.f32_split", split)
+        if dw is None:
+            dw = torch.full((3, 3, cin, cout), 3.0, device="cuda")
+        ws = _ws(ops.conv2d_wgrad_workspace(n, ho, wo, cin, cout, 3))
+        ops.conv2d_wgrad(dev(x), None, 0, cin, 0, dev(dy), cout, dw, n, h, w, cin, cin, cout, 3, 2, accumulate, ws)
+        torch.cuda.synchronize()
+        return dw, ops.last_kernel()
+    got, k = run(1)
+    assert k == "wgrad_halo_x3_kernel<2, false, true>", k
+    exact, k0 = run(0)
+    assert k0 == "wgrad_halo_kernel<0, true>", k0
+    e3, e1 = rel_l2(host(got), ref.numpy()), rel_l2(host(exact), ref.numpy())
+    print(f"stride 2: rel-L2 against float64: six bf16 products {e3:.2e}, exact-fp32 MFMA {e1:.2e}")
+    assert e3 < TOL and e3 < 4 * e1 + 1e-7
+    a1, _ = run(1, accumulate=1, dw=got.clone())
+    a2, _ = run(1, accumulate=1, dw=got.clone())
+    assert torch.equal(a1, a2) and rel_l2(host(a1), 2 * ref.numpy()) < TOL
+
+
+def test_x3_wgrad_stride2_is_exact_on_small_integers():
+    rng = np.random.default_rng(161)
+    ops = _ops()
+    n, h, cin, cout = 2, 32, 64, 64
+    x = rng.integers(-(1 << 18) + 1, 1 << 18, (n, h, h, cin)).astype(np.float64)
+    dy = rng.integers(-1, 2, (n, h // 2, h // 2, cout)).astype(np.float64)
+    wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(st.conv2d_same(nchw(x), wt, 2), wt, nchw(dy))
+    ops.set_tuning("wgrad.f32_split", 1)
+    dw = torch.empty((3, 3, cin, cout), device="cuda")
+    ws = _ws(ops.conv2d_wgrad_workspace(n, h // 2, h // 2, cin, cout, 3))
+    ops.conv2d_wgrad(dev(x), None, 0, cin, 0, dev(dy), cout, dw, n, h, h, cin, cin, cout, 3, 2, 0, ws)
+    assert ops.last_kernel() == "wgrad_halo_x3_kernel<2, false, true>"
+    g = host(dw)
+    same = g == ref.numpy()
+    assert same.mean() > 0.98 and rel_l2(g, ref.numpy()) < 1e-7
+    # maps whose output width is not a multiple of 16 keep the exact kernel
+    x8 = dev(rng.standard_normal((n, 16, 16, cin)))
+    dy8 = dev(rng.standard_normal((n, 8, 8, cout)))
+    ws = _ws(ops.conv2d_wgrad_workspace(n, 8, 8, cin, cout, 3))
+    ops.conv2d_wgrad(x8, None, 0, cin, 0, dy8, cout, dw, n, 16, 16, cin, cin, cout, 3, 2, 0, ws)
+    assert ops.last_kernel() == "wgrad_halo_kernel<0, true>"
+
+
 def test_knob_leaves_other_launches_alone():
-    """Stride 2, 1x1, thin first layers, bf16 and the fused-normalisation form keep their kernels under "wgrad.f32_split" = 1."""
+    """Stride 2 on maps whose output width is not a multiple of 16, 1x1, thin first layers, bf16 and the fused-normalisation form keep their
+    kernels under "wgrad.f32_split" = 1."""
     ops = _ops()
     ops.set_tuning("wgrad.f32_split", 1)
     rng = np.random.default_rng(73)
