@@ -6,6 +6,9 @@
 //                   LDS, no memory traffic inside the loop.  Also stamps s_memtime / s_memrealtime around the loop: in-kernel clock =
 //                   d(memtime) / d(memrealtime) x 100 MHz (MI355X guide, "DVFS give-back" item 6).
 //   ceil_copy       the block's algorithmic bytes as a 16-byte-per-lane streaming copy (read n*H*W*64 bf16, write the same).
+//   ceil_copy_cfg   (round 6) the same copy in a chosen shape -- threads per block, 2 / 4 / 8 loads in flight per lane, blocks, plain or non-temporal
+//                   accesses: bench.py calibrates the shape once on a 2 GB buffer (the round-5 probe's fixed shape reached 4.9 TB/s where the
+//                   MI355X guide's float4 copy reaches 6.29) and copies the block's bytes with the best one.
 //
 // bench.py's north_star_block runs both in the process that times the product kernel, right after it, and prints
 // ceiling_us = max(mfma_us, copy_us) and frac_of_ceiling = ceiling_us / us.  Test infrastructure: nothing in shmgan_amd/ loads this library.
@@ -93,7 +96,39 @@ __global__ __launch_bounds__(256) void ceil_copy_kernel(const u32x4* __restrict_
     }
 }
 
+template <int U, bool NT>
+__global__ void ceil_copy_cfg_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += U * stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < n16) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < n16) {
+                if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+                else dst[i + u * stride] = v[u];
+            }
+    }
+}
+
 extern "C" {
+int ceil_copy_cfg(const void* src, void* dst, size_t bytes, int blocks, int threads, int unroll, int nt, void* stream) {
+    const u32x4* s = (const u32x4*)src;
+    u32x4* d = (u32x4*)dst;
+    const size_t n16 = bytes / 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (threads != 256 && threads != 512 && threads != 1024) return -2;
+    if (unroll == 8 && nt) hipLaunchKernelGGL((ceil_copy_cfg_kernel<8, true>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else if (unroll == 8) hipLaunchKernelGGL((ceil_copy_cfg_kernel<8, false>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else if (unroll == 4 && nt) hipLaunchKernelGGL((ceil_copy_cfg_kernel<4, true>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else if (unroll == 4) hipLaunchKernelGGL((ceil_copy_cfg_kernel<4, false>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else if (unroll == 2 && nt) hipLaunchKernelGGL((ceil_copy_cfg_kernel<2, true>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else if (unroll == 2) hipLaunchKernelGGL((ceil_copy_cfg_kernel<2, false>), dim3(blocks), dim3(threads), 0, st, s, d, n16);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 // mfmas_per_wave is rounded down to a multiple of 8; returns the number of MFMAs each wave issues (or < 0 on a launch error)
 int ceil_mfma_bf16(const void* ops, float* out, unsigned long long* stamps, int blocks, int mfmas_per_wave, void* stream) {
     const int iters = mfmas_per_wave / 8;
