@@ -507,6 +507,7 @@ struct InBwdArgs {               // g1, g2, a, dz: tensors of the kernels' eleme
     int nt;                      // apply pass: g1 is read for the last time -> non-temporal loads
     int n0, nbatch;              // sample chunking (in_bwd_impl): this launch covers samples [n0, n0 + gridDim.y) of nbatch
     int interleave;              // apply pass: tiles of pixels dealt round-robin over a sample's blocks ("elem.interleave")
+    int fold;                    // one-pass kernels: the launch's last group folds the staged bias gradient into dbias itself
 };
 
 // G2 is a template parameter: a run-time `if (k.g2)` between the loads makes hipcc wait for each load
@@ -872,6 +873,40 @@ __device__ __forceinline__ V coh_load(const V* p) { return __hip_atomic_load(p, 
 template <typename V>
 __device__ __forceinline__ void coh_store(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The launch's last group folds the staged bias gradient (round 6: dbias_fold_kernel was one more launch behind each of the step's ~44 one-pass
+// calls).  `staging` = f64 [batch][c], written by every group's last departer (its CB channels of its sample, coherent stores, acknowledged before
+// the group takes a ticket at `ticket`); the group whose ticket is the last adds the samples in dbias_fold_kernel's order -- four interleaved partial
+// sums, (s0 + s1) + (s2 + s3): the same bits as the separate launch -- into dbias, and leaves staging and ticket zero.  Called by all 256 threads of a
+// group's last departer, after its staging stores.
+__device__ __forceinline__ void fused_fold_dbias(double* __restrict__ staging, double* __restrict__ dbias, unsigned* __restrict__ ticket, int batch, int c,
+                                                 unsigned ngroups, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups;
+    __syncthreads();
+    if (!*s_flag) return;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        double sg[4] = {0.0, 0.0, 0.0, 0.0};
+        int i = 0;
+        for (; i + 8 <= batch; i += 8) {             // eight loads in flight (one at a time, 160 samples were 160 round trips)
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = coh_load(staging + (size_t)(i + j) * c + ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sg[j & 3] += v[j];                   // (i is a multiple of 8: (i + j) & 3 == j & 3)
+                coh_store(staging + (size_t)(i + j) * c + ch, 0.0);
+            }
+        }
+        for (; i < batch; ++i) {
+            sg[i & 3] += coh_load(staging + (size_t)i * c + ch);
+            coh_store(staging + (size_t)i * c + ch, 0.0);
+        }
+        dbias[ch] += (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    }
+    if (threadIdx.x == 0) coh_store(ticket, 0u);
+}
+
 template <bool G2>
 __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const InBwdArgs k, float* __restrict__ fpart, float* __restrict__ fres,
                                                                          unsigned* __restrict__ fsync, unsigned* __restrict__ ferr,
@@ -1130,10 +1165,12 @@ __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const In
     if (s_last) {                     // every block of the sample is through: the bias-gradient staging of the sample, then a clean scratch
         if (k.dbias) {
             const int RG = rowsum(prow0 + 2 * CB, CB / 2);
-            for (int ch = threadIdx.x; ch < CB; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch] = total(ch, CB / 2, RG);
+            for (int ch = threadIdx.x; ch < CB; ch += 256) coh_store(k.red + (size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch, total(ch, CB / 2, RG));
         }
         for (int i = threadIdx.x; i < CB * 2; i += 256) coh_store(res + i, 0.f);
         if (threadIdx.x < SHM_FUSED_FLAGS + 2) coh_store(sy + 32 * threadIdx.x, 0u);
+        // fold = 1: this launch also folds the staged bias gradient (no dbias_fold_kernel behind it); ferr[1] is the launch's group ticket
+        if (k.dbias && k.fold) fused_fold_dbias(k.red + (size_t)k.nbatch * k.c * 2, k.dbias, ferr + 1, k.nbatch, k.c, gridDim.y * gridDim.z, &s_last);
     }
 #ifdef SHM_FUSED_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1366,10 +1403,12 @@ __global__ __launch_bounds__(256, BPC) void in_bwd_fusedg_kernel(const InBwdArgs
     if (s_last) {
         if (k.dbias) {
             const int RG = rowsum(prow0 + 2 * CB, CB / 2);
-            for (int ch = threadIdx.x; ch < CB; ch += 256) k.red[(size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch] = total(ch, CB / 2, RG);
+            for (int ch = threadIdx.x; ch < CB; ch += 256) coh_store(k.red + (size_t)k.nbatch * k.c * 2 + (size_t)n * k.c + c0 + ch, total(ch, CB / 2, RG));
         }
         for (int i = threadIdx.x; i < CB * 2; i += 256) coh_store(res + i, 0.f);
         if (threadIdx.x < SHM_FUSED_FLAGS + 2) coh_store(sy + 32 * threadIdx.x, 0u);
+        // fold = 1: this launch also folds the staged bias gradient (no dbias_fold_kernel behind it); ferr[1] is the launch's group ticket
+        if (k.dbias && k.fold) fused_fold_dbias(k.red + (size_t)k.nbatch * k.c * 2, k.dbias, ferr + 1, k.nbatch, k.c, gridDim.y * gridDim.z, &s_last);
     }
 }
 
@@ -1588,6 +1627,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
         const int hold = shm_tune(SHM_TUNE_ELEM_FUSED_HOLD);          // 0 automatic, 1 the round-5 kernel only (g and a held), 2 the g-held kernel only
         const int ncb = c / cb;
         const size_t red_bytes = (size_t)batch * c * 3 * sizeof(double);
+        k.fold = keep ? 0 : 1;             // (the per-sample sums are wanted too -- SHM_NORM_SCALED's second term: the separate fold kernel copies them out)
         // round 6: g held, a streamed twice; slices of 32768 / CB pixels (sixteen pixel slots per thread), half the blocks per group.  Groups of up
         // to 512 blocks where twice that fits the device (the 512 x 512 x 64 maps of BASELINE configs[3]): the knob's default 256 bounds the round-5
         // kernel, this one takes 2 x its value
@@ -1610,7 +1650,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
             else hipLaunchKernelGGL((in_bwd_fusedg_kernel<2, 2, 4>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
             shm_set_last_kernel(fgv == 1 ? "in_bwd_fusedg_kernel<8, 8, 3>" : "in_bwd_fusedg_kernel<2, 2, 4>");
             SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);
-            if (dbias) {
+            if (dbias && !k.fold) {
                 hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, (double*)nullptr, keep);
                 SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
             }
@@ -1626,7 +1666,7 @@ static int in_bwd_impl(const char* who, const void* g1, int ldg1, const void* g2
             else hipLaunchKernelGGL((in_bwd_fused8_kernel<false>), gridf, dim3(256), 0, st, k, (float*)fscr, fres, fsync, ferr, g_abort_dev, g_abort_host, arrivals);
             shm_set_last_kernel(g2 ? "in_bwd_fused8_kernel<true>" : "in_bwd_fused8_kernel<false>");
             SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fused)", red, red_bytes, st);
-            if (dbias) {       // (the two sum planes in front of the staging were not used: nothing to clear)
+            if (dbias && !k.fold) {       // (the two sum planes in front of the staging were not used: nothing to clear)
                 hipLaunchKernelGGL(dbias_fold_kernel, dim3(shm_cdiv(c, 64)), dim3(256), 0, st, red + (size_t)batch * c * 2, dbias, batch, c, (double*)nullptr, keep);
                 SHM_LAUNCH_CHECK_CLEAR("shm_in_bwd(fold)", red, red_bytes, st);
             }
