@@ -226,8 +226,9 @@ def main():
             # HBM-side bytes are PMC counters: they need rocprofv3 --pmc passes of this same command, which cannot run inside the
             # timed process -- the figure is read from the committed distillate of those passes (tools/profile_round.sh ->
             # tools/pmc_traffic.py, profiles/README.md); `traffic_source` names the file
-            tags = ((["r05_f32x3"] if args.dtype == "f32x3" else []) + ["r05_f32", "r04_f32", "r03_f32", "r02_f32"] if args.dtype != "bf16" else
-                    (["r04_s512_b4_bf16", "r03_s512_b4_bf16", "r02_s512_b4_bf16"] if (S, B) == (512, 4) else ["r05_bf16", "r04_bf16", "r03_bf16", "r02_bf16"]))
+            tags = ((["r06_f32x3", "r05_f32x3"] if args.dtype == "f32x3" else []) + ["r06_f32", "r05_f32", "r04_f32", "r03_f32", "r02_f32"] if args.dtype != "bf16" else
+                    (["r06_s512_b4_bf16", "r05_s512_b4_bf16", "r04_s512_b4_bf16", "r03_s512_b4_bf16", "r02_s512_b4_bf16"] if (S, B) == (512, 4) else
+                     ["r06_b32_bf16", "r05_b32_bf16"] if (S, B) == (256, 32) else ["r06_bf16", "r05_bf16", "r04_bf16", "r03_bf16", "r02_bf16"]))
             tpath = next((ROOT / "profiles" / f"{t}_traffic_pmc.json" for t in tags if (ROOT / "profiles" / f"{t}_traffic_pmc.json").exists()),
                          ROOT / "profiles" / "none")
             if tpath.exists():
