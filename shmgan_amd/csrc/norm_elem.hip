@@ -1184,7 +1184,8 @@ __global__ __launch_bounds__(256, G2 ? 3 : 4) void in_bwd_fused8_kernel(const In
 // block holds its 64 KiB of g and a for ~23 us; 4 blocks per CU fill the register file: 768-1024 x 96 KiB of traffic per 23 us = 3.2-4.3 TB/s,
 // LABNOTES 11.6).  Here a block holds ONLY g (the gradient is dead after this kernel; the activation stays in HBM and the Infinity Cache): a slice
 // is 16 pixel slots per thread (32768 / CB pixels), g raw bf16 in 64 registers, and `a` is streamed through 16-byte transient registers twice --
-// phase 1 for sum g * (x - mean), phase 2 for the apply; the second read comes back from L2 / the Infinity Cache 20-30 us after the first.  The
+// phase 1 for sum g * (x - mean), phase 2 for the apply (the second read, 20-30 us after the first, was meant to hit the Infinity Cache; the
+// counters of profiles/r06_* say it comes from HBM: 1.38 x the algorithmic bytes -- the kernel is residency bound and faster all the same).  The
 // same 4 blocks per CU now cover 192 KiB of traffic each, and a barrier group has HALF the blocks (128 on the 256 x 256 x 64 maps: the last
 // arriver's row sums, 5.9 of 13.3 us there, halve; the 512 x 512 maps of BASELINE configs[3] get 512-block groups, which twice fit the chip).
 // The register budget decides the form: 64 (g) + 16 (sums) + 8 (means) leave room for TWO transient loads of `a` per batch at four blocks per CU
